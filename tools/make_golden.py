@@ -1,0 +1,259 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (build container only).
+
+Imports the unmodified hot-path files from /root/reference through tools/ref_stubs.py, runs
+them on seeded inputs/weights (CPU fp32) and stores inputs + expected outputs as small
+fixtures.  The reference's Python never travels to the GPU box -- only these vectors do.
+Re-run:  python tools/make_golden.py [--only NAME]
+Weights are produced by ciaosr_amd.init_utils.seeded_init_ (name-keyed generators); each
+fixture records the sha256 of the weights so RNG drift is detected instead of mis-compared.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from tools import ref_stubs                                   # noqa: E402
+from ciaosr_amd.init_utils import seeded_init_, synthetic_pair  # noqa: E402
+from ciaosr_amd.coords import make_coord, make_cell           # noqa: E402
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+SQRT6 = math.sqrt(6.0)
+
+
+def mlp_cfg(hidden):
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=list(hidden))
+    return mk(4, 3), mk(64, 64), mk(64, 64)
+
+
+def edsr_generator(ref, mid=64, blocks=16, hidden=(256,) * 4, eval_bsize=30000, **kw):
+    q, k, v = mlp_cfg(hidden)
+    enc = dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=mid, num_blocks=blocks)
+    return ref.LocalImplicitSREDSR(enc, q, k, v, eval_bsize=eval_bsize, **kw)
+
+
+def rdn_generator(ref, hidden=(256,) * 4, eval_bsize=30000):
+    q, k, v = mlp_cfg(hidden)
+    enc = dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
+               upscale_factor=4, num_layers=8, channel_growth=64)
+    return ref.LocalImplicitSRRDN(enc, q, k, v, eval_bsize=eval_bsize)
+
+
+def head_sd(model):
+    return {k: v.detach().clone() for k, v in model.state_dict().items()
+            if k.startswith('imnet_') or k.startswith('cs_attn')}
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = v
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **conv)
+    print(f'  wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)')
+
+
+def coords_for(h, w, scale):
+    ht, wt = round(h * scale), round(w * scale)
+    return make_coord((ht, wt)).unsqueeze(0), make_cell((ht, wt)).unsqueeze(0), (ht, wt)
+
+
+def randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_tiny_head(ref):
+    """C=8, hidden [32,32], LR 7x9 -> 19x24 (x2.7): odd H/W (reflect pad + crop), all weights stored."""
+    m = edsr_generator(ref, mid=8, blocks=1, hidden=(32, 32), eval_bsize=200).eval()
+    sha = seeded_init_(m, seed=11, gain=1.0, head_gain=SQRT6)
+    feat = randn((1, 8, 7, 9), 21)
+    coord, cell, (ht, wt) = coords_for(7, 9, 2.7)
+    with torch.no_grad():
+        nl = m.cs_attn(feat)
+        out = m.batched_predict([feat], coord, cell)
+    w = {('w.' + k): v for k, v in head_sd(m).items()}
+    save('tiny_head_s2p7', feature=feat, coord=coord, cell=cell, out=out, nonlocal_map=nl,
+         target=np.array([ht, wt]), sha=np.array(sha), eval_bsize=np.array(200), **w)
+    return out
+
+
+def gen_tiny_head_variants(ref):
+    """local_size 3 / 1, softmax_scale 2, no non-local: branch coverage of query_rgb."""
+    for tag, kw in (('ls3', dict(local_size=3)), ('ls1', dict(local_size=1)),
+                    ('nonl0', dict(non_local_attn=False)), ('sm2', dict(softmax_scale=2))):
+        m = edsr_generator(ref, mid=8, blocks=1, hidden=(32, 32), eval_bsize=None, **kw).eval()
+        sha = seeded_init_(m, seed=12, gain=1.0, head_gain=SQRT6)
+        feat = randn((1, 8, 6, 8), 22)
+        coord, cell, (ht, wt) = coords_for(6, 8, 2.5)
+        with torch.no_grad():
+            out = m.query_rgb([feat], coord, cell)
+        w = {('w.' + k): v for k, v in head_sd(m).items()}
+        save(f'tiny_head_{tag}', feature=feat, coord=coord, cell=cell, out=out, sha=np.array(sha),
+             target=np.array([ht, wt]), **w)
+
+
+def gen_head_c64(ref):
+    """Full-size dims (576/580/644/640), LR 48x48 x4: Q = 36864."""
+    m = edsr_generator(ref, mid=64, blocks=1).eval()
+    sha = seeded_init_(m, seed=0, gain=1.0, head_gain=SQRT6)
+    feat = randn((1, 64, 48, 48), 7)
+    coord, cell, (ht, wt) = coords_for(48, 48, 4)
+    with torch.no_grad():
+        nl = m.cs_attn(feat)
+        out = m.batched_predict([feat], coord, cell)
+    print('  head_c64_x4: per-query std', out.std(dim=1).flatten().tolist())
+    save('head_c64_x4', out=out[0], nonlocal_map=nl[0], sha=np.array(sha), feat_seed=np.array(7),
+         weight_seed=np.array(0), target=np.array([ht, wt]))
+
+
+def gen_head_c64_x3p3(ref):
+    """Non-integer scale with rounding ties: LR 48x48 -> 158x158."""
+    m = edsr_generator(ref, mid=64, blocks=1).eval()
+    sha = seeded_init_(m, seed=0, gain=1.0, head_gain=SQRT6)
+    feat = randn((1, 64, 48, 48), 7)
+    coord, cell, (ht, wt) = coords_for(48, 48, 3.3)
+    with torch.no_grad():
+        out = m.batched_predict([feat], coord, cell)
+    save('head_c64_x3p3', out=out[0], sha=np.array(sha), feat_seed=np.array(7), weight_seed=np.array(0),
+         target=np.array([ht, wt]))
+
+
+def gen_nearest_idx(ref):
+    """Per-axis nearest-index tables obtained from F.grid_sample on an index-valued map, for the
+    query coordinate and both shifted/clamped key coordinates (ciaosr_net.py:145,162-183)."""
+    out = {}
+    for (n, nt) in ((48, 158), (192, 634), (45, 148), (192, 768), (48, 192), (7, 19), (9, 24), (100, 231)):
+        ramp = torch.arange(n, dtype=torch.float32).view(1, 1, n, 1).expand(1, 1, n, 3).contiguous()
+        seq = make_coord((nt, 3))[:, 0].view(nt, 3)[:, 0]            # per-axis coordinate sequence
+        cell0 = torch.tensor(2.0 / nt)
+
+        def sample(c):
+            grid = torch.stack([torch.zeros_like(c), c], -1).view(1, 1, -1, 2)   # (x=0, y=c)
+            return F.grid_sample(ramp, grid, mode='nearest', align_corners=False).flatten().long()
+
+        t = (n - 1) / (1 - cell0)
+        r = 1 / t
+        minus = (seq + (-1.0 * r + 1e-6)).clamp(-1 + 1e-6, 1 - 1e-6)
+        plus = (seq + (1.0 * r + 1e-6)).clamp(-1 + 1e-6, 1 - 1e-6)
+        out[f'q_{n}_{nt}'] = sample(seq).numpy().astype(np.int32)
+        out[f'km_{n}_{nt}'] = sample(minus).numpy().astype(np.int32)
+        out[f'kp_{n}_{nt}'] = sample(plus).numpy().astype(np.int32)
+    save('nearest_idx', **out)
+
+
+def gen_csattn(ref):
+    for tag, (h, w) in (('48', (48, 48)), ('45x51', (45, 51))):
+        att = ref.CrossScaleAttention(channel=64, scale=[2]).eval()
+        sha = seeded_init_(att, seed=3, gain=1.5)
+        x = randn((1, 64, h, w), 31)
+        with torch.no_grad():
+            y = att(x)
+        print(f'  csattn_{tag}: out std {y.std():.4f}')
+        save(f'csattn_c64_{tag}', out=y[0], sha=np.array(sha), in_seed=np.array(31), weight_seed=np.array(3),
+             gain=np.array(1.5), shape=np.array([h, w]))
+    att = ref.CrossScaleAttention(channel=8, scale=[2]).eval()
+    seeded_init_(att, seed=4, gain=1.5)
+    for tag, (h, w) in (('10x12', (10, 12)), ('9x11', (9, 11)), ('7x8', (7, 8))):
+        x = randn((2, 8, h, w), 32)
+        with torch.no_grad():
+            y = att(x)
+        w_ = {('w.cs_attn.' + k): v for k, v in att.state_dict().items()}
+        save(f'csattn_c8_{tag}', x=x, out=y, **w_)
+
+
+def gen_head_c180(ref):
+    """SwinIR-width head (1620/1624/1804/1800): encoder replaced by a 180-channel EDSR stand-in
+    because only the feature width matters to the head."""
+    m = edsr_generator(ref, mid=180, blocks=1).eval()
+    sha = seeded_init_(m, seed=5, gain=1.0, head_gain=SQRT6)
+    feat = randn((1, 180, 24, 24), 8)
+    coord, cell, (ht, wt) = coords_for(24, 24, 3.3)
+    with torch.no_grad():
+        out = m.batched_predict([feat], coord, cell)
+    save('head_c180_x3p3', out=out[0], sha=np.array(sha), feat_seed=np.array(8), weight_seed=np.array(5),
+         target=np.array([ht, wt]))
+
+
+def _restorer(ref, gen_cfg_fn, test_cfg):
+    """Build the reference restorer around an already-built generator class config."""
+    raise NotImplementedError
+
+
+def gen_e2e(ref):
+    mean = (0.4488, 0.4371, 0.4040)
+    for tag, kind, scale in (('e2e_edsr_x2_48', 'edsr', 2), ('e2e_rdn_x4_48', 'rdn', 4)):
+        q, k, v = mlp_cfg((256,) * 4)
+        if kind == 'edsr':
+            gen = dict(type=ref.LocalImplicitSREDSR,
+                       encoder=dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16),
+                       imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+        else:
+            gen = dict(type=ref.LocalImplicitSRRDN,
+                       encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
+                                    upscale_factor=4, num_layers=8, channel_growth=64),
+                       imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+        test_cfg = ref.ConfigDict(scale=scale, tile=192, tile_overlap=32)
+        model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
+                           rgb_mean=mean, rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
+        sha = seeded_init_(model, seed=0, gain=1.25 if kind == 'edsr' else 1.6, head_gain=SQRT6)
+        lq, gt = synthetic_pair(48, 48, scale)
+        coord, cell, (ht, wt) = coords_for(48, 48, scale)
+        with torch.no_grad():
+            feat = model.generator.gen_feature((lq - torch.tensor(mean).view(1, 3, 1, 1)))[0]
+            res = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+        out = res['output']
+        print(f'  {tag}: feature std {feat.std():.3f}  out range [{out.min():.3f},{out.max():.3f}] '
+              f'std {out.std():.3f}  frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f}')
+        names = {k2: list(v2.shape) for k2, v2 in model.state_dict().items()}
+        with open(os.path.join(OUT, f'state_dict_names_{kind}.json'), 'w') as f:
+            json.dump(names, f, indent=0)
+        save(tag, lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(0),
+             gain=np.array(1.25 if kind == 'edsr' else 1.6), scale=np.array(scale))
+
+
+def gen_tiling(ref):
+    """clip_test index lists + E/W blending: LR 100x132, tile 48, overlap 16, x2, small EDSR."""
+    q, k, v = mlp_cfg((64, 64))
+    gen = dict(type=ref.LocalImplicitSREDSR,
+               encoder=dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=16, num_blocks=2),
+               imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+    test_cfg = ref.ConfigDict(scale=2, tile=48, tile_overlap=16)
+    model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040),
+                       rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
+    sha = seeded_init_(model, seed=9, gain=2.0, head_gain=SQRT6)
+    lq, gt = synthetic_pair(100, 132, 2)
+    coord, cell, _ = coords_for(100, 132, 2)
+    with torch.no_grad():
+        res = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+    out = res['output']
+    print(f'  tiling_small: out range [{out.min():.3f},{out.max():.3f}] std {out.std():.3f} frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f}')
+    w = {('w.' + k2): v2 for k2, v2 in model.state_dict().items()}
+    save('tiling_small', lq=lq, out=out, sha=np.array(sha), **w)
+
+
+ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, head_c64=gen_head_c64,
+           head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
+           head_c180=gen_head_c180, e2e=gen_e2e, tiling=gen_tiling)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', nargs='*', default=None)
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    ref = ref_stubs.load_reference()
+    for name, fn in ALL.items():
+        if args.only and name not in args.only:
+            continue
+        print(f'[{name}]')
+        fn(ref)
