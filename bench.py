@@ -1,0 +1,217 @@
+#!/usr/bin/env python
+"""bench.py -- HR Mpix/s of the CiaoSR LocalImplicitSR forward path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "C2"): RDN-CiaoSR (c64b16) x4, one 48x48 LR image -> 192x192,
+random-init weights (seeded, default-init scale), fp32 arithmetic, synthetic DIV2K-shaped input
+resident in HBM.  A step = CiaoSR.forward_test body: normalise -> clip_test (1 tile) -> RDN encoder
+-> cs_attn -> head -> de-normalise/clamp, device to device.
+N > 1 (weak scaling): one LR image of 48 x 48N pixels = N tiles of the same 48x48 unit
+(tile_overlap 0), tile t on rank t, outputs gathered to rank 0 over RCCL and blended in the
+reference order; value = final HR pixels of the whole image / max-over-ranks time.
+
+The JSON line also carries
+  roofline     algorithmic FLOPs (or bytes) of the dominant kernel per launch / its average launch
+               duration measured with HIP events inside the timed region, against the gfx950 peak
+  cpu_baseline the CPU oracle (op-for-op port of the reference, per-chunk cs_attn recompute included)
+               timed on this host's cores on the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0           # HBM3E spec
+
+
+def rdn_ciaosr(test_cfg):
+    from ciaosr_amd import CiaoSR, LocalImplicitSRRDN
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[256, 256, 256, 256])
+    gen = dict(type=LocalImplicitSRRDN,
+               encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
+                            upscale_factor=4, num_layers=8, channel_growth=64),
+               imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
+    return CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
+                  rgb_mean=(0.4488, 0.4371, 0.4040), rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
+
+
+def kernel_work(tag, Q, HW, C=64, hidden=256, J=4):
+    """Algorithmic work of ONE launch of kernel `tag` at this workload: (amount, 'flop'|'byte')."""
+    D, Dv, R = 9 * C, 10 * C, Q * J
+    table = {
+        'mlp_hidden': (2.0 * R * hidden * hidden, 'flop'),
+        'mlp_out_k': (2.0 * R * hidden * D, 'flop'),
+        'mlp_out_v': (2.0 * R * hidden * Dv, 'flop'),
+        'mlp_in_q': (2.0 * Q * Dv * hidden, 'flop'),
+        'mlp_hidden_q': (2.0 * Q * hidden * hidden, 'flop'),
+        'head_table': (2.0 * HW * hidden * (D + Dv) / 2, 'flop'),
+        'csa_scores': (2.0 * HW * (HW / 4) * 4.5 * C, 'flop'),
+        'csa_attn_v': (2.0 * HW * (HW / 4) * 36 * C, 'flop'),
+        # K4, SURVEY 8(d): wk 4*D*4 + wv 4*Dv*4 + z Dv*4 + coords 16 B per query (+ amortised feature)
+        'local_attention': (Q * (4.0 * J * D + 4.0 * J * Dv + 4.0 * Dv + 16) + 2.0 * C * 4 * HW, 'byte'),
+        'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),
+    }
+    return table.get(tag)
+
+
+def cpu_baseline(scale=4):
+    """Oracle (port of the reference, configured like it) on this host's CPU cores, same workload."""
+    from oracle import ciaosr_oracle as orc          # checker / baseline only
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32))
+    seeded_init_(model, seed=0, gain=1.0)
+    params = {k[len('generator.'):]: v.detach() for k, v in model.state_dict().items()}
+    lq, _ = synthetic_pair(48, 48, scale)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    for i in range(4):                              # 1 warm-up + 3 timed, ~3 s each on 8 cores
+        t0 = time.perf_counter()
+        out = orc.forward_test(lq, None, None, params, scale=scale, tile=192, tile_overlap=32)
+        times.append(time.perf_counter() - t0)
+        if sum(times) > 45:
+            break
+    t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
+    return dict(value=out.shape[-1] * out.shape[-2] / 1e6 / t, unit='Mpix/s', cores=torch.get_num_threads(),
+                kind='port', sample=f'same workload (1 LR 48x48 -> 192x192 image), median of {len(times) - 1} '
+                f'runs after 1 warm-up, {t * 1e3:.0f} ms/img, torch CPU fp32, reference-style per-chunk cs_attn')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+    assert world == args.gpus, f'WORLD_SIZE {world} != --gpus {args.gpus}'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from ciaosr_amd import hip_ops, _lib
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    from ciaosr_amd.tile_shard import clip_test_distributed
+    _lib.load()
+
+    scale, lr = 4, 48
+    test_cfg = dict(scale=scale, tile=192, tile_overlap=32) if world == 1 else dict(scale=scale, tile=lr, tile_overlap=0)
+    model = rdn_ciaosr(test_cfg)
+    seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
+    model = model.to(dev)
+    lq, _ = synthetic_pair(lr, lr * world, scale)     # identical on every rank (CPU-generated)
+    lq = lq.to(dev)
+    out_pixels = (lr * scale) * (lr * world * scale)
+
+    def step():
+        if world == 1:
+            return model.restore(lq)
+        x = model.normalize(lq)
+        pred = clip_test_distributed(model, x, rank, world)
+        if rank == 0:
+            return hip_ops.denorm_clamp(pred[0].contiguous(), lr * scale, lr * world * scale, model.rgb_mean,
+                                        model.rgb_std)
+        return None
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # warm-up; the last warm-up step is fully profiled to find the dominant kernel
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    with hip_ops.profile():
+        step()
+        torch.cuda.synchronize(dev)
+    prof_all = hip_ops.profile.results()
+    dominant = max(prof_all, key=lambda k: prof_all[k]['total_ms']) if prof_all else None
+
+    # timed region: only the dominant kernel carries events
+    lib = _lib.load()
+    lib.ciaosr_prof_filter(dominant.encode() if dominant else None)
+    lib.ciaosr_prof_reset()
+    lib.ciaosr_prof_enable(1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.ciaosr_prof_enable(0)
+    prof_dom = hip_ops.profile.results()
+    lib.ciaosr_prof_filter(None)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        roof = None
+        if dominant and dominant in prof_dom:
+            Q, HW = (lr * scale) ** 2, lr * lr
+            work = kernel_work(dominant, Q, HW)
+            avg_ms = prof_dom[dominant]['avg_ms']
+            if work:
+                amount, kind = work
+                if kind == 'flop':
+                    ach = amount / (avg_ms * 1e-3) / 1e12
+                    roof = dict(bound='mfma', achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
+                else:
+                    ach = amount / (avg_ms * 1e-3) / 1e9
+                    roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+                roof.update(kernel=dominant, avg_launch_ms=round(avg_ms, 5),
+                            launches=prof_dom[dominant]['launches'],
+                            share_of_step=round(prof_all[dominant]['total_ms'] /
+                                                max(sum(v['total_ms'] for v in prof_all.values()), 1e-9), 3))
+                la = prof_all.get('local_attention')
+                if la:                      # north-star side metric: K4 against the HBM roofline
+                    b = kernel_work('local_attention', Q, HW)[0]
+                    roof['local_attention_hbm_frac'] = round(b / (la['avg_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+        line = {
+            'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
+            'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
+            'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init '
+                                   'weights, fp32' + ('' if world == 1 else f'; one {lr}x{lr * world} LR image, '
+                                   f'{world} tiles sharded one per GPU, RCCL all_gather + rank-0 blend'),
+                       'lr': [lr, lr * world], 'scale': scale, 'queries_per_step': out_pixels,
+                       'parallelism': f'tile-shard x{world}'},
+            'roofline': roof,
+            'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
+                prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(scale)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

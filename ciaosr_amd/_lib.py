@@ -1,0 +1,99 @@
+"""ctypes binding of libciaosr_hip.so (the C ABI declared in include/ciaosr_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C ciaosr_amd/csrc`.  There is
+no CPU fallback: if the shared object is missing, or an entry point returns an error code, the
+caller gets an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libciaosr_hip.so')
+MAX_LAYERS = 8
+
+ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+
+
+class CiaoSRHipError(RuntimeError):
+    pass
+
+
+class MlpT(C.Structure):
+    _fields_ = [('n_layers', C.c_int), ('in_dim', C.c_int), ('width', C.c_int * MAX_LAYERS),
+                ('weight', C.c_void_p * MAX_LAYERS), ('ld', C.c_int * MAX_LAYERS),
+                ('bias', C.c_void_p * MAX_LAYERS)]
+
+
+class HeadWeightsT(C.Structure):
+    _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('local_size', C.c_int),
+                ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT)]
+
+
+class CsAttnWeightsT(C.Structure):
+    _fields_ = [('channels', C.c_int),
+                ('w_match1', C.c_void_p), ('b_match1', C.c_void_p), ('slope_match1', C.c_float),
+                ('w_match2', C.c_void_p), ('b_match2', C.c_void_p), ('slope_match2', C.c_float),
+                ('w_assembly', C.c_void_p), ('b_assembly', C.c_void_p), ('slope_assembly', C.c_float),
+                ('w_down', C.c_void_p), ('b_down', C.c_void_p),
+                ('escape_nan', C.c_float), ('softmax_scale', C.c_float)]
+
+
+_P, _I, _F, _S = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); kept in sync with include/ciaosr_hip.h (tests/test_abi.py checks both ways)
+SIGNATURES = {
+    'ciaosr_version': (_I, []),
+    'ciaosr_error_string': (C.c_char_p, [_I]),
+    'ciaosr_prof_enable': (_I, [_I]),
+    'ciaosr_prof_filter': (_I, [C.c_char_p]),
+    'ciaosr_prof_reset': (_I, []),
+    'ciaosr_prof_collect': (_I, []),
+    'ciaosr_prof_get': (_I, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
+    'ciaosr_prof_names': (_I, [C.c_char_p, _I]),
+    'ciaosr_nchw_to_hwc_f32': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'ciaosr_hwc_to_nchw_f32': (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    'ciaosr_gemm_f32': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _I, _F, _P]),
+    'ciaosr_patch_rows_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P]),
+    'ciaosr_cs_attn_workspace_bytes': (_S, [_I, _I, _I]),
+    'ciaosr_cs_attn_f32': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _P, _S, _P]),
+    'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
+    'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
+    'ciaosr_head_workspace_bytes': (_S, [_I, _I, C.POINTER(HeadWeightsT), _I]),
+    'ciaosr_head_forward_f32': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
+                                     _I, _I, _P, _P, _S, _P]),
+    'ciaosr_normalize_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
+    'ciaosr_denorm_clamp_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
+    'ciaosr_tile_blend_f32': (_I, [_P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
+    'ciaosr_tile_finalize_f32': (_I, [_P, _P, _P, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared object (once).  Raises CiaoSRHipError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CiaoSRHipError(
+            f'{LIB_PATH} not found: build the HIP extension first '
+            f'(python -c "import __graft_entry__ as g; g.build()" or make -C ciaosr_amd/csrc). '
+            f'There is no CPU fallback for the product path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ciaosr_error_string(rc).decode()
+        raise CiaoSRHipError(f'{what} failed: {msg} (code {rc})')
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,107 @@
+// CrossScaleAttention for scale 2 (arch_csnln.py:430-532) as a sequence of launches on one stream.
+//
+//   xp   = reflect-pad to even H,W                                   pad_reflect          (:444-449)
+//   E    = PReLU(conv1x1_assembly(xp)),  M = PReLU(conv1x1_match1(xp))   gemm (MFMA)      (:452-453)
+//   R    = PReLU(conv1x1_match2(avgpool2(xp)))                       avgpool2 + gemm      (:474-475)
+//   Qp   = 3x3 patches of M (zero pad 1)            [HpWp][9C/2]     patch_rows           (:498-499)
+//   Kn   = L2-normalised 3x3 patches of R           [L][9C/2]        patch_rows(norm)     (:476-496)
+//   V    = 6x6 stride-2 patches of E (zero pad 2)   [L][36C]         patch_rows           (:462-469)
+//   S    = 10 * Qp . Kn^T                           [HpWp][L]        gemm NT (MFMA)       (:499-500)
+//   P    = softmax_L(S)                                               softmax_rows         (:505)
+//   O    = P . V                                     [HpWp][36C]      gemm NN (MFMA)       (:511)
+//   Y    = fold(O) (gather form, stride 2, pad 2)    [2Hp][2Wp][C]    fold                 (:511)
+//   out  = (conv3x3 s2 p1 (Y) + b) / 6, cropped      [H][W][C]        patch_rows + gemm    (:516-526)
+//
+// The score matrix is materialised in HBM (1.36 GB at the 192x192 tile: < 1 % of 288 GB and two
+// passes at HBM speed, against 1.76 TFLOP of MFMA work).
+#include "ops.h"
+
+namespace ciaosr {
+
+struct CsaPlan {
+    int H, W, C, Hp, Wp, L, Lld, Ch;
+    size_t n_xp, n_E, n_M, n_x2, n_R, n_Qp, n_Kn, n_V, n_S, n_O, n_Y, n_Yp;
+};
+
+static CsaPlan csa_plan(int H, int W, int C) {
+    CsaPlan p;
+    p.H = H; p.W = W; p.C = C; p.Ch = C / 2;
+    p.Hp = H + (H & 1); p.Wp = W + (W & 1);
+    p.L = (p.Hp / 2) * (p.Wp / 2);
+    p.Lld = (int)round_up(p.L, 4);
+    const size_t HW = (size_t)p.Hp * p.Wp;
+    p.n_xp = HW * C;
+    p.n_E = HW * C;
+    p.n_M = HW * p.Ch;
+    p.n_x2 = (size_t)p.L * C;
+    p.n_R = (size_t)p.L * p.Ch;
+    p.n_Qp = HW * 9 * p.Ch;
+    p.n_Kn = (size_t)p.L * 9 * p.Ch;
+    p.n_V = (size_t)p.L * 36 * C;
+    p.n_S = HW * p.Lld;
+    p.n_O = HW * 36 * C;
+    p.n_Y = 4 * HW * C;
+    p.n_Yp = (size_t)H * W * 9 * C;
+    return p;
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+extern "C" size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C) {
+    const CsaPlan p = csa_plan(H, W, C);
+    const size_t n = p.n_xp + p.n_E + p.n_M + p.n_x2 + p.n_R + p.n_Qp + p.n_Kn + p.n_V + p.n_S + p.n_O + p.n_Y + p.n_Yp;
+    return n * sizeof(float) + 16 * 256;
+}
+
+extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                                  float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream_) {
+    CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
+    const int C = w->channels;
+    CIAOSR_CHECK_ARG(C >= 8 && (C & 7) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
+    hipStream_t s = (hipStream_t)stream_;
+    const CsaPlan p = csa_plan(H, W, C);
+    Arena ar(workspace, workspace_bytes);
+    float* xp = ar.take<float>(p.n_xp);
+    float* E = ar.take<float>(p.n_E);
+    float* M = ar.take<float>(p.n_M);
+    float* x2 = ar.take<float>(p.n_x2);
+    float* R = ar.take<float>(p.n_R);
+    float* Qp = ar.take<float>(p.n_Qp);
+    float* Kn = ar.take<float>(p.n_Kn);
+    float* V = ar.take<float>(p.n_V);
+    float* S = ar.take<float>(p.n_S);
+    float* O = ar.take<float>(p.n_O);
+    float* Y = ar.take<float>(p.n_Y);
+    float* Yp = ar.take<float>(p.n_Yp);
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+
+    const int HWp = p.Hp * p.Wp;
+    int rc;
+#define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    RUN(pad_reflect(feat_hwc, ld_feat, H, W, C, xp, p.Hp, p.Wp, s));
+    RUN(gemm_f32(xp, C, w->w_assembly, C, false, E, C, w->b_assembly, HWp, C, C, 1.f, CIAOSR_ACT_PRELU,
+                 w->slope_assembly, s, "csa_conv1x1"));
+    RUN(gemm_f32(xp, C, w->w_match1, C, false, M, p.Ch, w->b_match1, HWp, p.Ch, C, 1.f, CIAOSR_ACT_PRELU,
+                 w->slope_match1, s, "csa_conv1x1"));
+    RUN(avgpool2(xp, p.Hp, p.Wp, C, x2, s));
+    RUN(gemm_f32(x2, C, w->w_match2, C, false, R, p.Ch, w->b_match2, p.L, p.Ch, C, 1.f, CIAOSR_ACT_PRELU,
+                 w->slope_match2, s, "csa_conv1x1"));
+    RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
+    RUN(patch_rows(R, p.Ch, p.Hp / 2, p.Wp / 2, p.Ch, 3, 1, 1, p.Hp / 2, p.Wp / 2, Kn, 9 * p.Ch, 1, w->escape_nan, s,
+                   "csa_patch_k"));
+    RUN(patch_rows(E, C, p.Hp, p.Wp, C, 6, 2, 2, p.Hp / 2, p.Wp / 2, V, 36 * C, 0, 0.f, s, "csa_patch_v"));
+    RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
+                 CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
+    RUN(softmax_rows(S, HWp, p.L, p.Lld, s));
+    RUN(gemm_f32(S, p.Lld, V, 36 * C, true, O, 36 * C, nullptr, HWp, 36 * C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, s,
+                 "csa_attn_v"));
+    RUN(fold(O, 36 * C, p.Hp, p.Wp, C, Y, s));
+    // down conv 3x3 stride 2 pad 1 on Y [2Hp][2Wp][C], only for the H x W output pixels kept by the crop
+    RUN(patch_rows(Y, C, 2 * p.Hp, 2 * p.Wp, C, 3, 2, 1, H, W, Yp, 9 * C, 0, 0.f, s, "csa_patch_down"));
+    RUN(gemm_f32(Yp, 9 * C, w->w_down, 9 * C, false, out, ld_out, w->b_down, H * W, C, 9 * C, 1.0f / 6.0f,
+                 CIAOSR_ACT_NONE, 0.f, s, "csa_down"));
+#undef RUN
+    return CIAOSR_OK;
+}

@@ -1,0 +1,230 @@
+// Exact-fp32 MFMA GEMM for gfx950:  C = act((A . B^T + bias) * alpha)
+//
+// v_mfma_f32_32x32x2_f32 (64 cycles/SIMD, 157 TFLOP/s chip peak, bitwise an fmaf chain).
+// Tile 128x128x32, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA tiles
+// (64 accumulator VGPRs).  A and B tiles are staged through LDS with a register prefetch of the
+// next K-tile and two LDS buffers (one barrier per K-tile).  LDS rows are padded to 36 floats so
+// the per-lane float4 fragment reads (ds_read_b128) are bank-conflict free; one float4 feeds four
+// MFMAs because the k index inside a fragment is free to be permuted consistently on A and B:
+// lane (i = l&31, h = l>>5) holds k = 8j + 4h + e for MFMA e of chunk j.
+//
+// Replaces torch addmm / conv2d(1x1) / conv_transpose2d-as-GEMM of the reference
+// (mlp_refiner.py:79-89, arch_csnln.py:452-453,475,499-500,511,516).
+#include "common.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDS_A = BK + 4;   // 36 floats / row (NT layouts)
+constexpr int LDS_BKN = BN + 4; // 132 floats / row for the [k][n] image
+constexpr int A_TILE = BM * LDS_A;                                        // 4608 floats
+constexpr int B_TILE = (BN * LDS_A > BK * LDS_BKN) ? BN * LDS_A : BK * LDS_BKN;  // 4608
+
+struct GemmP {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K, lda, ldb, ldc;
+    float alpha, slope;
+    int act;
+    int tiles_n, n_wg;
+};
+
+__device__ __forceinline__ float4 ld4_guard(const float* p, int k, int K) {
+    // p points at element k of a row; zero-fill past K (K need not be a multiple of 4)
+    if (k + 3 < K) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < K) v.x = p[0];
+    if (k + 1 < K) v.y = p[1];
+    if (k + 2 < K) v.z = p[2];
+    return v;
+}
+
+template <bool B_KN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][A_TILE]
+    float* Bs = smem + 2 * A_TILE;     // [2][B_TILE]
+
+    // XCD-aware bijective remap: each XCD (bid % 8) walks a contiguous run of tiles, and
+    // consecutive tiles share the A row-block, so A panels are re-read from that XCD's L2.
+    const int bid = blockIdx.x;
+    const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int m0 = (lid / p.tiles_n) * BM;
+    const int n0 = (lid % p.tiles_n) * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    float4 ra[4], rb[4];
+    const int nk = (p.K + BK - 1) / BK;
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int idx = t + 256 * s;
+            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int gm = m0 + r, gk = k0 + c4;
+            ra[s] = (gm < p.M && gk < p.K) ? ld4_guard(p.A + (size_t)gm * p.lda + gk, gk, p.K)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!B_KN) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int idx = t + 256 * s;
+                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                const int gn = n0 + r, gk = k0 + c4;
+                rb[s] = (gn < p.N && gk < p.K) ? ld4_guard(p.B + (size_t)gn * p.ldb + gk, gk, p.K)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int idx = t + 256 * s;
+                const int kr = idx >> 5, n4 = (idx & 31) * 4;
+                const int gk = k0 + kr, gn = n0 + n4;
+                rb[s] = (gk < p.K && gn < p.N) ? ld4_guard(p.B + (size_t)gk * p.ldb + gn, gn, p.N)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* a = As + buf * A_TILE;
+        float* b = Bs + buf * B_TILE;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int idx = t + 256 * s;
+            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(a + r * LDS_A + c4) = ra[s];
+        }
+        if (!B_KN) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int idx = t + 256 * s;
+                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                *reinterpret_cast<float4*>(b + r * LDS_A + c4) = rb[s];
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int idx = t + 256 * s;
+                const int kr = idx >> 5, n4 = (idx & 31) * 4;
+                *reinterpret_cast<float4*>(b + kr * LDS_BKN + n4) = rb[s];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const float* a = As + cur * A_TILE + (wm * 64 + li) * LDS_A + 4 * lh;
+        const float* b = B_KN ? (Bs + cur * B_TILE + (4 * lh) * LDS_BKN + wn * 64 + li)
+                              : (Bs + cur * B_TILE + (wn * 64 + li) * LDS_A + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < BK / 8; ++j) {
+            float4 fa[2], fb[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                fa[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * LDS_A + 8 * j);
+            if (!B_KN) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    fb[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * LDS_A + 8 * j);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float* bb = b + (8 * j) * LDS_BKN + ni * 32;
+                    fb[ni] = make_float4(bb[0], bb[LDS_BKN], bb[2 * LDS_BKN], bb[3 * LDS_BKN]);
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int col = n0 + wn * 64 + ni * 32 + li;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= p.M) continue;
+                float v = (acc[mi][ni][r] + bv) * p.alpha;
+                if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
+                p.C[(size_t)row * p.ldc + col] = v;
+            }
+        }
+    }
+}
+
+int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc,
+             const float* bias, int M, int N, int K, float alpha, int act, float slope,
+             hipStream_t stream, const char* tag) {
+    if (M <= 0 || N <= 0) return CIAOSR_OK;
+    CIAOSR_CHECK_ARG(K > 0 && A && B && C);
+    CIAOSR_CHECK_ARG((lda & 3) == 0 && (ldb & 3) == 0);
+    CIAOSR_CHECK_ARG(aligned16(A) && aligned16(B));
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.slope = slope; p.act = act;
+    p.tiles_n = ceil_div(N, BN);
+    p.n_wg = ceil_div(M, BM) * p.tiles_n;
+    const size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);
+    ProfScope prof(tag ? tag : (b_kn ? "gemm_f32_nn" : "gemm_f32_nt"), stream);
+    static bool attr_done = false;
+    if (!attr_done) {
+        allow_big_lds(gemm_f32_kernel<true>, smem);
+        allow_big_lds(gemm_f32_kernel<false>, smem);
+        attr_done = true;
+    }
+    if (b_kn)
+        hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(p.n_wg), dim3(256), smem, stream, p);
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(p.n_wg), dim3(256), smem, stream, p);
+    return launch_status("gemm_f32");
+}
+
+}  // namespace ciaosr
+
+extern "C" int ciaosr_gemm_f32(const float* A, int lda, const float* B, int ldb, int b_is_kn, float* C,
+                               int ldc, const float* bias, int M, int N, int K, float alpha, int act,
+                               float slope, void* stream) {
+    return ciaosr::gemm_f32(A, lda, B, ldb, b_is_kn != 0, C, ldc, bias, M, N, K, alpha, act, slope,
+                            (hipStream_t)stream, nullptr);
+}

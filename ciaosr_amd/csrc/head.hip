@@ -1,0 +1,171 @@
+// LocalImplicitSRNet.forward minus the encoder (ciaosr_net.py:88-248): one C entry point that
+// runs unfold -> cs_attn -> layer-1 tables -> [per work-chunk: rows, MLP chains, local attention,
+// decode] on one stream.  Staged form: every stage is its own kernel with a clean roofline.
+#include "ops.h"
+
+namespace ciaosr {
+
+struct HeadPlan {
+    int H, W, C, Cn, D, Dv, J, HW;
+    int wk0, wv0;            // layer-0 widths
+    int wmax;                // widest hidden activation among k / v / q chains
+    int qc;                  // queries per work-chunk
+    size_t csa_bytes;
+};
+
+static int n_samples(int local_size) { return local_size == 1 ? 1 : (local_size == 2 ? 4 : 9); }
+
+static HeadPlan head_plan(int H, int W, const ciaosr_head_weights_t* w, int Q) {
+    HeadPlan p;
+    p.H = H; p.W = W; p.C = w->channels; p.Cn = w->nonlocal_channels;
+    p.D = 9 * p.C; p.Dv = p.D + p.Cn; p.J = n_samples(w->local_size); p.HW = H * W;
+    p.wk0 = w->k.width[0];
+    p.wv0 = w->v.width[0];
+    int wm = 4;
+    for (int i = 0; i + 1 < w->k.n_layers; ++i) wm = wm > w->k.width[i] ? wm : w->k.width[i];
+    for (int i = 0; i + 1 < w->v.n_layers; ++i) wm = wm > w->v.width[i] ? wm : w->v.width[i];
+    for (int i = 0; i + 1 < w->q.n_layers; ++i) wm = wm > w->q.width[i] ? wm : w->q.width[i];
+    p.wmax = wm;
+    p.qc = Q < 65536 ? Q : 65536;
+    p.csa_bytes = p.Cn > 0 ? ciaosr_cs_attn_workspace_bytes(H, W, p.C) : 0;
+    return p;
+}
+
+static size_t head_ws_bytes(const HeadPlan& p) {
+    const size_t R = (size_t)p.qc * p.J;
+    size_t n = 0;
+    n += (size_t)p.HW * p.Dv;                 // U
+    n += (size_t)p.HW * (p.wk0 + p.wv0);      // tables
+    n += 2 * R * p.wmax;                      // ping-pong activations
+    n += R * p.wv0;                           // Hv (layer-1 rows of the value chain, kept while the key chain runs)
+    n += R * p.D + R * p.Dv;                  // WK, WV
+    n += (size_t)p.qc * p.Dv;                 // Z
+    n += (size_t)p.qc + R;                    // q_idx, k_idx (ints, same size as float)
+    return n * sizeof(float) + p.csa_bytes + 32 * 256;
+}
+
+static bool mlp_ok(const ciaosr_mlp_t& m) {
+    if (m.n_layers < 1 || m.n_layers > CIAOSR_MAX_LAYERS) return false;
+    for (int i = 0; i < m.n_layers; ++i)
+        if (!m.weight[i] || !m.bias[i] || (m.ld[i] & 3) != 0 || m.width[i] <= 0) return false;
+    return true;
+}
+
+// layers 1 .. n-1 of an MLP on rows already holding the layer-0 activations.
+// Returns the buffer holding the result; the last layer writes to `last_out` (ld_last) with no ReLU.
+static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA, float* bufB, float* last_out,
+                    int ld_last, long rows, hipStream_t s, const char* tag_hidden, const char* tag_out) {
+    const float* cur = h0;
+    int ld_cur = ld0;
+    float* pp[2] = {bufA, bufB};
+    int flip = 0;
+    for (int i = 1; i < m.n_layers; ++i) {
+        const bool last = (i == m.n_layers - 1);
+        float* dst = last ? last_out : pp[flip];
+        const int ldd = last ? ld_last : m.width[i];
+        int rc = gemm_f32(cur, ld_cur, m.weight[i], m.ld[i], false, dst, ldd, m.bias[i], (int)rows, m.width[i],
+                          m.width[i - 1], 1.f, last ? CIAOSR_ACT_NONE : CIAOSR_ACT_RELU, 0.f, s,
+                          last ? tag_out : tag_hidden);
+        if (rc != CIAOSR_OK) return rc;
+        cur = dst;
+        ld_cur = ldd;
+        flip ^= 1;
+    }
+    return CIAOSR_OK;
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+extern "C" size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w, int Q) {
+    if (!w || H <= 0 || W <= 0 || Q <= 0) return 0;
+    return head_ws_bytes(head_plan(H, W, w, Q));
+}
+
+extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                                       const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                                       const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                                       void* workspace, size_t workspace_bytes, void* stream_) {
+    CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
+    CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
+    CIAOSR_CHECK_ARG(w->local_size >= 1 && w->local_size <= 3 && w->softmax_scale != 0.f);
+    CIAOSR_CHECK_ARG(mlp_ok(w->q) && mlp_ok(w->k) && mlp_ok(w->v));
+    CIAOSR_CHECK_ARG((w->nonlocal_channels > 0) == (csattn != nullptr));
+    hipStream_t s = (hipStream_t)stream_;
+    const HeadPlan p = head_plan(H, W, w, Q);
+    // dims wiring of LocalImplicitSRNet.__init__ (ciaosr_net.py:61-76)
+    CIAOSR_CHECK_ARG(w->k.in_dim == p.D + 4 && w->k.width[w->k.n_layers - 1] == p.D);
+    CIAOSR_CHECK_ARG(w->v.in_dim == p.Dv + 4 && w->v.width[w->v.n_layers - 1] == p.Dv);
+    CIAOSR_CHECK_ARG(w->q.in_dim == p.Dv && w->q.width[w->q.n_layers - 1] == 3);
+    CIAOSR_CHECK_ARG(w->k.n_layers >= 2 && w->v.n_layers >= 2 && w->q.n_layers >= 2);
+    CIAOSR_CHECK_ARG((p.wk0 & 3) == 0 && (p.wv0 & 3) == 0);
+    if (csattn) CIAOSR_CHECK_ARG(csattn->channels == p.C && p.Cn == p.C);
+    if (workspace_bytes < head_ws_bytes(p)) return CIAOSR_ERR_WORKSPACE;
+
+    Arena ar(workspace, workspace_bytes);
+    const size_t R = (size_t)p.qc * p.J;
+    float* U = ar.take<float>((size_t)p.HW * p.Dv);
+    float* Tk = ar.take<float>((size_t)p.HW * p.wk0);
+    float* Tv = ar.take<float>((size_t)p.HW * p.wv0);
+    float* bufA = ar.take<float>(R * p.wmax);
+    float* bufB = ar.take<float>(R * p.wmax);
+    float* Hv = ar.take<float>(R * p.wv0);
+    float* WK = ar.take<float>(R * p.D);
+    float* WV = ar.take<float>(R * p.Dv);
+    float* Z = ar.take<float>((size_t)p.qc * p.Dv);
+    int* q_idx = ar.take<int>(p.qc);
+    int* k_idx = ar.take<int>(R);
+    char* csa_ws = ar.take<char>(p.csa_bytes);
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+
+    int rc;
+#define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    // unfold rows U[:, :9C] (net:132-136) and the non-local map into U[:, 9C:] (net:134-137)
+    RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
+    if (csattn)
+        RUN(ciaosr_cs_attn_f32(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, csa_ws, p.csa_bytes, stream_));
+    // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
+    RUN(gemm_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], false, Tk, p.wk0, w->k.bias[0], p.HW, p.wk0, p.D, 1.f,
+                 CIAOSR_ACT_NONE, 0.f, s, "head_table"));
+    RUN(gemm_f32(U, p.Dv, w->v.weight[0], w->v.ld[0], false, Tv, p.wv0, w->v.bias[0], p.HW, p.wv0, p.Dv, 1.f,
+                 CIAOSR_ACT_NONE, 0.f, s, "head_table"));
+
+    for (long q0 = 0; q0 < Q; q0 += p.qc) {
+        const int nq = (int)((Q - q0) < p.qc ? (Q - q0) : p.qc);
+        const long rows = (long)nq * p.J;
+        HeadRowsP hp;
+        hp.coord = coord; hp.cell = cell; hp.q0 = q0; hp.nq = nq; hp.chunk = chunk; hp.H = H; hp.W = W;
+        hp.local_size = w->local_size; hp.J = p.J;
+        hp.Tk = Tk; hp.Tv = Tv;
+        hp.tailK = w->k.weight[0] + p.D;      // columns [9C, 9C+4) of layer 0, stride ld -> packed copy below
+        hp.tailV = w->v.weight[0] + p.Dv;
+        hp.wk0 = p.wk0; hp.wv0 = p.wv0; hp.relu_k = 1; hp.relu_v = 1;
+        hp.Hk = bufA; hp.Hv = Hv; hp.q_idx = q_idx; hp.k_idx = k_idx;
+        hp.ld_tail_k = w->k.ld[0]; hp.ld_tail_v = w->v.ld[0];
+        RUN(head_rows(hp, s));
+        // imnet_k layers 1..n-1 -> WK   (bufA holds layer-0 rows; ping-pong through bufB/bufA)
+        RUN(run_tail(w->k, bufA, p.wk0, bufB, bufA, WK, p.D, rows, s, "mlp_hidden", "mlp_out_k"));
+        // imnet_v: layer-0 rows are in Hv
+        RUN(run_tail(w->v, Hv, p.wv0, bufA, bufB, WV, p.Dv, rows, s, "mlp_hidden", "mlp_out_v"));
+        LocalAttnP lp{U, p.Dv, p.D, p.Dv, q_idx, k_idx, WK, p.D, WV, p.Dv, Z, p.Dv, nq, p.J, w->softmax_scale};
+        RUN(local_attention(lp, s));
+        // imnet_q: layer 0 on Z, hidden layers, last layer fused with the bilinear residual
+        const ciaosr_mlp_t& mq = w->q;
+        const float* cur = Z;
+        int ld_cur = p.Dv, k_cur = p.Dv;
+        float* pp[2] = {bufA, bufB};
+        int flip = 0;
+        for (int i = 0; i + 1 < mq.n_layers; ++i) {
+            RUN(gemm_f32(cur, ld_cur, mq.weight[i], mq.ld[i], false, pp[flip], mq.width[i], mq.bias[i], nq,
+                         mq.width[i], k_cur, 1.f, CIAOSR_ACT_RELU, 0.f, s, i == 0 ? "mlp_in_q" : "mlp_hidden_q"));
+            cur = pp[flip]; ld_cur = mq.width[i]; k_cur = mq.width[i];
+            flip ^= 1;
+        }
+        DecodeP dp{cur, ld_cur, k_cur, mq.weight[mq.n_layers - 1], mq.ld[mq.n_layers - 1],
+                   mq.bias[mq.n_layers - 1], x_lr_nchw, coord, q0, nq, H, W, rgb};
+        RUN(decode_residual(dp, s));
+    }
+#undef RUN
+    return CIAOSR_OK;
+}

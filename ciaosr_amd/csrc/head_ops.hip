@@ -1,0 +1,260 @@
+// Staged head kernels of LocalImplicitSRNet.query_rgb (ciaosr_net.py:113-224).
+//
+//  head_indices     nearest LR index of each query and of its J key samples          (:145,159-183)
+//  head_rows        layer-1 activations of imnet_k / imnet_v per (query, shift) row via the exact
+//                   layer-1 hoist: h1 = relu(T[key pixel] + W1[:, tail] . [rel, scale]) where
+//                   T = U . W1[:, :D]^T + b1 is one GEMM per LR tile     (:185-202)
+//  local_attention  K4: 4 logits per query, softmax, weighted value sum               (:203-216)
+//  decode_residual  last Linear of imnet_q (-> 3) + bilinear/border LR residual       (:107-108,221)
+//
+// One wavefront (64 lanes) per row / query; lanes stride the channel dimension with float4.
+#include "common.h"
+#include "index_math.h"
+#include "ops.h"
+
+namespace ciaosr {
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ long cell0_index(long q, int chunk) { return chunk > 0 ? (q / chunk) * chunk : 0; }
+
+// ---------------------------------------------------------------------------------------------
+__global__ void head_indices_kernel(const float* __restrict__ coord, const float* __restrict__ cell, long q0,
+                                    int nq, int chunk, int H, int W, int local_size, int J,
+                                    int* __restrict__ q_idx, int* __restrict__ k_idx, float* __restrict__ rel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const long q = q0 + i;
+    const float cy = coord[2 * q], cx = coord[2 * q + 1];
+    const long c0 = cell0_index(q, chunk);
+    const float c0y = cell[2 * c0], c0x = cell[2 * c0 + 1];
+    const int iy = nearest_index(cy, H), ix = nearest_index(cx, W);
+    q_idx[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? iy * W + ix : -1;
+    for (int j = 0; j < J; ++j) {
+        const KeySample s = key_sample(cy, cx, c0y, c0x, H, W, j, local_size);
+        k_idx[(size_t)i * J + j] = s.ky * W + s.kx;
+        if (rel) {
+            rel[((size_t)i * J + j) * 2] = s.rel_y;
+            rel[((size_t)i * J + j) * 2 + 1] = s.rel_x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void head_rows_kernel(HeadRowsP p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)p.nq * p.J) return;
+    const int i = (int)(row / p.J), j = (int)(row - (long)i * p.J);
+    const long q = p.q0 + i;
+    const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+    const long c0 = cell0_index(q, p.chunk);
+    const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, p.local_size);
+    const int kpix = s.ky * p.W + s.kx;
+    const float sy = __fmul_rn(p.cell[2 * q], (float)p.H);       // scale_ = cell * [H, W]  (:191-193)
+    const float sx = __fmul_rn(p.cell[2 * q + 1], (float)p.W);
+    if (lane == 0) {
+        p.k_idx[row] = kpix;
+        if (j == 0) {
+            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+            p.q_idx[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+        }
+    }
+    {
+        const float4* T = reinterpret_cast<const float4*>(p.Tk + (size_t)kpix * p.wk0);
+        const float* tw = p.tailK;
+        float4* o = reinterpret_cast<float4*>(p.Hk + (size_t)row * p.wk0);
+        for (int n4 = lane; n4 < (p.wk0 >> 2); n4 += 64) {
+            const float4 t = T[n4];
+            float r[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 w = *reinterpret_cast<const float4*>(tw + (size_t)(4 * n4 + e) * p.ld_tail_k);
+                float v = r[e] + w.x * s.rel_y + w.y * s.rel_x + w.z * sy + w.w * sx;
+                r[e] = p.relu_k ? fmaxf(v, 0.f) : v;
+            }
+            o[n4] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+    {
+        const float4* T = reinterpret_cast<const float4*>(p.Tv + (size_t)kpix * p.wv0);
+        const float* tw = p.tailV;
+        float4* o = reinterpret_cast<float4*>(p.Hv + (size_t)row * p.wv0);
+        for (int n4 = lane; n4 < (p.wv0 >> 2); n4 += 64) {
+            const float4 t = T[n4];
+            float r[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 w = *reinterpret_cast<const float4*>(tw + (size_t)(4 * n4 + e) * p.ld_tail_v);
+                float v = r[e] + w.x * s.rel_y + w.y * s.rel_x + w.z * sy + w.w * sx;
+                r[e] = p.relu_v ? fmaxf(v, 0.f) : v;
+            }
+            o[n4] = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 local attention.  HBM traffic per query (fp32, C=64): wk 4*576*4 + wv 4*640*4 + z 640*4 B.
+// ---------------------------------------------------------------------------------------------
+
+
+template <int J>
+__global__ __launch_bounds__(256) void local_attention_kernel(LocalAttnP p) {
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.Q) return;
+    const int qi = p.q_idx[q];
+    int kp[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) kp[j] = p.k_idx[q * J + j];
+    float logit[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) logit[j] = 0.f;
+    if (qi >= 0) {
+        const float4* qrow = reinterpret_cast<const float4*>(p.U + (size_t)qi * p.ldu);
+        for (int t = lane; t < (p.D >> 2); t += 64) {
+            const float4 qv = qrow[t];
+            _Pragma("unroll") for (int j = 0; j < J; ++j) {
+                const float4 kv = reinterpret_cast<const float4*>(p.U + (size_t)kp[j] * p.ldu)[t];
+                const float4 wv = reinterpret_cast<const float4*>(p.wk + (size_t)(q * J + j) * p.ldwk)[t];
+                logit[j] += qv.x * (kv.x * wv.x) + qv.y * (kv.y * wv.y) + qv.z * (kv.z * wv.z) + qv.w * (kv.w * wv.w);
+            }
+        }
+    }
+    float m = -INFINITY;
+    _Pragma("unroll") for (int j = 0; j < J; ++j) {
+        logit[j] = wsum(logit[j]) / p.scale;
+        m = fmaxf(m, logit[j]);
+    }
+    float den = 0.f;
+    _Pragma("unroll") for (int j = 0; j < J; ++j) {
+        logit[j] = expf(logit[j] - m);
+        den += logit[j];
+    }
+    _Pragma("unroll") for (int j = 0; j < J; ++j) logit[j] /= den;
+    float4* zo = reinterpret_cast<float4*>(p.z + (size_t)q * p.ldz);
+    for (int t = lane; t < (p.Dv >> 2); t += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        _Pragma("unroll") for (int j = 0; j < J; ++j) {
+            const float4 vv = reinterpret_cast<const float4*>(p.U + (size_t)kp[j] * p.ldu)[t];
+            const float4 ww = reinterpret_cast<const float4*>(p.wv + (size_t)(q * J + j) * p.ldwv)[t];
+            const float a = logit[j];
+            acc.x += a * (vv.x * ww.x);
+            acc.y += a * (vv.y * ww.y);
+            acc.z += a * (vv.z * ww.z);
+            acc.w += a * (vv.w * ww.w);
+        }
+        zo[t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode: rgb = W_last . h + b_last + bilinear_border(x_lr; coord)
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
+    const int lane = threadIdx.x & 63;
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= p.nq) return;
+    const long q = p.q0 + i;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const float4* hr = reinterpret_cast<const float4*>(p.h + (size_t)i * p.ldh);
+    const float4* w0 = reinterpret_cast<const float4*>(p.w);
+    const float4* w1 = reinterpret_cast<const float4*>(p.w + p.ldw);
+    const float4* w2 = reinterpret_cast<const float4*>(p.w + 2 * p.ldw);
+    for (int t = lane; t < (p.width >> 2); t += 64) {
+        const float4 h = hr[t];
+        const float4 x = w0[t], y = w1[t], z = w2[t];
+        a0 += h.x * x.x + h.y * x.y + h.z * x.z + h.w * x.w;
+        a1 += h.x * y.x + h.y * y.y + h.z * y.z + h.w * y.w;
+        a2 += h.x * z.x + h.y * z.y + h.z * z.z + h.w * z.w;
+    }
+    a0 = wsum(a0); a1 = wsum(a1); a2 = wsum(a2);
+    if (lane < 3) {
+        float v = (lane == 0 ? a0 : lane == 1 ? a1 : a2) + p.b[lane];
+        if (p.x_lr) {
+            // F.grid_sample(bilinear, padding_mode='border', align_corners=False)  (ciaosr_net.py:107-108)
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            float fy = __fsub_rn(__fmul_rn(__fadd_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
+            float fx = __fsub_rn(__fmul_rn(__fadd_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
+            fy = fminf((float)(p.H - 1), fmaxf(fy, 0.f));
+            fx = fminf((float)(p.W - 1), fmaxf(fx, 0.f));
+            const float y0f = floorf(fy), x0f = floorf(fx);
+            const int y0 = (int)y0f, x0 = (int)x0f;
+            const float wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
+            const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx;
+            const float* img = p.x_lr + (size_t)lane * p.H * p.W;
+            const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
+            float r = img[(size_t)y0 * p.W + x0] * (wx0 * wy0);
+            if (x1ok) r += img[(size_t)y0 * p.W + x0 + 1] * (wx1 * wy0);
+            if (y1ok) r += img[(size_t)(y0 + 1) * p.W + x0] * (wx0 * wy1);
+            if (y1ok && x1ok) r += img[(size_t)(y0 + 1) * p.W + x0 + 1] * (wx1 * wy1);
+            v += r;
+        }
+        p.rgb[q * 3 + lane] = v;
+    }
+}
+
+// ---- host wrappers --------------------------------------------------------------------------
+int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
+                 int* q_idx, int* k_idx, float* rel, hipStream_t s) {
+    const int J = local_size == 1 ? 1 : (local_size == 2 ? 4 : 9);
+    ProfScope prof("head_indices", s);
+    hipLaunchKernelGGL(head_indices_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, coord, cell, q0, nq, chunk, H,
+                       W, local_size, J, q_idx, k_idx, rel);
+    return launch_status("head_indices");
+}
+
+int head_rows(const HeadRowsP& p, hipStream_t s) {
+    ProfScope prof("head_rows", s);
+    hipLaunchKernelGGL(head_rows_kernel, dim3(ceil_div((long)p.nq * p.J, 4)), dim3(256), 0, s, p);
+    return launch_status("head_rows");
+}
+
+int local_attention(const LocalAttnP& p, hipStream_t s) {
+    ProfScope prof("local_attention", s);
+    if (p.J == 4)
+        hipLaunchKernelGGL(local_attention_kernel<4>, dim3(ceil_div(p.Q, 4)), dim3(256), 0, s, p);
+    else if (p.J == 9)
+        hipLaunchKernelGGL(local_attention_kernel<9>, dim3(ceil_div(p.Q, 4)), dim3(256), 0, s, p);
+    else if (p.J == 1)
+        hipLaunchKernelGGL(local_attention_kernel<1>, dim3(ceil_div(p.Q, 4)), dim3(256), 0, s, p);
+    else
+        return CIAOSR_ERR_UNSUPPORTED;
+    return launch_status("local_attention");
+}
+
+int decode_residual(const DecodeP& p, hipStream_t s) {
+    ProfScope prof("decode_residual", s);
+    hipLaunchKernelGGL(decode_residual_kernel, dim3(ceil_div(p.nq, 4)), dim3(256), 0, s, p);
+    return launch_status("decode_residual");
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+extern "C" int ciaosr_head_indices_f32(const float* coord, const float* cell, int Q, int chunk, int H, int W,
+                                       int local_size, int* q_idx, int* k_idx, float* rel, void* stream) {
+    CIAOSR_CHECK_ARG(coord && cell && q_idx && k_idx && Q > 0 && H > 0 && W > 0);
+    CIAOSR_CHECK_ARG(local_size >= 1 && local_size <= 3);
+    return head_indices(coord, cell, 0, Q, chunk, H, W, local_size, q_idx, k_idx, rel, (hipStream_t)stream);
+}
+
+extern "C" int ciaosr_local_attention_f32(const float* unfold, int ld_u, int C, int Cn, const int* q_idx,
+                                          const int* k_idx, const float* wk, int ld_wk, const float* wv,
+                                          int ld_wv, float* z, int ld_z, int Q, int J, float softmax_scale,
+                                          void* stream) {
+    CIAOSR_CHECK_ARG(unfold && q_idx && k_idx && wk && wv && z && Q > 0);
+    CIAOSR_CHECK_ARG((J == 1 || J == 4 || J == 9) && (C & 3) == 0 && (Cn & 3) == 0);
+    CIAOSR_CHECK_ARG((ld_u & 3) == 0 && (ld_wk & 3) == 0 && (ld_wv & 3) == 0 && (ld_z & 3) == 0);
+    LocalAttnP p{unfold, ld_u, 9 * C, 9 * C + Cn, q_idx, k_idx, wk, ld_wk, wv, ld_wv, z, ld_z, Q, J,
+                 softmax_scale};
+    return local_attention(p, (hipStream_t)stream);
+}

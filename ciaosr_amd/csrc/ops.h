@@ -1,0 +1,86 @@
+// Internal declarations shared by the translation units of libciaosr_hip.so.
+#pragma once
+#include "common.h"
+
+namespace ciaosr {
+
+constexpr int MAXJ = 9;  // key samples per query for local_size 3
+
+struct HeadRowsP {
+    const float* coord;
+    const float* cell;
+    long q0;
+    int nq, chunk, H, W, local_size, J;
+    const float* Tk;   // [HW][wk0]  layer-0 table of imnet_k (bias included)
+    const float* Tv;   // [HW][wv0]
+    const float* tailK;  // &W1k[0][D]: 4 tail columns (rel_y rel_x scale_y scale_x) of each row, stride ld_tail_k
+    const float* tailV;  // &W1v[0][Dv]
+    int ld_tail_k, ld_tail_v;
+    int wk0, wv0, relu_k, relu_v;
+    float* Hk;  // [nq*J][wk0]
+    float* Hv;  // [nq*J][wv0]
+    int* q_idx;
+    int* k_idx;
+};
+
+struct LocalAttnP {
+    const float* U;
+    int ldu, D, Dv;   // D = 9C, Dv = 9C + Cn
+    const int* q_idx;
+    const int* k_idx;
+    const float* wk; int ldwk;
+    const float* wv; int ldwv;
+    float* z; int ldz;
+    int Q, J;
+    float scale;
+};
+
+struct DecodeP {
+    const float* h; int ldh, width;      // [nq][width] activations feeding the last Linear
+    const float* w; int ldw;             // [3][ldw]
+    const float* b;                      // [3]
+    const float* x_lr;                   // [3][H][W] or null
+    const float* coord;
+    long q0;
+    int nq, H, W;
+    float* rgb;                          // [Q][3] (global query index)
+};
+
+// gemm_f32.hip
+int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc, const float* bias,
+             int M, int N, int K, float alpha, int act, float slope, hipStream_t stream, const char* tag);
+// patch_ops.hip
+int nchw_to_hwc(const float* src, float* dst, int C, int H, int W, int ld, hipStream_t s);
+int hwc_to_nchw(const float* src, int ld, float* dst, int C, int H, int W, hipStream_t s);
+int pad_reflect(const float* src, int ld_src, int H, int W, int C, float* dst, int Hp, int Wp, hipStream_t s);
+int avgpool2(const float* src, int Hp, int Wp, int C, float* dst, hipStream_t s);
+int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int stride, int pad, int OH, int OW,
+               float* out, int ld_out, int normalize, float floor_, hipStream_t s, const char* tag);
+int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s);
+int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s);
+// head_ops.hip
+int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
+                 int* q_idx, int* k_idx, float* rel, hipStream_t s);
+int head_rows(const HeadRowsP& p, hipStream_t s);
+int local_attention(const LocalAttnP& p, hipStream_t s);
+int decode_residual(const DecodeP& p, hipStream_t s);
+
+// bump allocator over the caller-provided workspace (256-byte aligned carve-outs)
+struct Arena {
+    char* base;
+    size_t size, off;
+    bool ok;
+    Arena(void* p, size_t n) : base((char*)p), size(n), off(0), ok(true) {}
+    template <typename T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* r = reinterpret_cast<T*>(base + off);
+        off += count * sizeof(T);
+        if (off > size) ok = false;
+        return r;
+    }
+};
+
+static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace ciaosr

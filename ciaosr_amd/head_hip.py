@@ -1,0 +1,111 @@
+"""Weight packing + launch of the HIP head (ciaosr_head_forward_f32).
+
+Device channel order (include/ciaosr_hip.h): an unfold row is stored (ki,kj,c)-major instead of the
+reference's F.unfold order c*9+ki*3+kj (ciaosr_net.py:132), so that one 3x3 tap is C contiguous
+floats of the channels-last feature map.  The permutation is folded into the MLP weights once:
+  imnet_k / imnet_v layer 0 : columns   [perm(9C) | (Cn) | rel_y rel_x scale_y scale_x]
+  imnet_k / imnet_v last    : rows+bias [perm(9C) | (Cn)]
+  imnet_q layer 0           : columns   [perm(9C) | (Cn)]
+Dot products and element-wise products over the channel axis are invariant under it.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, hip_ops
+
+
+def unfold_perm(channels, device):
+    """perm[d_dev] = d_ref with d_dev = t*C + c, d_ref = c*9 + t (t = ki*3+kj)."""
+    return torch.arange(9 * channels, device=device).view(channels, 9).t().reshape(-1)
+
+
+class PackedHead:
+    """Packed (device-order, contiguous fp32) copies of a LocalImplicitSRNet head's weights."""
+
+    def __init__(self, net):
+        self.net = net
+        self._key = None
+        self._st = None
+        self._keep = None
+
+    def _version_key(self):
+        mods = [self.net.imnet_q, self.net.imnet_k, self.net.imnet_v]
+        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+
+    def _pack_mlp(self, mlp, col_perm=None, row_perm=None):
+        st = _lib.MlpT()
+        lin = mlp.linears()
+        if len(lin) > _lib.MAX_LAYERS:
+            raise _lib.CiaoSRHipError(f'MLP deeper than {_lib.MAX_LAYERS} Linear layers')
+        st.n_layers = len(lin)
+        keep = []
+        for i, l in enumerate(lin):
+            w = l.weight.detach().float()
+            b = l.bias.detach().float()
+            if i == 0 and col_perm is not None:
+                w = w[:, col_perm]
+            if i == len(lin) - 1 and row_perm is not None:
+                w, b = w[row_perm], b[row_perm]
+            if w.shape[1] % 4:
+                w = torch.nn.functional.pad(w, (0, 4 - w.shape[1] % 4))
+            w, b = w.contiguous(), b.contiguous()
+            hip_ops.require_gpu(w, b)
+            keep += [w, b]
+            st.width[i] = w.shape[0]
+            st.weight[i] = w.data_ptr()
+            st.ld[i] = w.stride(0)
+            st.bias[i] = b.data_ptr()
+        st.in_dim = lin[0].weight.shape[1]
+        return st, keep
+
+    def struct(self):
+        key = self._version_key()
+        if self._st is not None and self._key == key:
+            return self._st
+        net = self.net
+        Cc = net.imnet_dim
+        Cn = Cc * len(net.multi_scale) if net.non_local_attn else 0
+        dev = net.imnet_q.layers[0].weight.device
+        perm = unfold_perm(Cc, dev)
+        D = 9 * Cc
+        tail_n = torch.arange(D, D + Cn, device=dev)
+        k_cols = torch.cat([perm, torch.arange(D, D + 4, device=dev)])
+        v_cols = torch.cat([perm, tail_n, torch.arange(D + Cn, D + Cn + 4, device=dev)])
+        v_rows = torch.cat([perm, tail_n])
+        st = _lib.HeadWeightsT()
+        st.channels, st.nonlocal_channels = Cc, Cn
+        st.local_size, st.softmax_scale = int(net.local_size), float(net.softmax_scale)
+        keep = []
+        st.k, kk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm)
+        st.v, kv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows)
+        st.q, kq = self._pack_mlp(net.imnet_q, col_perm=v_rows)
+        self._keep = kk + kv + kq
+        self._st, self._key = st, key
+        return st
+
+    @torch.no_grad()
+    def forward(self, feature_chw, x_lr_chw, coord, cell, chunk):
+        """feature [C,H,W], x_lr [3,H,W] or None, coord/cell [Q,2] -> rgb [Q,3] (all on the GPU)."""
+        net = self.net
+        feature_chw = feature_chw.contiguous().float()
+        coord = coord.contiguous().float()
+        cell = cell.contiguous().float()
+        if x_lr_chw is not None:
+            x_lr_chw = x_lr_chw.contiguous().float()
+        hip_ops.require_gpu(feature_chw, x_lr_chw, coord, cell)
+        Cc, H, W = feature_chw.shape
+        Q = coord.shape[0]
+        st = self.struct()
+        cs = None
+        if net.non_local_attn:
+            cs, _ = net.cs_attn.packed()
+        feat_hwc = hip_ops.nchw_to_hwc(feature_chw)
+        nbytes = _lib.load().ciaosr_head_workspace_bytes(H, W, C.byref(st), Q)
+        ws = hip_ops.workspace(nbytes, coord.device)
+        rgb = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)
+        _lib.call('ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W, C.byref(st),
+                  C.byref(cs) if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
+                  hip_ops.ptr(cell), Q, int(chunk or 0), hip_ops.ptr(rgb), hip_ops.ptr(ws), ws.numel(),
+                  hip_ops.stream_ptr())
+        return rgb

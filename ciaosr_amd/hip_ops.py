@@ -1,0 +1,168 @@
+"""Tensor-level wrappers over the C ABI: device pointers from `tensor.data_ptr()`, the stream
+from `torch.cuda.current_stream()`.  PyTorch is used for device memory and streams only."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import CiaoSRHipError
+
+_workspaces = {}
+
+
+def require_gpu(*tensors, allow_row_stride=False):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise CiaoSRHipError('the LocalImplicitSR path runs on the MI355X only: got a CPU tensor '
+                                 '(no CPU fallback; move the model and inputs to cuda)')
+        if t.dtype not in (torch.float32, torch.int32):
+            raise CiaoSRHipError(f'expected float32/int32 tensor, got {t.dtype}')
+        if not t.is_contiguous() and not (allow_row_stride and t.dim() == 2 and t.stride(1) == 1):
+            raise CiaoSRHipError('expected a contiguous tensor')
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (never freed while the process lives)."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _workspaces[key] = None
+        buf = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def gemm(a, b, bias=None, act=_lib.ACT_NONE, slope=0.0, alpha=1.0, b_is_kn=False, out=None):
+    """out[M,N] = act((a[M,K] @ (b[N,K]^T | b[K,N]) + bias) * alpha) through ciaosr_gemm_f32."""
+    require_gpu(a, b, bias, allow_row_stride=True)
+    M, K = a.shape
+    N = b.shape[1] if b_is_kn else b.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _lib.call('ciaosr_gemm_f32', ptr(a), a.stride(0), ptr(b), b.stride(0), int(b_is_kn), ptr(out), out.stride(0),
+              ptr(bias), M, N, K, float(alpha), int(act), float(slope), stream_ptr())
+    return out
+
+
+def nchw_to_hwc(x):
+    require_gpu(x)
+    Cc, H, W = x.shape
+    out = torch.empty(H, W, Cc, dtype=torch.float32, device=x.device)
+    _lib.call('ciaosr_nchw_to_hwc_f32', ptr(x), ptr(out), Cc, H, W, Cc, stream_ptr())
+    return out
+
+
+def hwc_to_nchw(x):
+    require_gpu(x)
+    H, W, Cc = x.shape
+    out = torch.empty(Cc, H, W, dtype=torch.float32, device=x.device)
+    _lib.call('ciaosr_hwc_to_nchw_f32', ptr(x), Cc, ptr(out), Cc, H, W, stream_ptr())
+    return out
+
+
+def head_indices(coord, cell, H, W, local_size=2, chunk=0, want_rel=True):
+    require_gpu(coord, cell)
+    Q = coord.shape[0]
+    J = {1: 1, 2: 4, 3: 9}[local_size]
+    q_idx = torch.empty(Q, dtype=torch.int32, device=coord.device)
+    k_idx = torch.empty(Q, J, dtype=torch.int32, device=coord.device)
+    rel = torch.empty(Q, J, 2, dtype=torch.float32, device=coord.device) if want_rel else None
+    _lib.call('ciaosr_head_indices_f32', ptr(coord), ptr(cell), Q, chunk, H, W, local_size, ptr(q_idx), ptr(k_idx),
+              ptr(rel), stream_ptr())
+    return q_idx, k_idx, rel
+
+
+def patch_rows(src_hwc, ksize, stride, pad, OH, OW, normalize=False, floor=0.0):
+    require_gpu(src_hwc)
+    Hs, Ws, Cs = src_hwc.shape
+    out = torch.empty(OH * OW, ksize * ksize * Cs, dtype=torch.float32, device=src_hwc.device)
+    _lib.call('ciaosr_patch_rows_f32', ptr(src_hwc), Cs, Hs, Ws, Cs, ksize, stride, pad, OH, OW, ptr(out),
+              out.stride(0), int(normalize), float(floor), stream_ptr())
+    return out
+
+
+def local_attention(unfold, C_, Cn, q_idx, k_idx, wk, wv, softmax_scale=1.0):
+    require_gpu(unfold, q_idx, k_idx, wk, wv)
+    Q, J = k_idx.shape
+    z = torch.empty(Q, 9 * C_ + Cn, dtype=torch.float32, device=unfold.device)
+    _lib.call('ciaosr_local_attention_f32', ptr(unfold), unfold.stride(0), C_, Cn, ptr(q_idx), ptr(k_idx), ptr(wk),
+              wk.stride(0), ptr(wv), wv.stride(0), ptr(z), z.stride(0), Q, J, float(softmax_scale), stream_ptr())
+    return z
+
+
+def _f3(vals):
+    return (C.c_float * 3)(*[float(v) for v in vals])
+
+
+def normalize(lq_chw, mean, std):
+    require_gpu(lq_chw)
+    out = torch.empty_like(lq_chw)
+    _, H, W = lq_chw.shape
+    _lib.call('ciaosr_normalize_f32', ptr(lq_chw), ptr(out), H, W, _f3(mean), _f3(std), stream_ptr())
+    return out
+
+
+def denorm_clamp(pred_q3, H, W, mean, std):
+    require_gpu(pred_q3)
+    out = torch.empty(3, H, W, dtype=torch.float32, device=pred_q3.device)
+    _lib.call('ciaosr_denorm_clamp_f32', ptr(pred_q3), ptr(out), H, W, _f3(mean), _f3(std), stream_ptr())
+    return out
+
+
+def tile_blend(E, Wt, tile_q3, y0, x0, th, tw):
+    require_gpu(E, Wt, tile_q3)
+    _, Himg, Wimg = E.shape
+    _lib.call('ciaosr_tile_blend_f32', ptr(E), ptr(Wt), Himg, Wimg, ptr(tile_q3), y0, x0, th, tw, stream_ptr())
+
+
+def tile_finalize(E, Wt):
+    require_gpu(E, Wt)
+    _, Himg, Wimg = E.shape
+    out = torch.empty(Himg * Wimg, 3, dtype=torch.float32, device=E.device)
+    _lib.call('ciaosr_tile_finalize_f32', ptr(E), ptr(Wt), ptr(out), Himg, Wimg, stream_ptr())
+    return out
+
+
+class profile:
+    """Context manager around the library's per-kernel HIP-event timing."""
+
+    def __init__(self, only=None):
+        self.only = only
+
+    def __enter__(self):
+        lib = _lib.load()
+        lib.ciaosr_prof_filter(self.only.encode() if self.only else None)
+        lib.ciaosr_prof_reset()
+        lib.ciaosr_prof_enable(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib = _lib.load()
+        lib.ciaosr_prof_collect()
+        lib.ciaosr_prof_enable(0)
+        return False
+
+    @staticmethod
+    def results():
+        lib = _lib.load()
+        lib.ciaosr_prof_collect()
+        buf = C.create_string_buffer(8192)
+        lib.ciaosr_prof_names(buf, 8192)
+        out = {}
+        for name in [n for n in buf.value.decode().split(';') if n]:
+            ms, n = C.c_double(0), C.c_long(0)
+            lib.ciaosr_prof_get(name.encode(), C.byref(ms), C.byref(n))
+            if n.value:
+                out[name] = dict(total_ms=ms.value, launches=n.value, avg_ms=ms.value / n.value)
+        return out

@@ -1,0 +1,139 @@
+"""LocalImplicitSR generators: the reference's plugin surface over the HIP head.
+
+Mirrors mmedited/models/backbones/sr_backbones/ciaosr_net.py:
+  LocalImplicitSRNet   (:17-264)   ctor kwargs, dims wiring (:56-85), forward (:88-110),
+                                   query_rgb (:113-224), batched_predict (:226-248), init_weights (:250)
+  LocalImplicitSRRDN   (:267-342)  re-parents sfe1/sfe2/rdbs/gff, deletes `encoder`
+  LocalImplicitSREDSR  (:345-408)  re-parents conv_first/body/conv_after_body
+Same constructor arguments, attribute and state_dict names, argument meaning and error behaviour.
+The arithmetic of query_rgb / batched_predict runs in libciaosr_hip.so (hand-written gfx950 kernels);
+the encoder trunk runs through PyTorch-ROCm.  Inference only.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops
+from .head_hip import PackedHead
+from .nonlocal_attn import CrossScaleAttention
+from .registry import build_backbone, build_component
+
+
+class LocalImplicitSRNet(nn.Module):
+    def __init__(self, encoder, imnet_q, imnet_k, imnet_v, query_mlp=None, key_mlp=None, value_mlp=None,
+                 local_size=2, feat_unfold=True, eval_bsize=None, non_local_attn=True, multi_scale=[2],
+                 softmax_scale=1):
+        super().__init__()
+        self.feat_unfold = feat_unfold
+        self.eval_bsize = eval_bsize
+        self.local_size = local_size
+        self.non_local_attn = non_local_attn
+        self.multi_scale = list(multi_scale)
+        self.softmax_scale = softmax_scale
+        if not feat_unfold:
+            raise NotImplementedError('feat_unfold=False is not implemented on the HIP path '
+                                      '(every CiaoSR config uses feat_unfold=True)')
+        imnet_q, imnet_k, imnet_v = copy.deepcopy(imnet_q), copy.deepcopy(imnet_k), copy.deepcopy(imnet_v)
+        self.encoder = build_backbone(encoder)
+        dim = self.encoder.mid_channels if hasattr(self.encoder, 'mid_channels') else self.encoder.embed_dim
+        self.imnet_dim = dim
+        # dims wiring, ciaosr_net.py:61-76
+        imnet_q['in_dim'] = dim * 9
+        imnet_k['in_dim'] = imnet_k['out_dim'] = dim * 9
+        imnet_v['in_dim'] = imnet_v['out_dim'] = dim * 9
+        imnet_k['in_dim'] += 4
+        imnet_v['in_dim'] += 4
+        if non_local_attn:
+            imnet_q['in_dim'] += dim * len(multi_scale)
+            imnet_v['in_dim'] += dim * len(multi_scale)
+            imnet_v['out_dim'] += dim * len(multi_scale)
+        self.imnet_q = build_component(imnet_q)
+        self.imnet_k = build_component(imnet_k)
+        self.imnet_v = build_component(imnet_v)
+        if non_local_attn:
+            self.cs_attn = CrossScaleAttention(channel=dim, scale=multi_scale)
+        self._head = PackedHead(self)
+
+    # -- the reference interface ---------------------------------------------------------------
+    def gen_feature(self, x):
+        raise NotImplementedError('subclasses define gen_feature')
+
+    def forward(self, x, coord, cell, test_mode=False):
+        """x [B,3,H,W] normalised LR, coord/cell [B,Q,2] (y,x) -> [B,Q,3]   (ciaosr_net.py:88-110)."""
+        features = self.gen_feature(x)
+        chunk = None if (self.eval_bsize is None or not test_mode) else self.eval_bsize
+        return self._predict(features, coord, cell, chunk, x)
+
+    def query_rgb(self, features, coord, scale=None):
+        """ciaosr_net.py:113-224 (no bilinear residual); `scale` is the cell tensor."""
+        return self._predict(features, coord, scale, None, None)
+
+    def batched_predict(self, x, coord, cell):
+        """ciaosr_net.py:226-248: `x` is the feature list; eval_bsize chunking only matters through
+        which query's cell defines the shift radius -- the kernels take it as `chunk`."""
+        return self._predict(x, coord, cell, self.eval_bsize, None)
+
+    def init_weights(self, pretrained=None, strict=True):
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=strict)
+        elif pretrained is not None:
+            raise TypeError(f'"pretrained" must be a str or None. But received {type(pretrained)}.')
+
+    # -- HIP path ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def _predict(self, features, coord, cell, chunk, x_lr):
+        if isinstance(features, torch.Tensor):
+            features = [features]
+        if len(features) != 1:
+            raise NotImplementedError('one feature map per image (every encoder adapter returns [feat])')
+        feature = features[0]
+        hip_ops.require_gpu(feature.contiguous(), coord.contiguous(), cell.contiguous())
+        outs = []
+        for b in range(feature.shape[0]):
+            outs.append(self._head.forward(feature[b], None if x_lr is None else x_lr[b], coord[b], cell[b], chunk))
+        return torch.stack(outs, 0)
+
+
+class LocalImplicitSRRDN(LocalImplicitSRNet):
+    def __init__(self, encoder, imnet_q, imnet_k, imnet_v, query_mlp=None, key_mlp=None, value_mlp=None,
+                 local_size=2, feat_unfold=True, eval_bsize=None, non_local_attn=True, multi_scale=[2],
+                 softmax_scale=1):
+        super().__init__(encoder=encoder, imnet_q=imnet_q, imnet_k=imnet_k, imnet_v=imnet_v, query_mlp=query_mlp,
+                         key_mlp=key_mlp, value_mlp=value_mlp, local_size=local_size, feat_unfold=feat_unfold,
+                         eval_bsize=eval_bsize, non_local_attn=non_local_attn, multi_scale=multi_scale,
+                         softmax_scale=softmax_scale)
+        self.sfe1 = self.encoder.sfe1
+        self.sfe2 = self.encoder.sfe2
+        self.rdbs = self.encoder.rdbs
+        self.gff = self.encoder.gff
+        self.num_blocks = self.encoder.num_blocks
+        del self.encoder
+
+    def gen_feature(self, x):
+        sfe1 = self.sfe1(x)
+        h = self.sfe2(sfe1)
+        local = []
+        for i in range(self.num_blocks):
+            h = self.rdbs[i](h)
+            local.append(h)
+        return [self.gff(torch.cat(local, 1)) + sfe1]
+
+
+class LocalImplicitSREDSR(LocalImplicitSRNet):
+    def __init__(self, encoder, imnet_q, imnet_k, imnet_v, query_mlp=None, key_mlp=None, value_mlp=None,
+                 local_size=2, feat_unfold=True, eval_bsize=None, non_local_attn=True, multi_scale=[2],
+                 softmax_scale=1):
+        super().__init__(encoder=encoder, imnet_q=imnet_q, imnet_k=imnet_k, imnet_v=imnet_v, query_mlp=query_mlp,
+                         key_mlp=key_mlp, value_mlp=value_mlp, local_size=local_size, feat_unfold=feat_unfold,
+                         eval_bsize=eval_bsize, non_local_attn=non_local_attn, multi_scale=multi_scale,
+                         softmax_scale=softmax_scale)
+        self.conv_first = self.encoder.conv_first
+        self.body = self.encoder.body
+        self.conv_after_body = self.encoder.conv_after_body
+        del self.encoder
+
+    def gen_feature(self, x):
+        f = self.conv_first(x)
+        return [self.conv_after_body(self.body(f)) + f]

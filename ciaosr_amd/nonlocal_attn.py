@@ -1,0 +1,88 @@
+"""CrossScaleAttention ("scale-aware non-local attention"): parameters with the reference's
+names (arch_csnln.py:407-428) and a HIP forward (ciaosr_cs_attn_f32, arch_csnln.py:430-532).
+
+state_dict: conv_match_1.0.{weight,bias}, conv_match_1.1.weight (PReLU), conv_match_2.*,
+conv_assembly.*, down.{weight,bias}, buffer escape_NaN.  Only scale=[2] is supported (the only
+value any config uses, ciaosr_net.py:44).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, hip_ops
+
+
+def _conv_prelu(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 1, padding=0, bias=True), nn.PReLU())
+
+
+class CrossScaleAttention(nn.Module):
+    def __init__(self, channel=64, reduction=2, ksize=3, scale=2, stride=1, softmax_scale=10, average=True):
+        super().__init__()
+        scale = list(scale) if isinstance(scale, (list, tuple)) else [scale]
+        if scale != [2] or ksize != 3 or stride != 1 or not average:
+            raise NotImplementedError('only CrossScaleAttention(scale=[2], ksize=3, stride=1, average=True) '
+                                      'is implemented (the configuration every CiaoSR config uses)')
+        if reduction != 2:
+            raise NotImplementedError('reduction must be 2')
+        self.channel, self.scale, self.softmax_scale = channel, scale, softmax_scale
+        self.register_buffer('escape_NaN', torch.FloatTensor([1e-4]))
+        self.conv_match_1 = _conv_prelu(channel, channel // reduction)
+        self.conv_match_2 = _conv_prelu(channel, channel // reduction)
+        self.conv_assembly = _conv_prelu(channel, channel)
+        self.down = nn.Conv2d(channel, channel, ksize, 2, 1)
+        self._packed = None
+
+    # -- weight packing -------------------------------------------------------------------------
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self):
+        key = self._version_key()
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        Cc = self.channel
+        keep = dict(
+            w1=self.conv_match_1[0].weight.detach().reshape(Cc // 2, Cc).contiguous().float(),
+            b1=self.conv_match_1[0].bias.detach().contiguous().float(),
+            w2=self.conv_match_2[0].weight.detach().reshape(Cc // 2, Cc).contiguous().float(),
+            b2=self.conv_match_2[0].bias.detach().contiguous().float(),
+            wa=self.conv_assembly[0].weight.detach().reshape(Cc, Cc).contiguous().float(),
+            ba=self.conv_assembly[0].bias.detach().contiguous().float(),
+            # down.weight [co][ci][a][b] -> [co][(a*3+b)*C + ci]
+            wd=self.down.weight.detach().permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous().float(),
+            bd=self.down.bias.detach().contiguous().float())
+        hip_ops.require_gpu(*keep.values())
+        st = _lib.CsAttnWeightsT()
+        st.channels = Cc
+        st.w_match1, st.b_match1 = keep['w1'].data_ptr(), keep['b1'].data_ptr()
+        st.w_match2, st.b_match2 = keep['w2'].data_ptr(), keep['b2'].data_ptr()
+        st.w_assembly, st.b_assembly = keep['wa'].data_ptr(), keep['ba'].data_ptr()
+        st.w_down, st.b_down = keep['wd'].data_ptr(), keep['bd'].data_ptr()
+        st.slope_match1 = float(self.conv_match_1[1].weight.detach().float().cpu()[0])
+        st.slope_match2 = float(self.conv_match_2[1].weight.detach().float().cpu()[0])
+        st.slope_assembly = float(self.conv_assembly[1].weight.detach().float().cpu()[0])
+        st.escape_nan = float(self.escape_NaN.detach().float().cpu()[0])
+        st.softmax_scale = float(self.softmax_scale)
+        self._packed = (key, (st, keep))
+        return self._packed[1]
+
+    @torch.no_grad()
+    def forward(self, input):
+        """[B,C,H,W] -> [B,C,H,W] like the reference module (batch items are independent,
+        arch_csnln.py:491)."""
+        x = input.contiguous().float()
+        hip_ops.require_gpu(x)
+        B, Cc, H, W = x.shape
+        st, _keep = self.packed()
+        nbytes = _lib.load().ciaosr_cs_attn_workspace_bytes(H, W, Cc)
+        ws = hip_ops.workspace(nbytes, x.device)
+        out = torch.empty_like(x)
+        for b in range(B):
+            f = hip_ops.nchw_to_hwc(x[b])
+            o = torch.empty(H, W, Cc, dtype=torch.float32, device=x.device)
+            _lib.call('ciaosr_cs_attn_f32', hip_ops.ptr(f), Cc, H, W, C.byref(st), hip_ops.ptr(o), Cc,
+                      hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
+            out[b] = hip_ops.hwc_to_nchw(o)
+        return out

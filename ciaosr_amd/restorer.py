@@ -1,0 +1,174 @@
+"""Restorers: BasicRestorer / CiaoSR with the reference's call surface.
+
+Mirrors mmedited/models/restorers/basic_restorer.py:35-124 (`__init__`, `forward`, `evaluate`) and
+mmedited/models/restorers/ciaosr.py:36-58 (`__init__`), :111-203 (`forward_test`), :218-258
+(`clip_test`).  Normalisation, tile blending and de-normalisation run as HIP kernels; tiles are
+the unit sharded across GPUs (ciaosr_amd/tile_shard.py).  Training entry points are out of scope.
+"""
+import math
+import numbers
+import os.path as osp
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops, metrics
+from .coords import make_coord, make_cell
+from .registry import build_backbone, build_loss
+
+
+class _Cfg(dict):
+    """dict with attribute access (stands in for mmcv.ConfigDict)."""
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _as_cfg(cfg):
+    if cfg is None or isinstance(cfg, _Cfg):
+        return cfg
+    return _Cfg(cfg)
+
+
+class BasicRestorer(nn.Module):
+    allowed_metrics = {'PSNR': metrics.psnr, 'SSIM': metrics.ssim}
+
+    def __init__(self, generator, pixel_loss, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.train_cfg = _as_cfg(train_cfg)
+        self.test_cfg = _as_cfg(test_cfg)
+        self.fp16_enabled = False
+        self.generator = build_backbone(generator)
+        self.init_weights(pretrained)
+        self.pixel_loss = build_loss(pixel_loss)
+
+    def init_weights(self, pretrained=None):
+        self.generator.init_weights(pretrained)
+
+    def forward(self, lq, gt=None, test_mode=False, **kwargs):
+        if test_mode:
+            return self.forward_test(lq, gt, **kwargs)
+        raise NotImplementedError('forward_train / train_step are out of scope of the MI355X inference path')
+
+    def evaluate(self, output, gt):
+        """PSNR/SSIM on uint8 BGR images as basic_restorer.py:101-124."""
+        crop_border = self.test_cfg.crop_border
+        out_img, gt_img = metrics.tensor2img(output), metrics.tensor2img(gt)
+        res = {}
+        for metric in self.test_cfg.metrics:
+            fn = self.allowed_metrics[metric]
+            if 'convert_to' in self.test_cfg:
+                res[metric] = fn(out_img, gt_img, crop_border=crop_border, convert_to=self.test_cfg.convert_to)
+            else:
+                res[metric] = fn(out_img, gt_img, crop_border)
+        return res
+
+
+def tile_starts(n, tile, overlap):
+    """ciaosr.py:227-229."""
+    stride = tile - overlap
+    return list(range(0, n - tile, stride)) + [n - tile]
+
+
+def tile_grid(h, w, tile, overlap):
+    """Row-major (h outer, w inner) list of tile origins, the reference's blend order (ciaosr.py:233-234)."""
+    tile = min(tile, h, w)
+    return tile, [(hi, wi) for hi in tile_starts(h, tile, overlap) for wi in tile_starts(w, tile, overlap)]
+
+
+class CiaoSR(BasicRestorer):
+    def __init__(self, generator, pixel_loss, rgb_mean=(0.5, 0.5, 0.5), rgb_std=(0.5, 0.5, 0.5), train_cfg=None,
+                 test_cfg=None, pretrained=None):
+        super().__init__(generator, pixel_loss, train_cfg=train_cfg, test_cfg=test_cfg, pretrained=pretrained)
+        self.rgb_mean = tuple(float(v) for v in rgb_mean)
+        self.rgb_std = tuple(float(v) for v in rgb_std)
+        # host-side float32 copies (the reference keeps them as plain tensors, ciaosr.py:52-58)
+        self.lq_mean = torch.FloatTensor(rgb_mean).view(1, -1, 1, 1)
+        self.lq_std = torch.FloatTensor(rgb_std).view(1, -1, 1, 1)
+        self.gt_mean = torch.FloatTensor(rgb_mean).view(1, 1, -1)
+        self.gt_std = torch.FloatTensor(rgb_std).view(1, 1, -1)
+
+    def train_step(self, data_batch, optimizer):
+        raise NotImplementedError('training is out of scope of the MI355X inference path')
+
+    # -- pieces of forward_test, separately callable (bench / tile sharding) ---------------------
+    @torch.no_grad()
+    def normalize(self, lq):
+        """(lq - mean) / std  (ciaosr.py:142-144) on the GPU."""
+        lq = lq.contiguous().float()
+        hip_ops.require_gpu(lq)
+        return torch.stack([hip_ops.normalize(lq[b], self.rgb_mean, self.rgb_std) for b in range(lq.shape[0])])
+
+    @torch.no_grad()
+    def run_tile(self, x_norm, hi, wi, tile, sf):
+        """One tile of clip_test (ciaosr.py:235-245): [B, th*tw, 3] prediction of the LR crop."""
+        patch = x_norm[..., hi:hi + tile, wi:wi + tile].contiguous()
+        b = patch.shape[0]
+        th, tw = round(patch.shape[-2] * sf), round(patch.shape[-1] * sf)
+        coord = make_coord((th, tw)).to(patch.device).unsqueeze(0).expand(b, -1, 2).contiguous()
+        cell = make_cell((th, tw)).to(patch.device).unsqueeze(0).expand(b, -1, 2).contiguous()
+        return self.generator(patch, coord, cell, test_mode=True), (th, tw)
+
+    @torch.no_grad()
+    def clip_test(self, img_lq, model=None, tile_fn=None):
+        """Tiled inference of one large image (ciaosr.py:218-258).  Returns [B, h*sf*w*sf, 3]."""
+        sf = self.test_cfg.get('scale', None)
+        b, c, h, w = img_lq.shape
+        tile, origins = tile_grid(h, w, self.test_cfg.get('tile', None), self.test_cfg.get('tile_overlap', None))
+        E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
+        Wt = torch.zeros_like(E)
+        for (hi, wi) in origins:
+            out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf) if tile_fn is None else tile_fn(hi, wi)
+            for bi in range(b):
+                hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), hi * sf, wi * sf, th, tw)
+        return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
+
+    @torch.no_grad()
+    def restore(self, lq, coord=None, cell=None):
+        """forward_test body from normalised LR on device to de-normalised, clamped output
+        [B,3,round(h*s),round(w*s)] on device (ciaosr.py:142-169) -- the timed region of bench.py."""
+        x = self.normalize(lq)
+        if self.test_cfg.get('tile', None):
+            pred = self.clip_test(x, self.generator)
+            n_q = pred.shape[1]
+        else:
+            pred = self.generator(x, coord, cell, test_mode=True)
+            n_q = coord.shape[1]
+        ih, iw = lq.shape[-2:]
+        s = math.sqrt(n_q / (ih * iw))
+        H, W = round(ih * s), round(iw * s)
+        return torch.stack([hip_ops.denorm_clamp(pred[b].contiguous(), H, W, self.rgb_mean, self.rgb_std)
+                            for b in range(lq.shape[0])])
+
+    def forward_test(self, lq, gt, coord=None, cell=None, meta=None, save_image=False, save_path=None,
+                     iteration=None):
+        """Same contract as ciaosr.py:111-203."""
+        pred = self.restore(lq, coord, cell)
+        if gt is not None:
+            shape = [lq.shape[0], pred.shape[2], pred.shape[3], 3]
+            gt = gt.view(*shape).permute(0, 3, 1, 2).contiguous()
+        if self.test_cfg is not None and self.test_cfg.get('metrics', None):
+            assert gt is not None, 'evaluation with metrics must have gt images.'
+            results = dict(eval_result=self.evaluate(pred, gt))
+        else:
+            results = dict(lq=lq.cpu(), output=pred.cpu())
+            if gt is not None:
+                results['gt'] = gt.cpu()
+        if save_image:
+            if 'gt_path' in meta[0]:
+                folder_name = osp.splitext(osp.basename(meta[0]['gt_path']))[0]
+            else:
+                folder_name = osp.splitext(osp.basename(meta[0]['lq_path']))[0]
+            if isinstance(iteration, numbers.Number):
+                save_path = osp.join(save_path, folder_name, f'{folder_name}-{iteration + 1:06d}.png')
+            elif iteration is None:
+                save_path = osp.join(save_path, f'{folder_name}.png')
+            else:
+                raise ValueError(f'iteration should be number or None, but got {type(iteration)}')
+            from .imageio import imwrite
+            imwrite(metrics.tensor2img(pred), save_path)
+        return results
+
+    def init_weights(self, pretrained=None, strict=True):
+        self.generator.init_weights(pretrained, strict)

@@ -1,0 +1,76 @@
+"""Tile-sharded inference of one large image across the GPUs of a node.
+
+Units = the LR tiles of `CiaoSR.clip_test` (ciaosr.py:233-254): every tile runs encoder + cs_attn +
+head on its own crop with no cross-tile data, so the tile list is partitioned over ranks
+(row-major tile index t -> rank t % R) with no collective on the data path.  The single exchange
+step is the gather of output tiles to rank 0 over RCCL (torch.distributed backend 'nccl' on ROCm;
+'gloo' in the CPU tests), after which rank 0 blends in the reference order (h outer, w inner) so the
+result is bitwise equal to the 1-GPU run.  xGMI is point-to-point: every peer sends its own tiles
+straight to rank 0 over its direct link (all_gather of equal-sized, padded slabs), no ring needed.
+"""
+import torch
+import torch.distributed as dist
+
+from .restorer import tile_grid
+
+
+def partition(n_tiles, world):
+    """tile index -> owning rank, and per-rank tile lists (round-robin keeps neighbours apart so
+    each rank's share of the expensive border tiles is even)."""
+    return [[t for t in range(n_tiles) if t % world == r] for r in range(world)]
+
+
+def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_fn, rank, world, group=None,
+                      device=None, gather_to_all=False):
+    """Generic driver (device-agnostic so it can be exercised with gloo on CPU).
+
+    tile_fn(hi, wi, tile)      -> [B, th*tw, 3] tensor (prediction of the LR crop), th = tw = tile*sf
+    blend_fn(E, Wt, out, y0, x0, th, tw)  accumulates one tile (reference order)
+    finalize_fn(E, Wt)         -> [B, H*W, 3]
+    Returns the blended [B, h*sf*w*sf, 3] prediction on rank 0 (None elsewhere unless gather_to_all).
+    """
+    b, c, h, w = img_shape
+    tile, origins = tile_grid(h, w, tile, overlap)
+    th = tw = round(tile * sf)
+    mine = partition(len(origins), world)[rank]
+    n_max = (len(origins) + world - 1) // world
+    slab = torch.zeros(n_max, b, th * tw, 3, dtype=torch.float32, device=device)
+    for slot, t in enumerate(mine):
+        hi, wi = origins[t]
+        slab[slot] = tile_fn(hi, wi, tile)
+    if world > 1:
+        parts = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(parts, slab, group=group)          # the one exchange step (RCCL over xGMI)
+    else:
+        parts = [slab]
+    if rank != 0 and not gather_to_all:
+        return None
+    E = torch.zeros(b, c, round(h * sf), round(w * sf), dtype=torch.float32, device=device)
+    Wt = torch.zeros_like(E)
+    for t, (hi, wi) in enumerate(origins):                 # reference blend order (ciaosr.py:233-234)
+        out = parts[t % world][t // world]
+        blend_fn(E, Wt, out, round(hi * sf), round(wi * sf), th, tw)
+    return finalize_fn(E, Wt)
+
+
+def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False):
+    """Tile-sharded counterpart of CiaoSR.clip_test on the GPUs of one node."""
+    from . import hip_ops
+    rank = dist.get_rank(group) if rank is None else rank
+    world = dist.get_world_size(group) if world is None else world
+    cfg = restorer.test_cfg
+    sf = cfg.get('scale')
+
+    def tile_fn(hi, wi, tile):
+        out, _ = restorer.run_tile(x_norm, hi, wi, tile, sf)
+        return out
+
+    def blend_fn(E, Wt, out, y0, x0, th, tw):
+        for bi in range(E.shape[0]):
+            hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), y0, x0, th, tw)
+
+    def finalize_fn(E, Wt):
+        return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(E.shape[0])])
+
+    return sharded_clip_test(tuple(x_norm.shape), cfg.get('tile'), cfg.get('tile_overlap'), sf, tile_fn, blend_fn,
+                             finalize_fn, rank, world, group, x_norm.device, gather_to_all)

@@ -1,0 +1,166 @@
+/*
+ * libciaosr_hip.so -- C ABI of the MI355X (gfx950) implementation of CiaoSR's LocalImplicitSR
+ * forward path.  Plain pointers and sizes only; no torch types.  Every pointer is a DEVICE
+ * pointer unless marked "host".  Every function is asynchronous on `stream` (a hipStream_t passed
+ * as void*; NULL = default stream), never allocates persistent device memory (the caller passes
+ * a workspace), returns 0 on success or a negative CIAOSR_ERR_* code, and never throws.
+ *
+ * The reference (caojiezhang/CiaoSR) has no FFI: its hot path is Python nn.Modules.  Each entry
+ * point below names the reference code it replaces (paths relative to the reference root):
+ *   net  = mmedited/models/backbones/sr_backbones/ciaosr_net.py
+ *   csa  = mmedited/models/common/arch_csnln.py
+ *   mlp  = mmedited/models/components/refiners/mlp_refiner.py
+ *   rest = mmedited/models/restorers/ciaosr.py
+ *
+ * Device data layout ("device channel order"):
+ *   feature maps are channels-last  [H][W][C]  fp32;
+ *   an "unfold row" of LR pixel (y,x) is  U[(ki*3+kj)*C + c] = F[y+ki-1][x+kj-1][c]  (0 outside),
+ *   i.e. the reference's F.unfold index c*9+ki*3+kj (net:132) permuted to (ki,kj,c) so that one
+ *   3x3 tap is C contiguous floats; optionally followed by the Cn non-local channels (net:137).
+ *   The host packs MLP weights once with the same permutation (ciaosr_amd/head_hip.py).
+ */
+#ifndef CIAOSR_HIP_H
+#define CIAOSR_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIAOSR_OK 0
+#define CIAOSR_ERR_BAD_ARG (-1)
+#define CIAOSR_ERR_LAUNCH (-2)
+#define CIAOSR_ERR_UNSUPPORTED (-3)
+#define CIAOSR_ERR_WORKSPACE (-4)
+
+#define CIAOSR_ACT_NONE 0
+#define CIAOSR_ACT_RELU 1
+#define CIAOSR_ACT_PRELU 2
+
+#define CIAOSR_MAX_LAYERS 8
+
+/* ---- library ---------------------------------------------------------------------------- */
+int ciaosr_version(void);
+const char* ciaosr_error_string(int code);
+
+/* Opt-in per-kernel HIP-event timing used by bench.py's roofline leg. */
+int ciaosr_prof_enable(int on);
+int ciaosr_prof_filter(const char* kernel /*host; NULL or "" = all kernels*/);
+int ciaosr_prof_reset(void);
+int ciaosr_prof_collect(void); /* synchronises the recorded events and accumulates totals */
+int ciaosr_prof_get(const char* kernel, double* total_ms /*host*/, long* launches /*host*/);
+int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel names seen */
+
+/* ---- layout plumbing -------------------------------------------------------------------- */
+/* [C][H][W] -> [H][W][ld_dst] (first C columns).  Encoder output (net:100) enters here. */
+int ciaosr_nchw_to_hwc_f32(const float* src, float* dst, int C, int H, int W, int ld_dst, void* stream);
+int ciaosr_hwc_to_nchw_f32(const float* src, int ld_src, float* dst, int C, int H, int W, void* stream);
+
+/* ---- dense contraction (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32) ------------------------- */
+/* C[M][N] = act((A[M][K] . B^T + bias[N]) * alpha).  B is [N][K] (b_is_kn == 0, the PyTorch
+ * Linear / 1x1-conv weight layout; replaces addmm at mlp:79-89 and conv2d at csa:418-420,499)
+ * or [K][N] (b_is_kn == 1; the attn.V contraction csa:511).  lda/ldb/ldc multiples of 4, bases
+ * 16-byte aligned.  act: CIAOSR_ACT_*; slope = PReLU slope (host scalar). */
+int ciaosr_gemm_f32(const float* A, int lda, const float* B, int ldb, int b_is_kn, float* C, int ldc,
+                    const float* bias, int M, int N, int K, float alpha, int act, float slope,
+                    void* stream);
+
+/* ---- patch extraction (implicit F.unfold / extract_image_patches) -------------------------- */
+/* out[oy*OW+ox][(i*k+j)*Cs + c] = src[oy*stride-pad+i][ox*stride-pad+j][c] (0 outside), rows
+ * optionally L2-normalised with floor `norm_floor` (csa:494-496).  Replaces F.unfold (net:132-136)
+ * and extract_image_patches (csa:59-87, call sites :462-465, :476-479). */
+int ciaosr_patch_rows_f32(const float* src_hwc, int ld_src, int Hs, int Ws, int Cs, int ksize, int stride,
+                          int pad, int OH, int OW, float* out, int ld_out, int l2_normalize,
+                          float norm_floor, void* stream);
+
+/* ---- CrossScaleAttention, scale 2 (csa:430-532) ------------------------------------------- */
+typedef struct ciaosr_csattn_weights {
+    int channels;                 /* C */
+    const float* w_match1;        /* [C/2][C]  conv_match_1.0.weight  (csa:418) */
+    const float* b_match1;        /* [C/2] */
+    float slope_match1;           /* conv_match_1.1.weight (PReLU), host scalar */
+    const float* w_match2;        /* [C/2][C]  conv_match_2 (csa:419) */
+    const float* b_match2;
+    float slope_match2;
+    const float* w_assembly;      /* [C][C]    conv_assembly (csa:420) */
+    const float* b_assembly;
+    float slope_assembly;
+    const float* w_down;          /* [C][9C]   down.weight (csa:428) packed [co][(a*3+b)*C + ci] */
+    const float* b_down;          /* [C] */
+    float escape_nan;             /* 1e-4 (csa:415) */
+    float softmax_scale;          /* 10   (csa:408) */
+} ciaosr_csattn_weights_t;
+
+size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C);
+/* feat_hwc [H][W][ld_feat] -> out [H][W] rows of C floats with leading dimension ld_out
+ * (lets the caller write straight into the tail columns of the unfold rows, net:137). */
+int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                       float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- head ---------------------------------------------------------------------------------- */
+typedef struct ciaosr_mlp {
+    int n_layers;                          /* Linear layers = len(hidden_list)+1 (mlp:74-89) */
+    int in_dim;                            /* fan-in of layer 0 as stored (device channel order) */
+    int width[CIAOSR_MAX_LAYERS];          /* fan-out of layer i; width[n_layers-1] = out_dim */
+    const float* weight[CIAOSR_MAX_LAYERS];/* layer i: [width[i]][ld[i]] row-major */
+    int ld[CIAOSR_MAX_LAYERS];
+    const float* bias[CIAOSR_MAX_LAYERS];  /* [width[i]] */
+} ciaosr_mlp_t;
+
+typedef struct ciaosr_head_weights {
+    int channels;         /* C  (encoder width)                                   net:57-60 */
+    int nonlocal_channels;/* Cn = C*len(multi_scale) or 0                          net:73-76 */
+    int local_size;       /* 1, 2 or 3  -> 1, 4 or 9 key samples                   net:152-155 */
+    float softmax_scale;  /*                                                        net:215  */
+    /* imnet_k: in = 9C + 4 (unfold | rel_y rel_x scale_y scale_x), out = 9C.      net:63,70
+     * imnet_v: in = 9C + Cn + 4, out = 9C + Cn.                                   net:64,71,75-76
+     * imnet_q: in = 9C + Cn, out = 3.                                             net:62,74
+     * Layer-0 columns and last-layer rows are in device channel order. */
+    ciaosr_mlp_t q, k, v;
+} ciaosr_head_weights_t;
+
+/* Index math only (test/debug): nearest LR index of every query and of its key samples.
+ * q_idx [Q] (= iy*W+ix), k_idx [Q][J], rel [Q][J][2], following net:145-146,159-193. */
+int ciaosr_head_indices_f32(const float* coord, const float* cell, int Q, int chunk, int H, int W,
+                            int local_size, int* q_idx, int* k_idx, float* rel, void* stream);
+
+/* Staged K4 "local attention" (net:211-216): logits_j = sum_d q[d] key_j[d] wk_j[d],
+ * a = softmax(logits / softmax_scale), z = sum_j a_j value_j * wv_j.
+ * unfold [HW][ld_u] rows (9C | Cn), wk [Q*J][ld_wk], wv [Q*J][ld_wv], z [Q][ld_z]. */
+int ciaosr_local_attention_f32(const float* unfold, int ld_u, int C, int Cn, const int* q_idx,
+                               const int* k_idx, const float* wk, int ld_wk, const float* wv, int ld_wv,
+                               float* z, int ld_z, int Q, int J, float softmax_scale, void* stream);
+
+size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w, int Q);
+
+/* query_rgb + batched_predict + bilinear residual (net:88-248) given the encoder feature map.
+ *   feat_hwc   [H][W][C]                      encoder output, channels-last
+ *   csattn     non-NULL iff nonlocal_channels > 0 (net:134-137)
+ *   x_lr_nchw  [3][H][W] normalised LR image for the residual (net:107-108); NULL = no residual
+ *   coord/cell [Q][2] (y,x) fp32                                              (net:88-99)
+ *   chunk      the reference's eval_bsize (net:238-246): only selects which query's cell feeds the
+ *              shift radius (net:162-165); 0 = one chunk.  cs_attn is computed once (result-identical).
+ *   rgb        [Q][3] */
+int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                            const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                            const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- restorer plumbing (rest:142-169, :218-258) --------------------------------------------- */
+/* x = (lq - mean) / std on [3][H][W] */
+int ciaosr_normalize_f32(const float* lq, float* out, int H, int W, const float* mean3 /*host*/,
+                         const float* std3 /*host*/, void* stream);
+/* out[c][y][x] = clamp(pred[(y*W+x)*3+c] * std[c] + mean[c], 0, 1)      (rest:160-169) */
+int ciaosr_denorm_clamp_f32(const float* pred_q3, float* out_chw, int H, int W, const float* mean3 /*host*/,
+                            const float* std3 /*host*/, void* stream);
+/* E[c][y0+y][x0+x] += tile[(y*tw+x)*3+c];  Wt[...] += 1                  (rest:247-254) */
+int ciaosr_tile_blend_f32(float* E, float* Wt, int Himg, int Wimg, const float* tile_q3, int y0, int x0,
+                          int th, int tw, void* stream);
+/* out_q3[(y*W+x)*3+c] = E[c][y][x] / Wt[c][y][x]                          (rest:255-256) */
+int ciaosr_tile_finalize_f32(const float* E, const float* Wt, float* out_q3, int Himg, int Wimg, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIAOSR_HIP_H */

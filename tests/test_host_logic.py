@@ -1,0 +1,103 @@
+"""CPU-side tests: host logic, ABI surface, fail-loud behaviour (no GPU needed)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from tests.helpers import GOLDEN
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small_restorer(test_cfg):
+    from ciaosr_amd import CiaoSR, LocalImplicitSREDSR
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[32, 32])
+    gen = dict(type=LocalImplicitSREDSR,
+               encoder=dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=8, num_blocks=1),
+               imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
+    return CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040),
+                  rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    """Every function declared in include/ciaosr_hip.h is exported by the built .so, and the ctypes
+    table in ciaosr_amd/_lib.py covers exactly that set (no compute calls here)."""
+    from ciaosr_amd import _lib
+    header = open(os.path.join(REPO, 'include', 'ciaosr_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(ciaosr_[a-z0-9_]+)\s*\(', header))
+    assert declared, 'no declarations parsed'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in the header but not exported'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.load().ciaosr_version() >= 100
+    assert _lib.load().ciaosr_error_string(-4).decode().startswith('workspace')
+
+
+def test_product_path_rejects_cpu_tensors():
+    """No CPU fallback: calling the generator on CPU tensors raises instead of computing."""
+    from ciaosr_amd._lib import CiaoSRHipError
+    model = _small_restorer(dict(scale=2))
+    with pytest.raises(CiaoSRHipError):
+        model.restore(torch.rand(1, 3, 8, 8), torch.zeros(1, 4, 2), torch.ones(1, 4, 2))
+
+
+def test_product_code_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, 'ciaosr_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+
+
+@pytest.mark.parametrize('kind', ['rdn', 'edsr'])
+def test_state_dict_names_match_reference(kind):
+    """Parameter names/shapes/order equal what the reference's classes produce (checkpoint compat)."""
+    from ciaosr_amd import CiaoSR, LocalImplicitSREDSR, LocalImplicitSRRDN
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[256] * 4)
+    if kind == 'rdn':
+        gen = dict(type=LocalImplicitSRRDN,
+                   encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
+                                upscale_factor=4, num_layers=8, channel_growth=64),
+                   imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
+    else:
+        gen = dict(type=LocalImplicitSREDSR,
+                   encoder=dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16),
+                   imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
+    m = CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'))
+    names = json.load(open(os.path.join(GOLDEN, f'state_dict_names_{kind}.json')))
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert list(mine) == list(names) and mine == names
+    assert not hasattr(m.generator, 'encoder')       # re-parented then deleted (ciaosr_net.py:314-319)
+
+
+def test_dims_wiring():
+    """ciaosr_net.py:56-76: the config's in/out dims are overwritten from the encoder width."""
+    m = _small_restorer(dict(scale=2)).generator
+    assert m.imnet_q.layers[0].in_features == 8 * 9 + 8
+    assert m.imnet_k.layers[0].in_features == 8 * 9 + 4 and m.imnet_k.layers[-1].out_features == 72
+    assert m.imnet_v.layers[0].in_features == 8 * 9 + 8 + 4 and m.imnet_v.layers[-1].out_features == 80
+    with pytest.raises(TypeError):
+        m.init_weights(pretrained=3)
+
+
+def test_tile_grid_matches_reference_lists():
+    from ciaosr_amd.restorer import tile_grid, tile_starts
+    assert tile_starts(1356, 192, 32) == list(range(0, 1356 - 192, 160)) + [1356 - 192]
+    tile, origins = tile_grid(1356, 2040, 192, 32)
+    assert tile == 192 and len(origins) == 9 * 13 and origins[0] == (0, 0) and origins[-1] == (1164, 1848)
+    tile, origins = tile_grid(48, 48, 192, 32)
+    assert tile == 48 and origins == [(0, 0)]
+
+
+def test_unfold_permutation_is_the_documented_one():
+    from ciaosr_amd.head_hip import unfold_perm
+    C = 5
+    perm = unfold_perm(C, 'cpu')
+    x = torch.arange(C * 9).view(C, 3, 3)          # reference index c*9 + ki*3 + kj
+    dev_order = x.permute(1, 2, 0).reshape(-1)     # (ki,kj,c)
+    assert torch.equal(perm, dev_order)
