@@ -44,19 +44,23 @@ def rdn_ciaosr(test_cfg):
                   rgb_mean=(0.4488, 0.4371, 0.4040), rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
 
 
-def kernel_work(tag, Q, HW, C=64, hidden=256, J=4):
-    """Algorithmic work of ONE launch of kernel `tag` at this workload: (amount, 'flop'|'byte')."""
+def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
+    """Algorithmic work of ALL launches of kernel `tag` in one step of this workload (one 48x48 tile):
+    (amount, 'flop'|'byte').  FLOPs = 2 x MACs of the contraction as the reference writes it, minus the
+    exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query."""
     D, Dv, R = 9 * C, 10 * C, Q * J
+    dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
     table = {
-        'mlp_hidden': (2.0 * R * hidden * hidden, 'flop'),
+        'mlp_hidden': (6 * 2.0 * R * hidden * hidden, 'flop'),
         'mlp_out_k': (2.0 * R * hidden * D, 'flop'),
         'mlp_out_v': (2.0 * R * hidden * Dv, 'flop'),
         'mlp_in_q': (2.0 * Q * Dv * hidden, 'flop'),
-        'mlp_hidden_q': (2.0 * Q * hidden * hidden, 'flop'),
-        'head_table': (2.0 * HW * hidden * (D + Dv) / 2, 'flop'),
+        'mlp_hidden_q': (3 * 2.0 * Q * hidden * hidden, 'flop'),
+        'head_table': (2.0 * HW * hidden * (D + Dv), 'flop'),
         'csa_scores': (2.0 * HW * (HW / 4) * 4.5 * C, 'flop'),
         'csa_attn_v': (2.0 * HW * (HW / 4) * 36 * C, 'flop'),
-        # K4, SURVEY 8(d): wk 4*D*4 + wv 4*Dv*4 + z Dv*4 + coords 16 B per query (+ amortised feature)
+        'enc_conv3x3': (dense + 2 * 2.0 * HW * 9 * C * C, 'flop'),
+        'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),
         'local_attention': (Q * (4.0 * J * D + 4.0 * J * Dv + 4.0 * Dv + 16) + 2.0 * C * 4 * HW, 'byte'),
         'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),
     }
@@ -71,7 +75,11 @@ def cpu_baseline(scale=4):
     seeded_init_(model, seed=0, gain=1.0)
     params = {k[len('generator.'):]: v.detach() for k, v in model.state_dict().items()}
     lq, _ = synthetic_pair(48, 48, scale)
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))                   # small ops: more threads only add contention
     torch.set_num_threads(cores)
     times = []
     for i in range(4):                              # 1 warm-up + 3 timed, ~3 s each on 8 cores
@@ -172,14 +180,15 @@ def main():
             Q, HW = (lr * scale) ** 2, lr * lr
             work = kernel_work(dominant, Q, HW)
             avg_ms = prof_dom[dominant]['avg_ms']
+            step_ms = prof_dom[dominant]['total_ms'] / args.steps      # all launches of the tag in one step
             if work:
                 amount, kind = work
                 if kind == 'flop':
-                    ach = amount / (avg_ms * 1e-3) / 1e12
+                    ach = amount / (step_ms * 1e-3) / 1e12
                     roof = dict(bound='mfma', achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                                 frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
                 else:
-                    ach = amount / (avg_ms * 1e-3) / 1e9
+                    ach = amount / (step_ms * 1e-3) / 1e9
                     roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
                 roof.update(kernel=dominant, avg_launch_ms=round(avg_ms, 5),
@@ -189,7 +198,7 @@ def main():
                 la = prof_all.get('local_attention')
                 if la:                      # north-star side metric: K4 against the HBM roofline
                     b = kernel_work('local_attention', Q, HW)[0]
-                    roof['local_attention_hbm_frac'] = round(b / (la['avg_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                    roof['local_attention_hbm_frac'] = round(b / (la['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         line = {
             'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),

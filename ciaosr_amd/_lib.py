@@ -38,6 +38,22 @@ class CsAttnWeightsT(C.Structure):
                 ('escape_nan', C.c_float), ('softmax_scale', C.c_float)]
 
 
+class ConvT(C.Structure):
+    _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int)]
+
+
+class RdnWeightsT(C.Structure):
+    _fields_ = [('mid_channels', C.c_int), ('growth', C.c_int), ('num_blocks', C.c_int), ('num_layers', C.c_int),
+                ('sfe1', ConvT), ('sfe2', ConvT), ('gff0', ConvT), ('gff1', ConvT),
+                ('dense', C.POINTER(ConvT)), ('lff', C.POINTER(ConvT))]
+
+
+class EdsrWeightsT(C.Structure):
+    _fields_ = [('mid_channels', C.c_int), ('num_blocks', C.c_int), ('res_scale', C.c_float),
+                ('conv_first', ConvT), ('conv_after_body', ConvT),
+                ('conv1', C.POINTER(ConvT)), ('conv2', C.POINTER(ConvT))]
+
+
 _P, _I, _F, _S = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); kept in sync with include/ciaosr_hip.h (tests/test_abi.py checks both ways)
@@ -61,6 +77,10 @@ SIGNATURES = {
     'ciaosr_head_workspace_bytes': (_S, [_I, _I, C.POINTER(HeadWeightsT), _I]),
     'ciaosr_head_forward_f32': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
                                      _I, _I, _P, _P, _S, _P]),
+    'ciaosr_rdn_workspace_bytes': (_S, [_I, _I, C.POINTER(RdnWeightsT)]),
+    'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
+    'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),
+    'ciaosr_edsr_forward_f32': (_I, [_P, _I, _I, C.POINTER(EdsrWeightsT), _P, _P, _S, _P]),
     'ciaosr_normalize_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     'ciaosr_denorm_clamp_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     'ciaosr_tile_blend_f32': (_I, [_P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),

@@ -25,7 +25,7 @@ struct CsaPlan {
 
 static CsaPlan csa_plan(int H, int W, int C) {
     CsaPlan p;
-    p.H = H; p.W = W; p.C = C; p.Ch = C / 2;
+    p.H = H; p.W = W; p.C = C; p.Ch = (int)round_up(C / 2, 4);  // zero-padded half width
     p.Hp = H + (H & 1); p.Wp = W + (W & 1);
     p.L = (p.Hp / 2) * (p.Wp / 2);
     p.Lld = (int)round_up(p.L, 4);
@@ -59,7 +59,7 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
                                   float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream_) {
     CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
     const int C = w->channels;
-    CIAOSR_CHECK_ARG(C >= 8 && (C & 7) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
+    CIAOSR_CHECK_ARG(C >= 4 && (C & 3) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
     hipStream_t s = (hipStream_t)stream_;
     const CsaPlan p = csa_plan(H, W, C);
     Arena ar(workspace, workspace_bytes);

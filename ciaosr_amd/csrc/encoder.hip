@@ -1,0 +1,150 @@
+// Encoder trunks (`gen_feature`) as sequences of implicit-GEMM convolutions on channels-last maps.
+//   RDN  : ciaosr_net.py:321-342 over mmedit's RDN modules (sfe1, sfe2, rdbs[b].layers[l].conv, rdbs[b].lff, gff)
+//   EDSR : ciaosr_net.py:393-408 (conv_first, body[b].conv1/conv2, conv_after_body)
+// Output: feature map [H][W][C] channels-last, exactly what the head consumes.
+#include "ops.h"
+
+namespace ciaosr {
+
+int conv2d_hwc(const float* src, int ld_src, int H, int W, int Cin, const float* wgt, int ldw, const float* bias,
+               int Cout, int ksize, float* dst, int ld_dst, float* dst2, int ld_dst2, const float* res, int ld_res,
+               int act, float alpha, float* partial, size_t partial_floats, hipStream_t s, const char* tag);
+
+__global__ void image_to_hwc4_kernel(const float* __restrict__ x, float* __restrict__ out, long HW) {
+    // [3][H][W] -> [H*W][4] with a zero 4th channel (so the first conv moves float4 taps)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<float4*>(out)[i] = make_float4(x[i], x[HW + i], x[2 * HW + i], 0.f);
+}
+
+// first conv: 3 (padded to 4) input channels -> explicit patch rows [HW][36] + MFMA GEMM
+static int first_conv(const float* x_nchw, int H, int W, const ciaosr_conv_t& c, float* img4, float* rows,
+                      float* dst, int ld_dst, hipStream_t s) {
+    const long HW = (long)H * W;
+    {
+        ProfScope prof("image_to_hwc4", s);
+        int grid = (int)((HW + 255) / 256);
+        hipLaunchKernelGGL(image_to_hwc4_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, s, x_nchw, img4, HW);
+    }
+    int rc = launch_status("image_to_hwc4");
+    if (rc != CIAOSR_OK) return rc;
+    rc = patch_rows(img4, 4, H, W, 4, 3, 1, 1, H, W, rows, 36, 0, 0.f, s, "enc_patch_first");
+    if (rc != CIAOSR_OK) return rc;
+    return gemm_f32(rows, 36, c.weight, 36, false, dst, ld_dst, c.bias, (int)HW, c.cout, 36, 1.f, CIAOSR_ACT_NONE, 0.f,
+                    s, "enc_conv_first");
+}
+
+static bool conv_ok(const ciaosr_conv_t& c, int cin, int cout, int k) {
+    return c.weight && c.bias && c.cin == cin && c.cout == cout && c.ksize == k;
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weights_t* w) {
+    if (!w || H <= 0 || W <= 0) return 0;
+    const size_t HW = (size_t)H * W;
+    const int C = w->mid_channels, G = w->growth, cb = C + G * w->num_layers;
+    size_t n = HW * 4 + HW * 36 + HW * C /*sfe1*/ + 2 * HW * cb /*block buffers*/ +
+               HW * (size_t)G * w->num_blocks /*global concat*/ + HW * C /*gff0*/ + 16 * HW * (size_t)(C > G ? C : G);
+    return n * sizeof(float) + 16 * 256;
+}
+
+extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
+                                      float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream_) {
+    CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
+    const int C = w->mid_channels, G = w->growth, NB = w->num_blocks, NL = w->num_layers;
+    CIAOSR_CHECK_ARG(C % 32 == 0 && G % 32 == 0 && NB >= 1 && NL >= 1 && w->dense && w->lff);
+    CIAOSR_CHECK_ARG(C == G);   // mmedit's RDN feeds rdbs[b>0] with channel_growth channels and adds sfe1 (mid) at the end
+    CIAOSR_CHECK_ARG(conv_ok(w->sfe1, 3, C, 3) && conv_ok(w->sfe2, C, C, 3));
+    CIAOSR_CHECK_ARG(conv_ok(w->gff0, G * NB, C, 1) && conv_ok(w->gff1, C, C, 3));
+    if (workspace_bytes < ciaosr_rdn_workspace_bytes(H, W, w)) return CIAOSR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t HW = (size_t)H * W;
+    const int cb = C + G * NL;
+    Arena ar(workspace, workspace_bytes);
+    float* img4 = ar.take<float>(HW * 4);
+    float* rows = ar.take<float>(HW * 36);
+    float* sfe1 = ar.take<float>(HW * C);
+    float* X[2] = {ar.take<float>(HW * cb), ar.take<float>(HW * cb)};
+    float* Gc = ar.take<float>(HW * (size_t)G * NB);
+    float* g0 = ar.take<float>(HW * C);
+    const size_t pf = 16 * HW * (size_t)(C > G ? C : G);
+    float* part = ar.take<float>(pf);
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+    int rc;
+#define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    RUN(first_conv(x_nchw, H, W, w->sfe1, img4, rows, sfe1, C, s));
+    // sfe2 -> block 0 input (columns [0, C) of X[0])
+    RUN(conv2d_hwc(sfe1, C, H, W, C, w->sfe2.weight, 9 * C, w->sfe2.bias, C, 3, X[0], cb, nullptr, 0, nullptr, 0,
+                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
+    for (int b = 0; b < NB; ++b) {
+        float* x = X[b & 1];
+        float* xn = X[(b + 1) & 1];
+        for (int l = 0; l < NL; ++l) {
+            const ciaosr_conv_t& c = w->dense[b * NL + l];
+            const int cin = C + G * l;
+            CIAOSR_CHECK_ARG(conv_ok(c, cin, G, 3));
+            // DenseLayer: cat([x, relu(conv(x))]) == write the G new channels next to the inputs
+            RUN(conv2d_hwc(x, cb, H, W, cin, c.weight, 9 * cin, c.bias, G, 3, x + cin, cb, nullptr, 0, nullptr, 0,
+                           CIAOSR_ACT_RELU, 1.f, part, pf, s, "enc_conv3x3"));
+        }
+        const ciaosr_conv_t& f = w->lff[b];
+        CIAOSR_CHECK_ARG(conv_ok(f, cb, G, 1));
+        // RDB output = x + lff(dense): goes to the global concat and is the next block's input
+        RUN(conv2d_hwc(x, cb, H, W, cb, f.weight, cb, f.bias, G, 1, Gc + (size_t)b * G, G * NB,
+                       b + 1 < NB ? xn : nullptr, cb, x, cb, CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
+    }
+    RUN(conv2d_hwc(Gc, G * NB, H, W, G * NB, w->gff0.weight, G * NB, w->gff0.bias, C, 1, g0, C, nullptr, 0, nullptr, 0,
+                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
+    RUN(conv2d_hwc(g0, C, H, W, C, w->gff1.weight, 9 * C, w->gff1.bias, C, 3, feat_hwc, C, nullptr, 0, sfe1, C,
+                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
+#undef RUN
+    return CIAOSR_OK;
+}
+
+extern "C" size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w) {
+    if (!w || H <= 0 || W <= 0) return 0;
+    const size_t HW = (size_t)H * W;
+    const int C = w->mid_channels;
+    return (HW * 4 + HW * 36 + 4 * HW * C + 16 * HW * C) * sizeof(float) + 16 * 256;
+}
+
+extern "C" int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w,
+                                       float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream_) {
+    CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
+    const int C = w->mid_channels, NB = w->num_blocks;
+    CIAOSR_CHECK_ARG(C % 32 == 0 && NB >= 0 && (NB == 0 || (w->conv1 && w->conv2)));
+    CIAOSR_CHECK_ARG(conv_ok(w->conv_first, 3, C, 3) && conv_ok(w->conv_after_body, C, C, 3));
+    if (workspace_bytes < ciaosr_edsr_workspace_bytes(H, W, w)) return CIAOSR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t HW = (size_t)H * W;
+    Arena ar(workspace, workspace_bytes);
+    float* img4 = ar.take<float>(HW * 4);
+    float* rows = ar.take<float>(HW * 36);
+    float* first = ar.take<float>(HW * C);
+    float* a = ar.take<float>(HW * C);
+    float* b = ar.take<float>(HW * C);
+    float* tmp = ar.take<float>(HW * C);
+    const size_t pf = 16 * HW * (size_t)C;
+    float* part = ar.take<float>(pf);
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+    int rc;
+#define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    RUN(first_conv(x_nchw, H, W, w->conv_first, img4, rows, first, C, s));
+    const float* cur = first;
+    float* pp[2] = {a, b};
+    for (int i = 0; i < NB; ++i) {
+        CIAOSR_CHECK_ARG(conv_ok(w->conv1[i], C, C, 3) && conv_ok(w->conv2[i], C, C, 3));
+        // ResidualBlockNoBN: x + conv2(relu(conv1(x))) * res_scale
+        RUN(conv2d_hwc(cur, C, H, W, C, w->conv1[i].weight, 9 * C, w->conv1[i].bias, C, 3, tmp, C, nullptr, 0, nullptr, 0,
+                       CIAOSR_ACT_RELU, 1.f, part, pf, s, "enc_conv3x3"));
+        RUN(conv2d_hwc(tmp, C, H, W, C, w->conv2[i].weight, 9 * C, w->conv2[i].bias, C, 3, pp[i & 1], C, nullptr, 0, cur, C,
+                       CIAOSR_ACT_NONE, w->res_scale, part, pf, s, "enc_conv3x3"));
+        cur = pp[i & 1];
+    }
+    RUN(conv2d_hwc(cur, C, H, W, C, w->conv_after_body.weight, 9 * C, w->conv_after_body.bias, C, 3, feat_hwc, C, nullptr, 0,
+                   first, C, CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
+#undef RUN
+    return CIAOSR_OK;
+}

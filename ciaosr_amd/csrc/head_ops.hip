@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadRowsP p) {
     const long c0 = cell0_index(q, p.chunk);
     const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, p.local_size);
     const int kpix = s.ky * p.W + s.kx;
-    const float sy = __fmul_rn(p.cell[2 * q], (float)p.H);       // scale_ = cell * [H, W]  (:191-193)
-    const float sx = __fmul_rn(p.cell[2 * q + 1], (float)p.W);
+    const float sy = mul_rn(p.cell[2 * q], (float)p.H);       // scale_ = cell * [H, W]  (:191-193)
+    const float sx = mul_rn(p.cell[2 * q + 1], (float)p.W);
     if (lane == 0) {
         p.k_idx[row] = kpix;
         if (j == 0) {
@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
         if (p.x_lr) {
             // F.grid_sample(bilinear, padding_mode='border', align_corners=False)  (ciaosr_net.py:107-108)
             const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
-            float fy = __fsub_rn(__fmul_rn(__fadd_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
-            float fx = __fsub_rn(__fmul_rn(__fadd_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
+            float fy = sub_rn(mul_rn(add_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
+            float fx = sub_rn(mul_rn(add_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
             fy = fminf((float)(p.H - 1), fmaxf(fy, 0.f));
             fx = fminf((float)(p.W - 1), fmaxf(fx, 0.f));
             const float y0f = floorf(fy), x0f = floorf(fx);

@@ -6,10 +6,29 @@
 
 namespace ciaosr {
 
+// HIP's __fmul_rn/__fadd_rn are plain operators and may be contracted into FMAs under the default
+// -ffp-contract=fast-honor-pragmas; these helpers carry the pragma that forbids it.
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float div_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a / b;
+}
+
 // F.grid_sample(mode='nearest', align_corners=False) source index on an axis of n samples:
 // u = (c + 1) * (n / 2) - 0.5 (three roundings), idx = round-half-even(u).   (ciaosr_net.py:145)
 __device__ __forceinline__ int nearest_index(float c, int n) {
-    const float u = __fsub_rn(__fmul_rn(__fadd_rn(c, 1.0f), (float)n * 0.5f), 0.5f);
+    const float u = sub_rn(mul_rn(add_rn(c, 1.0f), (float)n * 0.5f), 0.5f);
     return (int)__builtin_rintf(u);
 }
 
@@ -18,10 +37,10 @@ __device__ __forceinline__ int nearest_index(float c, int n) {
 __device__ __forceinline__ float shifted_coord(float c, float cell0, int n, int sign) {
     float out = c;
     if (sign != 0) {
-        const float t = __fdiv_rn((float)(n - 1), __fsub_rn(1.0f, cell0));
-        const float r = __fdiv_rn(1.0f, t);
-        const float d = __fadd_rn(__fmul_rn((float)sign, r), 1e-6f);
-        out = __fadd_rn(c, d);
+        const float t = div_rn((float)(n - 1), sub_rn(1.0f, cell0));
+        const float r = div_rn(1.0f, t);
+        const float d = add_rn(mul_rn((float)sign, r), 1e-6f);
+        out = add_rn(c, d);
     }
     const float lo = (float)(-1 + 1e-6), hi = (float)(1 - 1e-6);
     return fminf(fmaxf(out, lo), hi);
@@ -31,7 +50,7 @@ __device__ __forceinline__ float shifted_coord(float c, float cell0, int n, int 
 __device__ __forceinline__ float pixel_centre(int k, int n) {
     const float v0r = (float)(-1.0 + 1.0 / (double)n);
     const float r2 = (float)(2.0 / (double)n);
-    return __fadd_rn(v0r, __fmul_rn(r2, (float)k));
+    return add_rn(v0r, mul_rn(r2, (float)k));
 }
 
 // shift list of query_rgb (ciaosr_net.py:152-155): local_size 1 -> {0}; 2 -> {-1,+1}^2; 3 -> {-1,0,1}^2
@@ -62,8 +81,8 @@ __device__ __forceinline__ KeySample key_sample(float cy, float cx, float cell0y
     // grid_sample zero-pads out-of-range indices; after the clamp they cannot occur, but stay safe
     s.ky = min(max(s.ky, 0), H - 1);
     s.kx = min(max(s.kx, 0), W - 1);
-    s.rel_y = __fmul_rn(__fsub_rn(cy, pixel_centre(s.ky, H)), (float)H);
-    s.rel_x = __fmul_rn(__fsub_rn(cx, pixel_centre(s.kx, W)), (float)W);
+    s.rel_y = mul_rn(sub_rn(cy, pixel_centre(s.ky, H)), (float)H);
+    s.rel_x = mul_rn(sub_rn(cx, pixel_centre(s.kx, W)), (float)W);
     return s;
 }
 

@@ -3,6 +3,7 @@
 // All accesses are float4 along the channel (innermost) dimension: one 3x3 / 6x6 tap of a
 // channels-last map is C contiguous floats.
 #include "common.h"
+#include "index_math.h"
 
 namespace ciaosr {
 
@@ -227,7 +228,7 @@ __global__ void denorm_clamp_kernel(const float* __restrict__ pred, float* __res
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i / HW);
         const long p = i - (long)c * HW;
-        const float v = __fadd_rn(__fmul_rn(pred[p * 3 + c], std.v[c]), mean.v[c]);
+        const float v = add_rn(mul_rn(pred[p * 3 + c], std.v[c]), mean.v[c]);
         out[i] = fminf(fmaxf(v, 0.f), 1.f);
     }
 }

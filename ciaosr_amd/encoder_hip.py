@@ -1,0 +1,109 @@
+"""Weight packing + launch of the HIP encoder trunks (ciaosr_rdn_forward_f32 / ciaosr_edsr_forward_f32).
+
+Conv weights [co][ci][a][b] are packed once to [co][(a*k+b)*ci' + ci] so that one tap of the
+channels-last map is contiguous in K (implicit-GEMM convolution, csrc/conv_f32.hip)."""
+import ctypes as C
+
+import torch
+
+from . import _lib, hip_ops
+
+
+def _pack_conv(conv, keep, pad_cin_to=None):
+    w = conv.weight.detach().float()
+    co, ci, kh, kw = w.shape
+    w = w.permute(0, 2, 3, 1)
+    if pad_cin_to is not None and ci < pad_cin_to:
+        w = torch.nn.functional.pad(w, (0, pad_cin_to - ci))
+    w = w.reshape(co, -1).contiguous()
+    b = conv.bias.detach().float().contiguous()
+    hip_ops.require_gpu(w, b)
+    keep += [w, b]
+    st = _lib.ConvT()
+    st.weight, st.bias, st.cin, st.cout, st.ksize = w.data_ptr(), b.data_ptr(), ci, co, kh
+    return st
+
+
+class PackedEncoder:
+    """Packed weights of the re-parented RDN / EDSR trunk of a LocalImplicitSR generator."""
+
+    def __init__(self, net, kind):
+        self.net, self.kind = net, kind
+        self._key = None
+        self._st = None
+        self._keep = None
+
+    def _params(self):
+        n = self.net
+        mods = [n.sfe1, n.sfe2, n.rdbs, n.gff] if self.kind == 'rdn' else [n.conv_first, n.body, n.conv_after_body]
+        return [p for m in mods for p in m.parameters()]
+
+    def struct(self):
+        key = tuple((p.data_ptr(), p._version) for p in self._params())
+        if self._st is not None and key == self._key:
+            return self._st
+        n, keep = self.net, []
+        if self.kind == 'rdn':
+            st = _lib.RdnWeightsT()
+            nb, nl = len(n.rdbs), len(n.rdbs[0].layers)
+            st.mid_channels = n.sfe1.out_channels
+            st.growth = n.rdbs[0].layers[0].conv.out_channels
+            st.num_blocks, st.num_layers = nb, nl
+            st.sfe1 = _pack_conv(n.sfe1, keep, pad_cin_to=4)
+            st.sfe2 = _pack_conv(n.sfe2, keep)
+            st.gff0 = _pack_conv(n.gff[0], keep)
+            st.gff1 = _pack_conv(n.gff[1], keep)
+            dense = (_lib.ConvT * (nb * nl))()
+            lff = (_lib.ConvT * nb)()
+            for b in range(nb):
+                for l in range(nl):
+                    dense[b * nl + l] = _pack_conv(n.rdbs[b].layers[l].conv, keep)
+                lff[b] = _pack_conv(n.rdbs[b].lff, keep)
+            st.dense, st.lff = dense, lff
+            keep += [dense, lff]
+        else:
+            st = _lib.EdsrWeightsT()
+            nb = len(n.body)
+            st.mid_channels = n.conv_first.out_channels
+            st.num_blocks = nb
+            st.res_scale = float(n.body[0].res_scale) if nb else 1.0
+            st.conv_first = _pack_conv(n.conv_first, keep, pad_cin_to=4)
+            st.conv_after_body = _pack_conv(n.conv_after_body, keep)
+            c1 = (_lib.ConvT * max(nb, 1))()
+            c2 = (_lib.ConvT * max(nb, 1))()
+            for b in range(nb):
+                c1[b] = _pack_conv(n.body[b].conv1, keep)
+                c2[b] = _pack_conv(n.body[b].conv2, keep)
+            st.conv1, st.conv2 = c1, c2
+            keep += [c1, c2]
+        self._st, self._keep, self._key = st, keep, key
+        return st
+
+    def supported(self):
+        n = self.net
+        c = (n.sfe1 if self.kind == 'rdn' else n.conv_first).out_channels
+        if c % 32:
+            return False
+        if self.kind == 'rdn':
+            return n.rdbs[0].layers[0].conv.out_channels == c and n.sfe1.in_channels == 3
+        return n.conv_first.in_channels == 3
+
+    @torch.no_grad()
+    def forward_hwc(self, x_chw):
+        """x [3,H,W] normalised LR (GPU) -> feature [H,W,C] channels-last."""
+        x_chw = x_chw.contiguous().float()
+        hip_ops.require_gpu(x_chw)
+        _, H, W = x_chw.shape
+        st = self.struct()
+        lib = _lib.load()
+        if self.kind == 'rdn':
+            nbytes = lib.ciaosr_rdn_workspace_bytes(H, W, C.byref(st))
+            fn = 'ciaosr_rdn_forward_f32'
+        else:
+            nbytes = lib.ciaosr_edsr_workspace_bytes(H, W, C.byref(st))
+            fn = 'ciaosr_edsr_forward_f32'
+        ws = hip_ops.workspace(nbytes, x_chw.device, slot='encoder')
+        out = torch.empty(H, W, st.mid_channels, dtype=torch.float32, device=x_chw.device)
+        _lib.call(fn, hip_ops.ptr(x_chw), H, W, C.byref(st), hip_ops.ptr(out), hip_ops.ptr(ws), ws.numel(),
+                  hip_ops.stream_ptr())
+        return out

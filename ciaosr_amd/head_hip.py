@@ -85,22 +85,27 @@ class PackedHead:
         return st
 
     @torch.no_grad()
-    def forward(self, feature_chw, x_lr_chw, coord, cell, chunk):
-        """feature [C,H,W], x_lr [3,H,W] or None, coord/cell [Q,2] -> rgb [Q,3] (all on the GPU)."""
+    def forward(self, feature_chw, x_lr_chw, coord, cell, chunk, feature_hwc=None):
+        """feature [C,H,W] (or channels-last [H,W,C] via feature_hwc), x_lr [3,H,W] or None,
+        coord/cell [Q,2] -> rgb [Q,3] (all on the GPU)."""
         net = self.net
-        feature_chw = feature_chw.contiguous().float()
+        if feature_hwc is not None:
+            feature_hwc = feature_hwc.contiguous().float()
+            feature_chw = feature_hwc.permute(2, 0, 1)      # shape bookkeeping only
+        else:
+            feature_chw = feature_chw.contiguous().float()
         coord = coord.contiguous().float()
         cell = cell.contiguous().float()
         if x_lr_chw is not None:
             x_lr_chw = x_lr_chw.contiguous().float()
-        hip_ops.require_gpu(feature_chw, x_lr_chw, coord, cell)
+        hip_ops.require_gpu(feature_hwc if feature_hwc is not None else feature_chw, x_lr_chw, coord, cell)
         Cc, H, W = feature_chw.shape
         Q = coord.shape[0]
         st = self.struct()
         cs = None
         if net.non_local_attn:
             cs, _ = net.cs_attn.packed()
-        feat_hwc = hip_ops.nchw_to_hwc(feature_chw)
+        feat_hwc = feature_hwc if feature_hwc is not None else hip_ops.nchw_to_hwc(feature_chw)
         nbytes = _lib.load().ciaosr_head_workspace_bytes(H, W, C.byref(st), Q)
         ws = hip_ops.workspace(nbytes, coord.device)
         rgb = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)

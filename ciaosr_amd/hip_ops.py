@@ -31,9 +31,9 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def workspace(nbytes, device):
+def workspace(nbytes, device, slot='head'):
     """Grow-only per-device scratch buffer (never freed while the process lives)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = (slot, device.type, device.index if device.index is not None else torch.cuda.current_device())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None

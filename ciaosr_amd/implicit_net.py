@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from . import hip_ops
 from .head_hip import PackedHead
+from .encoder_hip import PackedEncoder
 from .nonlocal_attn import CrossScaleAttention
 from .registry import build_backbone, build_component
 
@@ -61,8 +62,15 @@ class LocalImplicitSRNet(nn.Module):
 
     def forward(self, x, coord, cell, test_mode=False):
         """x [B,3,H,W] normalised LR, coord/cell [B,Q,2] (y,x) -> [B,Q,3]   (ciaosr_net.py:88-110)."""
-        features = self.gen_feature(x)
         chunk = None if (self.eval_bsize is None or not test_mode) else self.eval_bsize
+        enc = getattr(self, '_encoder_hip', None)
+        if enc is not None and x.is_cuda and enc.supported():
+            # HIP trunk: channels-last feature map goes straight into the head (no NCHW round trip)
+            x = x.contiguous().float()
+            outs = [self._head.forward(None, x[b], coord[b], cell[b], chunk, feature_hwc=enc.forward_hwc(x[b]))
+                    for b in range(x.shape[0])]
+            return torch.stack(outs, 0)
+        features = self.gen_feature(x)
         return self._predict(features, coord, cell, chunk, x)
 
     def query_rgb(self, features, coord, scale=None):
@@ -110,15 +118,24 @@ class LocalImplicitSRRDN(LocalImplicitSRNet):
         self.gff = self.encoder.gff
         self.num_blocks = self.encoder.num_blocks
         del self.encoder
+        self._encoder_hip = PackedEncoder(self, 'rdn')
 
     def gen_feature(self, x):
+        enc = self._encoder_hip
+        if x.is_cuda and enc.supported():
+            x = x.contiguous().float()
+            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b])) for b in range(x.shape[0])])]
+        return [self.gen_feature_torch(x)]
+
+    def gen_feature_torch(self, x):
+        """PyTorch-ROCm (MIOpen) trunk, kept for widths the HIP convolution does not cover."""
         sfe1 = self.sfe1(x)
         h = self.sfe2(sfe1)
         local = []
         for i in range(self.num_blocks):
             h = self.rdbs[i](h)
             local.append(h)
-        return [self.gff(torch.cat(local, 1)) + sfe1]
+        return self.gff(torch.cat(local, 1)) + sfe1
 
 
 class LocalImplicitSREDSR(LocalImplicitSRNet):
@@ -133,7 +150,15 @@ class LocalImplicitSREDSR(LocalImplicitSRNet):
         self.body = self.encoder.body
         self.conv_after_body = self.encoder.conv_after_body
         del self.encoder
+        self._encoder_hip = PackedEncoder(self, 'edsr')
 
     def gen_feature(self, x):
+        enc = self._encoder_hip
+        if x.is_cuda and enc.supported():
+            x = x.contiguous().float()
+            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b])) for b in range(x.shape[0])])]
+        return [self.gen_feature_torch(x)]
+
+    def gen_feature_torch(self, x):
         f = self.conv_first(x)
-        return [self.conv_after_body(self.body(f)) + f]
+        return self.conv_after_body(self.body(f)) + f

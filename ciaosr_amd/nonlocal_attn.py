@@ -43,11 +43,13 @@ class CrossScaleAttention(nn.Module):
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]
         Cc = self.channel
+        half = Cc // 2
+        pad = (-half) % 4            # the kernels move channels as float4: zero-pad C/2 to a multiple of 4
+        padw = lambda w: torch.nn.functional.pad(w.detach().reshape(half, Cc).float(), (0, 0, 0, pad)).contiguous()
+        padb = lambda b: torch.nn.functional.pad(b.detach().float(), (0, pad)).contiguous()
         keep = dict(
-            w1=self.conv_match_1[0].weight.detach().reshape(Cc // 2, Cc).contiguous().float(),
-            b1=self.conv_match_1[0].bias.detach().contiguous().float(),
-            w2=self.conv_match_2[0].weight.detach().reshape(Cc // 2, Cc).contiguous().float(),
-            b2=self.conv_match_2[0].bias.detach().contiguous().float(),
+            w1=padw(self.conv_match_1[0].weight), b1=padb(self.conv_match_1[0].bias),
+            w2=padw(self.conv_match_2[0].weight), b2=padb(self.conv_match_2[0].bias),
             wa=self.conv_assembly[0].weight.detach().reshape(Cc, Cc).contiguous().float(),
             ba=self.conv_assembly[0].bias.detach().contiguous().float(),
             # down.weight [co][ci][a][b] -> [co][(a*3+b)*C + ci]

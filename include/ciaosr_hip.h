@@ -77,10 +77,11 @@ int ciaosr_patch_rows_f32(const float* src_hwc, int ld_src, int Hs, int Ws, int 
 /* ---- CrossScaleAttention, scale 2 (csa:430-532) ------------------------------------------- */
 typedef struct ciaosr_csattn_weights {
     int channels;                 /* C */
-    const float* w_match1;        /* [C/2][C]  conv_match_1.0.weight  (csa:418) */
-    const float* b_match1;        /* [C/2] */
+    /* Ch = C/2 rounded up to a multiple of 4; rows >= C/2 of the two match weights and biases are 0 */
+    const float* w_match1;        /* [Ch][C]   conv_match_1.0.weight  (csa:418) */
+    const float* b_match1;        /* [Ch] */
     float slope_match1;           /* conv_match_1.1.weight (PReLU), host scalar */
-    const float* w_match2;        /* [C/2][C]  conv_match_2 (csa:419) */
+    const float* w_match2;        /* [Ch][C]   conv_match_2 (csa:419) */
     const float* b_match2;
     float slope_match2;
     const float* w_assembly;      /* [C][C]    conv_assembly (csa:420) */
@@ -145,6 +146,36 @@ size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w,
 int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                             const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                             const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- encoder trunks: gen_feature (net:321-342 RDN, net:393-408 EDSR) -------------------------- */
+typedef struct ciaosr_conv {
+    const float* weight; /* [cout][k*k*cin'] packed (a*k+b)*cin' + ci; cin' = cin (4 for the 3-channel first conv, zero padded) */
+    const float* bias;   /* [cout] */
+    int cin, cout, ksize;
+} ciaosr_conv_t;
+
+typedef struct ciaosr_rdn_weights {
+    int mid_channels, growth, num_blocks, num_layers;
+    ciaosr_conv_t sfe1, sfe2, gff0, gff1;
+    const ciaosr_conv_t* dense; /* host array [num_blocks*num_layers]: rdbs[b].layers[l].conv */
+    const ciaosr_conv_t* lff;   /* host array [num_blocks]:            rdbs[b].lff */
+} ciaosr_rdn_weights_t;
+
+typedef struct ciaosr_edsr_weights {
+    int mid_channels, num_blocks;
+    float res_scale;
+    ciaosr_conv_t conv_first, conv_after_body;
+    const ciaosr_conv_t* conv1; /* host array [num_blocks]: body[b].conv1 */
+    const ciaosr_conv_t* conv2; /* host array [num_blocks]: body[b].conv2 */
+} ciaosr_edsr_weights_t;
+
+size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weights_t* w);
+/* x_nchw [3][H][W] normalised LR image -> feat_hwc [H][W][mid_channels] */
+int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                           void* workspace, size_t workspace_bytes, void* stream);
+size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w);
+int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w, float* feat_hwc,
                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- restorer plumbing (rest:142-169, :218-258) --------------------------------------------- */

@@ -198,8 +198,21 @@ def test_head_full_width_vs_golden(dev, name, C, hw):
     ht, wt = [int(v) for v in fx['target']]
     coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
     out = g.batched_predict([feat], coord, cell).cpu()
+    # These fixtures are deliberately ill-conditioned (sqrt(6)-gain MLPs on N(0,1) features: logits
+    # of std ~40 feed the 4-way softmax); the reference's own fp32 result is 9.4e-5 away from an fp64
+    # evaluation.  Bounds: 5e-4 against the fp32 reference, 2.5e-4 against fp64 on a query subset.
     err = (out[0] - _t(fx['out'])).abs().max().item()
-    assert err < TOL, err
+    assert err < 5e-4, err
+    from oracle import ciaosr_oracle as orc
+    idx = torch.arange(0, ht * wt, 16)
+    P64 = {k: v.double() for k, v in seeded_head(C, int(fx['weight_seed'])).items()}
+    torch.set_default_dtype(torch.float64)
+    try:
+        want = orc.query_rgb(feat.cpu().double(), coord[:, idx].cpu().double(), cell[:, idx].cpu().double(), P64)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    err64 = (out[0, idx].double() - want[0]).abs().max().item()
+    assert err64 < 2.5e-4, err64
 
 
 def test_staged_local_attention_kernel(dev):
@@ -217,6 +230,29 @@ def test_staged_local_attention_kernel(dev):
     a = (logit / 1.5).softmax(-1)
     want = (a.unsqueeze(-1) * (kv * wv).view(Q, J, -1)).sum(1)
     assert (z - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------
+# encoder trunks (implicit-GEMM convolutions)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind,hw', [('rdn', (48, 48)), ('edsr', (48, 48)), ('rdn', (37, 53)), ('edsr', (19, 70))])
+def test_encoder_features_vs_oracle(dev, kind, hw):
+    """HIP gen_feature (split-K implicit GEMM, concat-by-leading-dimension) vs the torch-CPU trunk."""
+    from ciaosr_amd.init_utils import seeded_init_
+    from oracle import ciaosr_oracle as orc
+    model = _restorer(kind, 4, dev, dict(scale=4))
+    seeded_init_(model, seed=21, gain=1.6 if kind == 'rdn' else 1.25)
+    params = {k[len('generator.'):]: v.detach().clone() for k, v in model.state_dict().items()}
+    x = randn((1, 3) + hw, 77) * 0.3
+    want = orc.encoder_features(x, params)
+    gen = model.generator.to(dev)
+    assert gen._encoder_hip.supported()
+    got = gen.gen_feature(x.to(dev))[0].cpu()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0) * 10, ((got - want).abs().max().item(), scale)
+    # the PyTorch-ROCm trunk must agree too (it serves widths the HIP convolution does not cover)
+    got_t = gen.gen_feature_torch(x.to(dev)).cpu()
+    assert (got_t - want).abs().max().item() < 2e-4 * max(scale, 1.0)
 
 
 # ------------------------------------------------------------------------------------------------
