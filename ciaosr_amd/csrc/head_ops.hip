@@ -201,6 +201,19 @@ __global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// make_coord + cell of an Ht x Wt target grid on the device (ciaosr.py:237-243, mmedit make_coord)
+// ---------------------------------------------------------------------------------------------
+__global__ void make_coord_cell_kernel(float* __restrict__ coord, float* __restrict__ cell, int Ht, int Wt) {
+    const long n = (long)Ht * Wt;
+    const float cy = (float)(2.0 / (double)Ht), cx = (float)(2.0 / (double)Wt);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / Wt), x = (int)(i - (long)y * Wt);
+        reinterpret_cast<float2*>(coord)[i] = make_float2(pixel_centre(y, Ht), pixel_centre(x, Wt));
+        reinterpret_cast<float2*>(cell)[i] = make_float2(cy, cx);
+    }
+}
+
 // ---- host wrappers --------------------------------------------------------------------------
 int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
                  int* q_idx, int* k_idx, float* rel, hipStream_t s) {
@@ -245,6 +258,16 @@ extern "C" int ciaosr_head_indices_f32(const float* coord, const float* cell, in
     CIAOSR_CHECK_ARG(coord && cell && q_idx && k_idx && Q > 0 && H > 0 && W > 0);
     CIAOSR_CHECK_ARG(local_size >= 1 && local_size <= 3);
     return head_indices(coord, cell, 0, Q, chunk, H, W, local_size, q_idx, k_idx, rel, (hipStream_t)stream);
+}
+
+extern "C" int ciaosr_make_coord_cell_f32(float* coord, float* cell, int Ht, int Wt, void* stream) {
+    CIAOSR_CHECK_ARG(coord && cell && Ht > 0 && Wt > 0);
+    ProfScope prof("make_coord_cell", (hipStream_t)stream);
+    long n = (long)Ht * Wt;
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(make_coord_cell_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, (hipStream_t)stream, coord,
+                       cell, Ht, Wt);
+    return launch_status("make_coord_cell");
 }
 
 extern "C" int ciaosr_local_attention_f32(const float* unfold, int ld_u, int C, int Cn, const int* q_idx,

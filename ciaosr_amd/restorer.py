@@ -106,8 +106,9 @@ class CiaoSR(BasicRestorer):
         patch = x_norm[..., hi:hi + tile, wi:wi + tile].contiguous()
         b = patch.shape[0]
         th, tw = round(patch.shape[-2] * sf), round(patch.shape[-1] * sf)
-        coord = make_coord((th, tw)).to(patch.device).unsqueeze(0).expand(b, -1, 2).contiguous()
-        cell = make_cell((th, tw)).to(patch.device).unsqueeze(0).expand(b, -1, 2).contiguous()
+        coord, cell = hip_ops.make_coord_cell(th, tw, patch.device)       # generated on the GPU, cached per shape
+        coord = coord.unsqueeze(0).expand(b, -1, 2)
+        cell = cell.unsqueeze(0).expand(b, -1, 2)
         return self.generator(patch, coord, cell, test_mode=True), (th, tw)
 
     @torch.no_grad()

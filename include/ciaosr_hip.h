@@ -121,6 +121,11 @@ typedef struct ciaosr_head_weights {
     ciaosr_mlp_t q, k, v;
 } ciaosr_head_weights_t;
 
+/* Grid-centre coordinates and cells of an Ht x Wt target: coord[q] = (seq_y[i], seq_x[j]) with
+ * seq[i] = fp32(-1 + 1/n) + fp32(2/n) * fp32(i), cell[q] = (2/Ht, 2/Wt), q = i*Wt + j
+ * (mmedit make_coord, call site rest:240; cell rest:241-243). */
+int ciaosr_make_coord_cell_f32(float* coord, float* cell, int Ht, int Wt, void* stream);
+
 /* Index math only (test/debug): nearest LR index of every query and of its key samples.
  * q_idx [Q] (= iy*W+ix), k_idx [Q][J], rel [Q][J][2], following net:145-146,159-193. */
 int ciaosr_head_indices_f32(const float* coord, const float* cell, int Q, int chunk, int H, int W,

@@ -98,6 +98,15 @@ def test_nearest_indices_bit_exact(dev):
         assert np.array_equal(k_idx[:, 3], tp * n + tp), key      # (+1,+1)
 
 
+@pytest.mark.parametrize('ht,wt', [(192, 192), (158, 131), (19, 24), (768, 5)])
+def test_device_make_coord_bit_exact(dev, ht, wt):
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    coord, cell = hip_ops.make_coord_cell(ht, wt, dev)
+    assert torch.equal(coord.cpu(), make_coord((ht, wt)))
+    assert torch.equal(cell.cpu(), make_cell((ht, wt)))
+
+
 def test_rel_offsets_match_oracle(dev):
     from ciaosr_amd import hip_ops
     from ciaosr_amd.coords import make_coord, make_cell
