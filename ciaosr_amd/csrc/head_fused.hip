@@ -1,0 +1,429 @@
+// Fused head kernels (hidden width 256, local_size 2): activations never leave the CU.
+//
+//  head_kv_fused   one workgroup = 64 rows = 16 queries x 4 key samples.
+//                  index math -> layer-0 rows from the hoisted tables -> phi_k hidden layers
+//                  in LDS -> phi_k output layer fused with  logit = sum_d q[d] key[d] w_k[d]  -> softmax
+//                  over the 4 samples -> phi_v hidden layers -> phi_v output layer fused with
+//                  z = sum_j a_j value_j * w_v,j  -> Z [Q][9C+Cn]                 (ciaosr_net.py:159-216)
+//  head_decode_fused   64 queries per workgroup: phi_q on Z (layer 0 streamed through LDS), last
+//                  Linear (-> 3) and the bilinear/border residual on the VALU      (ciaosr_net.py:107-108,220-222)
+//
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  A operand = the 64 x 256 activation tile in LDS (row stride
+// 260 floats: conflict-free ds_read_b128, one float4 feeds 4 MFMAs through the consistent k permutation
+// k = 8j + 4h + e); B operand = weights pre-packed on the device into per-wave fragment order
+// [n_tile][j][lane][4] so that a wave's fragment is one coalesced 1 KiB load straight from L2 into VGPRs
+// (weights are shared by every workgroup and never staged in LDS).  4 waves split the output columns;
+// layers run in place: all waves finish reading X, barrier, write bias+ReLU results, barrier.
+// Two workgroups per CU (69 KB LDS each) overlap one's epilogue/barrier bubbles with the other's MFMAs.
+#include "index_math.h"
+#include "ops.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FBM = 64;        // rows per workgroup
+constexpr int FH = 256;        // hidden width
+constexpr int FLD = FH + 4;    // LDS row stride (floats)
+constexpr int FNJ = FH / 8;    // k-chunks of 8 per 256-wide layer
+
+// ---- fragment packing ---------------------------------------------------------------------------
+// W [N][ld] (K valid columns) -> P[nt][j][lane][4]: lane (i = lane&31, h = lane>>5) holds
+// W[nt*32 + i][8j + 4h .. 8j + 4h + 3]; rows >= N and columns >= K are zero.
+__global__ void pack_fragments_kernel(const float* __restrict__ W, int ld, int N, int K, float* __restrict__ P,
+                                      int n_tiles, int nj) {
+    const long total = (long)n_tiles * nj * 64;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long t = idx >> 6;
+        const int j = (int)(t % nj), nt = (int)(t / nj);
+        const int n = nt * 32 + (lane & 31), k = 8 * j + 4 * (lane >> 5);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            const float* r = W + (size_t)n * ld;
+            if (k < K) v.x = r[k];
+            if (k + 1 < K) v.y = r[k + 1];
+            if (k + 2 < K) v.z = r[k + 2];
+            if (k + 3 < K) v.w = r[k + 3];
+        }
+        reinterpret_cast<float4*>(P)[idx] = v;
+    }
+}
+
+// ---- one MFMA pass: acc[mi][ni] (+)= W_tile . X_tile^T  (SWAPPED operands) --------------------------
+// The weight fragment is the MFMA A operand and the activation fragment the B operand, so the result
+// tile is D[n][m]: a lane holds ONE activation row m = 32*mi + (lane&31) and the 16 output columns
+// n = 32*tile + 8g + 4h + e (g = reg>>2, e = reg&3, h = lane>>5), i.e. four groups of 4 CONSECUTIVE
+// columns.  Epilogues are therefore per-row: one key/value row pointer per lane, float4 loads along the
+// channel axis, ds_write_b128 / float4 stores, and the reduction over channels is in-register.
+// xa: &X[lane row][4h] of this lane; wf: this wave's first n-tile fragment stream (+lane), tile stride in float4
+template <int NT>
+__device__ __forceinline__ void mma_pass(const float* xa, const float4* __restrict__ wf, int nj, long tile_stride,
+                                         f32x16 (&acc)[2][NT]) {
+    float4 fb[NT], fbn[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) fb[ni] = wf[ni * tile_stride];
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+        if (j + 1 < nj) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fbn[ni] = wf[ni * tile_stride + (long)(j + 1) * 64];
+        }
+        const float4 fa0 = *reinterpret_cast<const float4*>(xa + 8 * j);
+        const float4 fa1 = *reinterpret_cast<const float4*>(xa + 32 * FLD + 8 * j);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa0.x, acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa1.x, acc[1][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa0.y, acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa1.y, acc[1][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa0.z, acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa1.z, acc[1][ni], 0, 0, 0);
+            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa0.w, acc[0][ni], 0, 0, 0);
+            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa1.w, acc[1][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) fb[ni] = fbn[ni];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+}
+
+// X[m][n] <- relu(acc + bias[n]) for the wave's 64 columns: 4 consecutive columns per register group
+__device__ __forceinline__ void store_relu_tile(float* X, const f32x16 (&acc)[2][2], const float* __restrict__ bias,
+                                                int w, int li, int lh) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float4 o;
+                o.x = fmaxf(acc[mi][ni][4 * g] + b.x, 0.f);
+                o.y = fmaxf(acc[mi][ni][4 * g + 1] + b.y, 0.f);
+                o.z = fmaxf(acc[mi][ni][4 * g + 2] + b.z, 0.f);
+                o.w = fmaxf(acc[mi][ni][4 * g + 3] + b.w, 0.f);
+                *reinterpret_cast<float4*>(X + (32 * mi + li) * FLD + col) = o;
+            }
+        }
+}
+
+// hidden layer in place: X <- relu(X . W^T + b); wave w owns columns [64w, 64w+64)
+__device__ __forceinline__ void hidden_layer(float* X, const float* __restrict__ frag, const float* __restrict__ bias,
+                                             int w, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    mma_pass<2>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(frag) + (size_t)(2 * w) * FNJ * 64 + lane, FNJ,
+                (long)FNJ * 64, acc);
+    __syncthreads();   // every wave has finished reading X
+    store_relu_tile(X, acc, bias, w, li, lh);
+    __syncthreads();
+}
+
+// layer-0 rows of one chain into X (64 rows x 256)
+__device__ __forceinline__ void build_rows(float* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
+    // 64 rows x 64 float4: thread handles float4 column (t & 63) of rows (t >> 6) + 4*s
+    const int n4 = t & 63;
+    float4 tw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
+    for (int r = t >> 6; r < FBM; r += 4) {
+        const float4 tv = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[r] * FH)[n4];
+        const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
+        float4 o;
+        o.x = fmaxf(tv.x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f);
+        o.y = fmaxf(tv.y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f);
+        o.z = fmaxf(tv.z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f);
+        o.w = fmaxf(tv.w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f);
+        *reinterpret_cast<float4*>(X + r * FLD + 4 * n4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                   // [64][260]
+    float* s_t4 = X + FBM * FLD;                       // [64][4]  rel_y rel_x scale_y scale_x
+    float* s_part = s_t4 + FBM * 4;                    // [4][64]  per-wave partial logits
+    float* s_attn = s_part + 4 * FBM;                  // [64]
+    int* s_kpix = reinterpret_cast<int*>(s_attn + FBM);  // [64]
+    int* s_qpix = s_kpix + FBM;                        // [16]
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * (FBM / 4);          // local query index of row 0
+
+    // ---- index math: one thread per row (ciaosr_net.py:145-193) ---------------------------------
+    if (t < FBM) {
+        const int ql = qbase + (t >> 2), j = t & 3;
+        int kpix = 0;
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ql < p.nq) {
+            const long q = p.q0 + ql;
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            const long c0 = p.chunk > 0 ? (q / p.chunk) * p.chunk : 0;
+            const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, 2);
+            kpix = s.ky * p.W + s.kx;
+            t4[0] = s.rel_y; t4[1] = s.rel_x;
+            t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
+            t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
+            if (j == 0) {
+                const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+                s_qpix[t >> 2] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+            }
+        } else if (j == 0) {
+            s_qpix[t >> 2] = -1;
+        }
+        s_kpix[t] = kpix;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
+    }
+    __syncthreads();
+
+    // ================= phi_k =====================================================================
+    build_rows(X, p.k, s_kpix, s_t4, t);
+    __syncthreads();
+    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+
+    // output layer fused with the logit dot product: wave w takes 32-column units w, w+4, ...
+    {
+        float part[2] = {0.f, 0.f};
+        const int n_units = (p.k.n_out + 31) >> 5;
+        const float* krow[2];
+        const float* qrow[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = 32 * mi + li;
+            krow[mi] = p.U + (size_t)s_kpix[m] * p.ldu;
+            const int qp = s_qpix[m >> 2];
+            qrow[mi] = qp >= 0 ? p.U + (size_t)qp * p.ldu : nullptr;
+        }
+        for (int u = w; u < n_units; u += 4) {
+            f32x16 acc[2][1];
+            zero_acc<1>(acc);
+            mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
+                        FNJ, 0, acc);
+            // logit += sum_d q[d] * (key[d] * (w_k[d] + b[d]))   (ciaosr_net.py:203,214)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                if (d0 < p.k.n_out) {
+                    const float4 b = *reinterpret_cast<const float4*>(p.k.bias_out + d0);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        if (qrow[mi]) {
+                            const float4 kv = *reinterpret_cast<const float4*>(krow[mi] + d0);
+                            const float4 qv = *reinterpret_cast<const float4*>(qrow[mi] + d0);
+                            part[mi] += qv.x * (kv.x * (acc[mi][0][4 * g] + b.x)) + qv.y * (kv.y * (acc[mi][0][4 * g + 1] + b.y)) +
+                                        qv.z * (kv.z * (acc[mi][0][4 * g + 2] + b.z)) + qv.w * (kv.w * (acc[mi][0][4 * g + 3] + b.w));
+                        }
+                    }
+                }
+            }
+        }
+        // the two half-waves hold different channels of the same rows
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            part[mi] += __shfl_xor(part[mi], 32, 64);
+            if (lh == 0) s_part[w * FBM + 32 * mi + li] = part[mi];
+        }
+    }
+    __syncthreads();
+    // softmax over the 4 key samples of each query (ciaosr_net.py:214-215)
+    if (t < FBM / 4) {
+        float lg[4], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * t + j;
+            lg[j] = (s_part[row] + s_part[FBM + row] + s_part[2 * FBM + row] + s_part[3 * FBM + row]) / p.softmax_scale;
+            m = fmaxf(m, lg[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lg[j] = expf(lg[j] - m); den += lg[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_attn[4 * t + j] = lg[j] / den;
+    }
+    // (the barrier inside build_rows' caller below also orders s_attn)
+
+    // ================= phi_v =====================================================================
+    build_rows(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
+    __syncthreads();
+    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    {
+        const int n_units = (p.v.n_out + 31) >> 5;
+        const float* vrow[2];
+        float av[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int m = 32 * mi + li;
+            vrow[mi] = p.U + (size_t)s_kpix[m] * p.ldu;
+            av[mi] = s_attn[m];
+        }
+        const int jsel = li & 3;     // this lane's key sample; also the channel group it stores
+        for (int u = w; u < n_units; u += 4) {
+            f32x16 acc[2][1];
+            zero_acc<1>(acc);
+            mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
+                        FNJ, 0, acc);
+            // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
+            // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float4 zsel = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 32 * u + 8 * g + 4 * lh;
+                    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (d0 < p.v.n_out) {
+                        const float4 b = *reinterpret_cast<const float4*>(p.v.bias_out + d0);
+                        const float4 vv = *reinterpret_cast<const float4*>(vrow[mi] + d0);
+                        z.x = av[mi] * (vv.x * (acc[mi][0][4 * g] + b.x));
+                        z.y = av[mi] * (vv.y * (acc[mi][0][4 * g + 1] + b.y));
+                        z.z = av[mi] * (vv.z * (acc[mi][0][4 * g + 2] + b.z));
+                        z.w = av[mi] * (vv.w * (acc[mi][0][4 * g + 3] + b.w));
+                    }
+                    z.x += __shfl_xor(z.x, 1, 64); z.y += __shfl_xor(z.y, 1, 64);
+                    z.z += __shfl_xor(z.z, 1, 64); z.w += __shfl_xor(z.w, 1, 64);
+                    z.x += __shfl_xor(z.x, 2, 64); z.y += __shfl_xor(z.y, 2, 64);
+                    z.z += __shfl_xor(z.z, 2, 64); z.w += __shfl_xor(z.w, 2, 64);
+                    if (jsel == g) zsel = z;
+                }
+                const int ql = qbase + ((32 * mi + li) >> 2);
+                const int d0 = 32 * u + 8 * jsel + 4 * lh;
+                if (ql < p.nq && d0 < p.v.n_out) *reinterpret_cast<float4*>(p.Z + (size_t)ql * p.ldz + d0) = zsel;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;   // [64][260]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * FBM;
+
+    // layer 0: K = Dv streamed through X in chunks of 256 columns
+    f32x16 acc[2][2];
+    zero_acc<2>(acc);
+    for (int k0 = 0; k0 < p.Dv; k0 += FH) {
+        const int kc = min(FH, p.Dv - k0);          // multiple of 8
+        if (k0 > 0) __syncthreads();                 // previous chunk fully consumed
+        for (int idx = t; idx < FBM * (FH / 4); idx += 256) {
+            const int r = idx >> 6, c4 = (idx & 63) * 4;
+            const int ql = qbase + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ql < p.nq && c4 < kc) v = *reinterpret_cast<const float4*>(p.Z + (size_t)ql * p.ldz + k0 + c4);
+            *reinterpret_cast<float4*>(X + r * FLD + c4) = v;
+        }
+        __syncthreads();
+        mma_pass<2>(X + li * FLD + 4 * lh,
+                    reinterpret_cast<const float4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 3)) * 64 + lane,
+                    kc >> 3, (long)p.nj_in * 64, acc);
+    }
+    __syncthreads();
+    store_relu_tile(X, acc, p.bias_in, w, li, lh);
+    __syncthreads();
+    for (int l = 0; l < p.n_hidden; ++l) hidden_layer(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
+
+    // last Linear (256 -> 3): 4 threads per row, 64 columns each
+    const int row = t >> 2, part = t & 3;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    {
+        const float* xr = X + row * FLD + 64 * part;
+        const float* w0 = p.w_last + 64 * part;
+        const float* w1 = w0 + p.ld_last;
+        const float* w2 = w1 + p.ld_last;
+#pragma unroll 4
+        for (int n = 0; n < 64; n += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(xr + n);
+            const float4 u0 = *reinterpret_cast<const float4*>(w0 + n);
+            const float4 u1 = *reinterpret_cast<const float4*>(w1 + n);
+            const float4 u2 = *reinterpret_cast<const float4*>(w2 + n);
+            a0 += x.x * u0.x + x.y * u0.y + x.z * u0.z + x.w * u0.w;
+            a1 += x.x * u1.x + x.y * u1.y + x.z * u1.z + x.w * u1.w;
+            a2 += x.x * u2.x + x.y * u2.y + x.z * u2.z + x.w * u2.w;
+        }
+    }
+    a0 += __shfl_xor(a0, 1, 64); a0 += __shfl_xor(a0, 2, 64);
+    a1 += __shfl_xor(a1, 1, 64); a1 += __shfl_xor(a1, 2, 64);
+    a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+    const int ql = qbase + row;
+    if (part < 3 && ql < p.nq) {
+        const long q = p.q0 + ql;
+        float v = (part == 0 ? a0 : part == 1 ? a1 : a2) + p.b_last[part];
+        if (p.x_lr) {
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            float fy = sub_rn(mul_rn(add_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
+            float fx = sub_rn(mul_rn(add_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
+            fy = fminf((float)(p.H - 1), fmaxf(fy, 0.f));
+            fx = fminf((float)(p.W - 1), fmaxf(fx, 0.f));
+            const float y0f = floorf(fy), x0f = floorf(fx);
+            const int y0 = (int)y0f, x0 = (int)x0f;
+            const float wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
+            const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx;
+            const float* img = p.x_lr + (size_t)part * p.H * p.W;
+            const bool y1ok = y0 + 1 < p.H, x1ok = x0 + 1 < p.W;
+            float r = img[(size_t)y0 * p.W + x0] * (wx0 * wy0);
+            if (x1ok) r += img[(size_t)y0 * p.W + x0 + 1] * (wx1 * wy0);
+            if (y1ok) r += img[(size_t)(y0 + 1) * p.W + x0] * (wx0 * wy1);
+            if (y1ok && x1ok) r += img[(size_t)(y0 + 1) * p.W + x0 + 1] * (wx1 * wy1);
+            v += r;
+        }
+        p.rgb[q * 3 + part] = v;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+size_t fragment_floats(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 7) / 8) * 64 * 4; }
+
+int pack_fragments(const float* W, int ld, int N, int K, float* P, hipStream_t s) {
+    const int n_tiles = (N + 31) / 32, nj = (K + 7) / 8;
+    const long total = (long)n_tiles * nj * 64;
+    int grid = (int)((total + 255) / 256);
+    ProfScope prof("pack_fragments", s);
+    hipLaunchKernelGGL(pack_fragments_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, W, ld, N, K, P, n_tiles, nj);
+    return launch_status("pack_fragments");
+}
+
+constexpr size_t kFusedLds = (size_t)(FBM * FLD + FBM * 4 + 4 * FBM + FBM) * sizeof(float) + (FBM + 16) * sizeof(int);
+
+int head_kv_fused(const FusedKVP& p, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { allow_big_lds(head_kv_fused_kernel, kFusedLds); attr = true; }
+    ProfScope prof("head_kv_fused", s);
+    hipLaunchKernelGGL(head_kv_fused_kernel, dim3(ceil_div(p.nq, FBM / 4)), dim3(256), kFusedLds, s, p);
+    return launch_status("head_kv_fused");
+}
+
+int head_decode_fused(const FusedQP& p, hipStream_t s) {
+    const size_t lds = (size_t)FBM * FLD * sizeof(float);
+    static bool attr = false;
+    if (!attr) { allow_big_lds(head_decode_fused_kernel, lds); attr = true; }
+    ProfScope prof("head_decode_fused", s);
+    hipLaunchKernelGGL(head_decode_fused_kernel, dim3(ceil_div(p.nq, FBM)), dim3(256), lds, s, p);
+    return launch_status("head_decode_fused");
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+extern "C" size_t ciaosr_fragment_floats(int N, int K) { return fragment_floats(N, K); }
+
+extern "C" int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, float* out, void* stream) {
+    CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
+    return pack_fragments(W, ld, N, K, out, (hipStream_t)stream);
+}

@@ -65,6 +65,49 @@ int head_rows(const HeadRowsP& p, hipStream_t s);
 int local_attention(const LocalAttnP& p, hipStream_t s);
 int decode_residual(const DecodeP& p, hipStream_t s);
 
+// head_fused.hip
+struct FusedChain {
+    const float* table;
+    const float* tail;
+    int ld_tail;
+    const float* frag_hidden[CIAOSR_MAX_LAYERS];
+    const float* bias_hidden[CIAOSR_MAX_LAYERS];
+    int n_hidden;
+    const float* frag_out;
+    const float* bias_out;
+    int n_out;
+};
+struct FusedKVP {
+    const float* coord;
+    const float* cell;
+    long q0;
+    int nq, chunk, H, W;
+    const float* U;
+    int ldu, D, Dv;
+    FusedChain k, v;
+    float softmax_scale;
+    float* Z;
+    int ldz;
+};
+struct FusedQP {
+    const float* Z; int ldz, Dv;
+    const float* frag_in;
+    const float* bias_in;
+    int nj_in;
+    const float* frag_hidden[CIAOSR_MAX_LAYERS];
+    const float* bias_hidden[CIAOSR_MAX_LAYERS];
+    int n_hidden;
+    const float* w_last; int ld_last;
+    const float* b_last;
+    const float* x_lr;
+    const float* coord;
+    long q0;
+    int nq, H, W;
+    float* rgb;
+};
+int head_kv_fused(const FusedKVP& p, hipStream_t s);
+int head_decode_fused(const FusedQP& p, hipStream_t s);
+
 // bump allocator over the caller-provided workspace (256-byte aligned carve-outs)
 struct Arena {
     char* base;

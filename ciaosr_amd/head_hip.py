@@ -33,7 +33,7 @@ class PackedHead:
         mods = [self.net.imnet_q, self.net.imnet_k, self.net.imnet_v]
         return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
 
-    def _pack_mlp(self, mlp, col_perm=None, row_perm=None):
+    def _pack_mlp(self, mlp, col_perm=None, row_perm=None, frag_layers=()):
         st = _lib.MlpT()
         lin = mlp.linears()
         if len(lin) > _lib.MAX_LAYERS:
@@ -56,6 +56,15 @@ class PackedHead:
             st.weight[i] = w.data_ptr()
             st.ld[i] = w.stride(0)
             st.bias[i] = b.data_ptr()
+            st.frag[i] = None
+            if i in frag_layers and w.shape[1] % 8 == 0:
+                # MFMA fragment order for the fused kernels, packed on the device by the library
+                n, k = w.shape
+                frag = torch.empty(_lib.load().ciaosr_fragment_floats(n, k), dtype=torch.float32, device=w.device)
+                _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(frag),
+                          hip_ops.stream_ptr())
+                keep.append(frag)
+                st.frag[i] = frag.data_ptr()
         st.in_dim = lin[0].weight.shape[1]
         return st, keep
 
@@ -77,9 +86,10 @@ class PackedHead:
         st.channels, st.nonlocal_channels = Cc, Cn
         st.local_size, st.softmax_scale = int(net.local_size), float(net.softmax_scale)
         keep = []
-        st.k, kk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm)
-        st.v, kv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows)
-        st.q, kq = self._pack_mlp(net.imnet_q, col_perm=v_rows)
+        nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
+        st.k, kk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
+        st.v, kv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
+        st.q, kq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
         self._keep = kk + kv + kq
         self._st, self._key = st, key
         return st

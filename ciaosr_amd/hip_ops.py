@@ -159,6 +159,11 @@ def tile_finalize(E, Wt):
     return out
 
 
+def set_head_mode(mode):
+    """0 = automatic (fused head kernels when eligible), 1 = force the staged per-layer path."""
+    _lib.call('ciaosr_set_head_mode', int(mode))
+
+
 class profile:
     """Context manager around the library's per-kernel HIP-event timing."""
 

@@ -107,7 +107,19 @@ typedef struct ciaosr_mlp {
     const float* weight[CIAOSR_MAX_LAYERS];/* layer i: [width[i]][ld[i]] row-major */
     int ld[CIAOSR_MAX_LAYERS];
     const float* bias[CIAOSR_MAX_LAYERS];  /* [width[i]] */
+    /* optional: layer i pre-packed into MFMA fragment order by ciaosr_pack_fragments_f32 (NULL = not
+     * packed).  With every hidden width 256, local_size 2 and fragments present the fused kernels run
+     * (head_kv_fused / head_decode_fused); otherwise the staged per-layer GEMM path. */
+    const float* frag[CIAOSR_MAX_LAYERS];
 } ciaosr_mlp_t;
+
+/* MFMA fragment packing of a Linear weight W[N][ld] (K valid columns): out[nt][j][lane][4] with
+ * lane (i = lane&31, h = lane>>5) holding W[32nt+i][8j+4h .. 8j+4h+3]; zero padded. */
+size_t ciaosr_fragment_floats(int N, int K);
+int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, float* out, void* stream);
+
+/* 0 = automatic (fused kernels when eligible), 1 = force the staged per-layer path (tests, rooflines) */
+int ciaosr_set_head_mode(int mode);
 
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */

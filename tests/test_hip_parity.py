@@ -224,6 +224,28 @@ def test_head_full_width_vs_golden(dev, name, C, hw):
     assert err64 < 2.5e-4, err64
 
 
+def test_fused_and_staged_head_paths_agree(dev):
+    """The fused kernels (head_kv_fused / head_decode_fused) against the staged per-layer path on the
+    same inputs (both through ciaosr_head_forward_f32), including a ragged last workgroup."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 3, head_gain=2.0), dev, eval_bsize=30000)
+    feat = randn((1, 64, 21, 30), 11).to(dev)
+    ht, wt = 59, 83                         # Q = 4897: not a multiple of 16 or 64
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    x = (randn((1, 3, 21, 30), 12) * 0.3).to(dev)
+    try:
+        hip_ops.set_head_mode(1)
+        staged = g._predict([feat], coord, cell, 30000, x).cpu()
+        hip_ops.set_head_mode(0)
+        with hip_ops.profile():
+            fused = g._predict([feat], coord, cell, 30000, x).cpu()
+        assert 'head_kv_fused' in hip_ops.profile.results(), 'fused kernels did not run'
+    finally:
+        hip_ops.set_head_mode(0)
+    assert (fused - staged).abs().max() < 5e-5 * max(1.0, staged.abs().max().item())
+
+
 def test_staged_local_attention_kernel(dev):
     """K4 alone: ciaosr_local_attention_f32 against a direct torch evaluation of net:211-216."""
     from ciaosr_amd import hip_ops
