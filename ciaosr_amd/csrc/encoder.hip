@@ -10,6 +10,9 @@ int conv2d_hwc(const float* src, int ld_src, int H, int W, int Cin, const float*
                int Cout, int ksize, float* dst, int ld_dst, float* dst2, int ld_dst2, const float* res, int ld_res,
                int act, float alpha, float* partial, size_t partial_floats, hipStream_t s, const char* tag);
 
+int dense_scatter_step(float* X, int ldx, int H, int W, int step, int num_layers, const float* wgt, const float* bias_all,
+                       float* acc_buf, float* partial, size_t partial_floats, hipStream_t s);
+
 __global__ void image_to_hwc4_kernel(const float* __restrict__ x, float* __restrict__ out, long HW) {
     // [3][H][W] -> [H*W][4] with a zero 4th channel (so the first conv moves float4 taps)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x)
@@ -46,7 +49,8 @@ extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weig
     const size_t HW = (size_t)H * W;
     const int C = w->mid_channels, G = w->growth, cb = C + G * w->num_layers;
     size_t n = HW * 4 + HW * 36 + HW * C /*sfe1*/ + 2 * HW * cb /*block buffers*/ +
-               HW * (size_t)G * w->num_blocks /*global concat*/ + HW * C /*gff0*/ + 16 * HW * (size_t)(C > G ? C : G);
+               HW * (size_t)G * w->num_blocks /*global concat*/ + HW * C /*gff0*/ + HW * (size_t)G * w->num_layers /*scatter sums*/ +
+               16 * HW * (size_t)(C > G ? C : G);
     return n * sizeof(float) + 16 * 256;
 }
 
@@ -69,6 +73,7 @@ extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const c
     float* X[2] = {ar.take<float>(HW * cb), ar.take<float>(HW * cb)};
     float* Gc = ar.take<float>(HW * (size_t)G * NB);
     float* g0 = ar.take<float>(HW * C);
+    float* accb = ar.take<float>(HW * (size_t)G * NL);
     const size_t pf = 16 * HW * (size_t)(C > G ? C : G);
     float* part = ar.take<float>(pf);
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
@@ -81,13 +86,21 @@ extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const c
     for (int b = 0; b < NB; ++b) {
         float* x = X[b & 1];
         float* xn = X[(b + 1) & 1];
-        for (int l = 0; l < NL; ++l) {
-            const ciaosr_conv_t& c = w->dense[b * NL + l];
-            const int cin = C + G * l;
-            CIAOSR_CHECK_ARG(conv_ok(c, cin, G, 3));
-            // DenseLayer: cat([x, relu(conv(x))]) == write the G new channels next to the inputs
-            RUN(conv2d_hwc(x, cb, H, W, cin, c.weight, 9 * cin, c.bias, G, 3, x + cin, cb, nullptr, 0, nullptr, 0,
-                           CIAOSR_ACT_RELU, 1.f, part, pf, s, "enc_conv3x3"));
+        if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
+            // scatter form: input group s (64 channels) feeds every later dense layer in ONE convolution with
+            // N = 64*(NL-s) output channels and K = 576: no split-K slabs, 8 launches instead of 16
+            for (int st = 0; st < NL; ++st)
+                RUN(dense_scatter_step(x, cb, H, W, st, NL, w->scatter_weight[b * NL + st],
+                                       w->scatter_bias + (size_t)b * NL * 64, accb, part, pf, s));
+        } else {
+            for (int l = 0; l < NL; ++l) {
+                const ciaosr_conv_t& c = w->dense[b * NL + l];
+                const int cin = C + G * l;
+                CIAOSR_CHECK_ARG(conv_ok(c, cin, G, 3));
+                // DenseLayer: cat([x, relu(conv(x))]) == write the G new channels next to the inputs
+                RUN(conv2d_hwc(x, cb, H, W, cin, c.weight, 9 * cin, c.bias, G, 3, x + cin, cb, nullptr, 0, nullptr, 0,
+                               CIAOSR_ACT_RELU, 1.f, part, pf, s, "enc_conv3x3"));
+            }
         }
         const ciaosr_conv_t& f = w->lff[b];
         CIAOSR_CHECK_ARG(conv_ok(f, cb, G, 1));

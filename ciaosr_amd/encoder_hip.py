@@ -61,6 +61,23 @@ class PackedEncoder:
                 lff[b] = _pack_conv(n.rdbs[b].lff, keep)
             st.dense, st.lff = dense, lff
             keep += [dense, lff]
+            st.scatter_weight, st.scatter_bias = None, None
+            if st.mid_channels == 64 and st.growth == 64:
+                # scatter form of the dense blocks (include/ciaosr_hip.h): stack, for input group s, the weight
+                # slices of every later layer -> one N = 64*(nl-s), K = 576 convolution per group
+                ptrs = (C.c_void_p * (nb * nl))()
+                for b in range(nb):
+                    convs = [n.rdbs[b].layers[l].conv.weight.detach().float() for l in range(nl)]   # [64][64(l+1)][3][3]
+                    for s_ in range(nl):
+                        sl = [convs[l][:, 64 * s_:64 * s_ + 64].permute(0, 2, 3, 1).reshape(64, 576) for l in range(s_, nl)]
+                        wst = torch.cat(sl, 0).contiguous()
+                        keep.append(wst)
+                        ptrs[b * nl + s_] = wst.data_ptr()
+                bias = torch.stack([torch.stack([n.rdbs[b].layers[l].conv.bias.detach().float() for l in range(nl)])
+                                    for b in range(nb)]).contiguous()
+                keep += [ptrs, bias]
+                st.scatter_weight = C.cast(ptrs, C.POINTER(C.c_void_p))
+                st.scatter_bias = bias.data_ptr()
         else:
             st = _lib.EdsrWeightsT()
             nb = len(n.body)

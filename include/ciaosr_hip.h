@@ -177,6 +177,13 @@ typedef struct ciaosr_rdn_weights {
     ciaosr_conv_t sfe1, sfe2, gff0, gff1;
     const ciaosr_conv_t* dense; /* host array [num_blocks*num_layers]: rdbs[b].layers[l].conv */
     const ciaosr_conv_t* lff;   /* host array [num_blocks]:            rdbs[b].lff */
+    /* optional "scatter form" of the dense blocks (mid_channels == growth == 64): for block b and input group s
+     * (s = 0: block input, s >= 1: output of dense layer s-1) the weight slices of all later layers stacked:
+     * scatter_weight[b*num_layers + s] = [64*(num_layers-s)][9*64], row (l-s)*64+co, column tap*64+ci
+     *   = rdbs[b].layers[l].conv.weight[co][64*s + ci][tap];  scatter_bias = [num_blocks][num_layers][64].
+     * NULL = every dense layer runs as its own (gather-form) convolution. */
+    const float* const* scatter_weight; /* host array [num_blocks*num_layers] of device pointers */
+    const float* scatter_bias;          /* device */
 } ciaosr_rdn_weights_t;
 
 typedef struct ciaosr_edsr_weights {
