@@ -31,15 +31,24 @@ struct GemmP {
     float alpha, slope;
     int act;
     int tiles_n, n_wg;
+    unsigned a_bytes, b_bytes;   // buffer-descriptor extents (< 4 GiB)
 };
 
-__device__ __forceinline__ float4 ld4_guard(const float* p, int k, int K) {
-    // p points at element k of a row; zero-fill past K (K need not be a multiple of 4)
-    if (k + 3 < K) return *reinterpret_cast<const float4*>(p);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < K) v.x = p[0];
-    if (k + 1 < K) v.y = p[1];
-    if (k + 2 < K) v.z = p[2];
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobG = 0xFFFFFFF0u;
+
+// Tile loads go through buffer descriptors: rows past M / N and k past K get an out-of-range offset and the
+// hardware returns zeros without a branch ("cond ? load : 0" makes hipcc branch around every load and wait
+// vmcnt(0) per element, turning the 8 loads of a K-tile into dependent round trips).  A float4 that straddles
+// K (K % 4 != 0) is masked component-wise when it is written to LDS, i.e. after the MFMA phase.
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ float4 mask4(float4 v, int first, int limit) {
+    if (first + 1 >= limit) v.y = 0.f;
+    if (first + 2 >= limit) v.z = 0.f;
+    if (first + 3 >= limit) v.w = 0.f;
     return v;
 }
 
@@ -65,6 +74,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
 
     float4 ra[4], rb[4];
     const int nk = (p.K + BK - 1) / BK;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
 
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
@@ -73,8 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             const int idx = t + 256 * s;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
             const int gm = m0 + r, gk = k0 + c4;
-            ra[s] = (gm < p.M && gk < p.K) ? ld4_guard(p.A + (size_t)gm * p.lda + gk, gk, p.K)
-                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[s] = buf_ld4(rs_a, (gm < p.M && gk < p.K) ? ((unsigned)gm * (unsigned)p.lda + (unsigned)gk) * 4u : kOobG);
         }
         if (!B_KN) {
 #pragma unroll
@@ -82,8 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
                 const int idx = t + 256 * s;
                 const int r = idx >> 3, c4 = (idx & 7) * 4;
                 const int gn = n0 + r, gk = k0 + c4;
-                rb[s] = (gn < p.N && gk < p.K) ? ld4_guard(p.B + (size_t)gn * p.ldb + gk, gk, p.K)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[s] = buf_ld4(rs_b, (gn < p.N && gk < p.K) ? ((unsigned)gn * (unsigned)p.ldb + (unsigned)gk) * 4u : kOobG);
             }
         } else {
 #pragma unroll
@@ -91,33 +100,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
                 const int idx = t + 256 * s;
                 const int kr = idx >> 5, n4 = (idx & 31) * 4;
                 const int gk = k0 + kr, gn = n0 + n4;
-                rb[s] = (gk < p.K && gn < p.N) ? ld4_guard(p.B + (size_t)gk * p.ldb + gn, gn, p.N)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[s] = buf_ld4(rs_b, (gk < p.K && gn < p.N) ? ((unsigned)gk * (unsigned)p.ldb + (unsigned)gn) * 4u : kOobG);
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int kt) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
+        const int k0 = kt * BK;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int idx = t + 256 * s;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
-            *reinterpret_cast<float4*>(a + r * LDS_A + c4) = ra[s];
+            *reinterpret_cast<float4*>(a + r * LDS_A + c4) = mask4(ra[s], k0 + c4, p.K);
         }
         if (!B_KN) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int idx = t + 256 * s;
                 const int r = idx >> 3, c4 = (idx & 7) * 4;
-                *reinterpret_cast<float4*>(b + r * LDS_A + c4) = rb[s];
+                *reinterpret_cast<float4*>(b + r * LDS_A + c4) = mask4(rb[s], k0 + c4, p.K);
             }
         } else {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int idx = t + 256 * s;
                 const int kr = idx >> 5, n4 = (idx & 31) * 4;
-                *reinterpret_cast<float4*>(b + kr * LDS_BKN + n4) = rb[s];
+                *reinterpret_cast<float4*>(b + kr * LDS_BKN + n4) = mask4(rb[s], n0 + n4, p.N);
             }
         }
     };
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(0, 0);
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        if (kt + 1 < nk) store_tiles(cur ^ 1, kt + 1);
         __syncthreads();
     }
 
@@ -203,6 +212,12 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.slope = slope; p.act = act;
+    {
+        const size_t ab = ((size_t)(M - 1) * lda + K) * sizeof(float);
+        const size_t bb = (b_kn ? ((size_t)(K - 1) * ldb + N) : ((size_t)(N - 1) * ldb + K)) * sizeof(float);
+        CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);   // 32-bit buffer offsets
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    }
     p.tiles_n = ceil_div(N, BN);
     p.n_wg = ceil_div(M, BM) * p.tiles_n;
     const size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);

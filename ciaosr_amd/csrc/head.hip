@@ -130,6 +130,7 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
     CIAOSR_CHECK_ARG((p.wk0 & 3) == 0 && (p.wv0 & 3) == 0);
     if (csattn) CIAOSR_CHECK_ARG(csattn->channels == p.C && p.Cn == p.C);
     if (workspace_bytes < head_ws_bytes(p)) return CIAOSR_ERR_WORKSPACE;
+    CIAOSR_CHECK_ARG((size_t)p.HW * p.Dv * sizeof(float) < 0xFFFFFF00ull);   // 32-bit buffer offsets into U
 
     Arena ar(workspace, workspace_bytes);
     const size_t R = (size_t)p.qc * p.J;
@@ -168,6 +169,7 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
             FusedKVP kp;
             kp.coord = coord; kp.cell = cell; kp.q0 = q0; kp.nq = nq; kp.chunk = chunk; kp.H = H; kp.W = W;
             kp.U = U; kp.ldu = p.Dv; kp.D = p.D; kp.Dv = p.Dv;
+            kp.u_bytes = (unsigned)((size_t)p.HW * p.Dv * sizeof(float));
             fill_chain(kp.k, w->k, Tk, p.D);
             fill_chain(kp.v, w->v, Tv, p.Dv);
             kp.softmax_scale = w->softmax_scale;

@@ -27,6 +27,22 @@ constexpr int FH = 256;        // hidden width
 constexpr int FLD = FH + 4;    // LDS row stride (floats)
 constexpr int FNJ = FH / 8;    // k-chunks of 8 per 256-wide layer
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobF = 0xFFFFFFF0u;
+
+// Epilogue gathers go through buffer descriptors: a column group past the layer width or a missing query row
+// gets an out-of-range offset and reads zeros; no branch around the load, so all loads of an epilogue are in
+// flight together (per-element conditionals make hipcc wait vmcnt(0) after each one).
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, float4 v) {
+    i32x4 iv;
+    iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(iv, rsrc, (int)byte_off, 0, 0);
+}
+
 // ---- fragment packing ---------------------------------------------------------------------------
 // W [N][ld] (K valid columns) -> P[nt][j][lane][4]: lane (i = lane&31, h = lane>>5) holds
 // W[nt*32 + i][8j + 4h .. 8j + 4h + 3]; rows >= N and columns >= K are zero.
@@ -199,14 +215,16 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     {
         float part[2] = {0.f, 0.f};
         const int n_units = (p.k.n_out + 31) >> 5;
-        const float* krow[2];
-        const float* qrow[2];
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bk =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.k.bias_out), 0, (unsigned)p.k.n_out * 4u, 0x00020000);
+        unsigned koff[2], qoff[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int m = 32 * mi + li;
-            krow[mi] = p.U + (size_t)s_kpix[m] * p.ldu;
+            koff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
             const int qp = s_qpix[m >> 2];
-            qrow[mi] = qp >= 0 ? p.U + (size_t)qp * p.ldu : nullptr;
+            qoff[mi] = qp >= 0 ? (unsigned)qp * (unsigned)p.ldu * 4u : kOobF;     // missing query row reads zeros
         }
         for (int u = w; u < n_units; u += 4) {
             f32x16 acc[2][1];
@@ -214,22 +232,26 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
             mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
                         FNJ, 0, acc);
             // logit += sum_d q[d] * (key[d] * (w_k[d] + b[d]))   (ciaosr_net.py:203,214)
+            float4 bv[4], kv[2][4], qv[2][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 32 * u + 8 * g + 4 * lh;
-                if (d0 < p.k.n_out) {
-                    const float4 b = *reinterpret_cast<const float4*>(p.k.bias_out + d0);
+                const unsigned doff = d0 < p.k.n_out ? (unsigned)d0 * 4u : kOobF;
+                bv[g] = bload4(rs_bk, doff);
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
-                        if (qrow[mi]) {
-                            const float4 kv = *reinterpret_cast<const float4*>(krow[mi] + d0);
-                            const float4 qv = *reinterpret_cast<const float4*>(qrow[mi] + d0);
-                            part[mi] += qv.x * (kv.x * (acc[mi][0][4 * g] + b.x)) + qv.y * (kv.y * (acc[mi][0][4 * g + 1] + b.y)) +
-                                        qv.z * (kv.z * (acc[mi][0][4 * g + 2] + b.z)) + qv.w * (kv.w * (acc[mi][0][4 * g + 3] + b.w));
-                        }
-                    }
+                for (int mi = 0; mi < 2; ++mi) {
+                    kv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : koff[mi] + doff);
+                    qv[mi][g] = bload4(rs_u, (doff == kOobF || qoff[mi] == kOobF) ? kOobF : qoff[mi] + doff);
                 }
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    part[mi] += qv[mi][g].x * (kv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x)) +
+                                qv[mi][g].y * (kv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y)) +
+                                qv[mi][g].z * (kv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z)) +
+                                qv[mi][g].w * (kv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
         }
         // the two half-waves hold different channels of the same rows
 #pragma unroll
@@ -262,15 +284,22 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
     {
         const int n_units = (p.v.n_out + 31) >> 5;
-        const float* vrow[2];
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bv =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v.bias_out), 0, (unsigned)p.v.n_out * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z =
+            __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
+        unsigned voff[2], zoff[2];
         float av[2];
+        const int jsel = li & 3;     // this lane's key sample; also the channel group it stores
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int m = 32 * mi + li;
-            vrow[mi] = p.U + (size_t)s_kpix[m] * p.ldu;
+            voff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
             av[mi] = s_attn[m];
+            const int ql = qbase + (m >> 2);
+            zoff[mi] = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 4u : kOobF;
         }
-        const int jsel = li & 3;     // this lane's key sample; also the channel group it stores
         for (int u = w; u < n_units; u += 4) {
             f32x16 acc[2][1];
             zero_acc<1>(acc);
@@ -278,30 +307,33 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
                         FNJ, 0, acc);
             // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
             // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
+            float4 bv[4], vv[2][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.v.n_out ? (unsigned)d0 * 4u : kOobF;
+                bv[g] = bload4(rs_bv, doff);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) vv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : voff[mi] + doff);
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 float4 zsel = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int d0 = 32 * u + 8 * g + 4 * lh;
-                    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (d0 < p.v.n_out) {
-                        const float4 b = *reinterpret_cast<const float4*>(p.v.bias_out + d0);
-                        const float4 vv = *reinterpret_cast<const float4*>(vrow[mi] + d0);
-                        z.x = av[mi] * (vv.x * (acc[mi][0][4 * g] + b.x));
-                        z.y = av[mi] * (vv.y * (acc[mi][0][4 * g + 1] + b.y));
-                        z.z = av[mi] * (vv.z * (acc[mi][0][4 * g + 2] + b.z));
-                        z.w = av[mi] * (vv.w * (acc[mi][0][4 * g + 3] + b.w));
-                    }
+                    float4 z;
+                    z.x = av[mi] * (vv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x));
+                    z.y = av[mi] * (vv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y));
+                    z.z = av[mi] * (vv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z));
+                    z.w = av[mi] * (vv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
                     z.x += __shfl_xor(z.x, 1, 64); z.y += __shfl_xor(z.y, 1, 64);
                     z.z += __shfl_xor(z.z, 1, 64); z.w += __shfl_xor(z.w, 1, 64);
                     z.x += __shfl_xor(z.x, 2, 64); z.y += __shfl_xor(z.y, 2, 64);
                     z.z += __shfl_xor(z.z, 2, 64); z.w += __shfl_xor(z.w, 2, 64);
                     if (jsel == g) zsel = z;
                 }
-                const int ql = qbase + ((32 * mi + li) >> 2);
                 const int d0 = 32 * u + 8 * jsel + 4 * lh;
-                if (ql < p.nq && d0 < p.v.n_out) *reinterpret_cast<float4*>(p.Z + (size_t)ql * p.ldz + d0) = zsel;
+                bstore4(rs_z, (zoff[mi] == kOobF || d0 >= p.v.n_out) ? kOobF : zoff[mi] + (unsigned)d0 * 4u, zsel);
             }
         }
     }

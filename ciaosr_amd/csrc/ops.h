@@ -84,6 +84,7 @@ struct FusedKVP {
     int nq, chunk, H, W;
     const float* U;
     int ldu, D, Dv;
+    unsigned u_bytes;
     FusedChain k, v;
     float softmax_scale;
     float* Z;

@@ -162,3 +162,28 @@ class LocalImplicitSREDSR(LocalImplicitSRNet):
     def gen_feature_torch(self, x):
         f = self.conv_first(x)
         return self.conv_after_body(self.body(f)) + f
+
+
+class LocalImplicitSRSWINIR(LocalImplicitSRNet):
+    """ciaosr_net.py:411-525: SwinIR trunk (PyTorch-ROCm) + the HIP head.  Leading `window_size` argument."""
+
+    def __init__(self, window_size, encoder, imnet_q, imnet_k, imnet_v, query_mlp=None, key_mlp=None, value_mlp=None,
+                 local_size=2, feat_unfold=True, eval_bsize=None, non_local_attn=True, multi_scale=[2],
+                 softmax_scale=1):
+        super().__init__(encoder=encoder, imnet_q=imnet_q, imnet_k=imnet_k, imnet_v=imnet_v, query_mlp=query_mlp,
+                         key_mlp=key_mlp, value_mlp=value_mlp, local_size=local_size, feat_unfold=feat_unfold,
+                         eval_bsize=eval_bsize, non_local_attn=non_local_attn, multi_scale=multi_scale,
+                         softmax_scale=softmax_scale)
+        self.window_size = window_size
+        self.conv_first = self.encoder.conv_first
+        self.patch_embed = self.encoder.patch_embed
+        self.pos_drop = self.encoder.pos_drop
+        self.layers = self.encoder.layers
+        self.norm = self.encoder.norm
+        self.patch_unembed = self.encoder.patch_unembed
+        self.conv_after_body = self.encoder.conv_after_body
+        del self.encoder
+
+    def gen_feature(self, img):
+        from .encoders.swinir import swinir_features
+        return [swinir_features(self, img)]

@@ -341,3 +341,77 @@ def test_whole_image_path_non_integer_scale_vs_oracle(dev):
     """No tiling (scale > 4 style path, ciaosr.py:158) at x3.3 against the oracle run here."""
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_swinir_e2e_vs_golden(dev):
+    """Config C5: SwinIR-CiaoSR x3.3, whole-image path (non-integer scale), C = 180 head through the fused
+    kernels; trunk through PyTorch-ROCm.  Reference output from tests/golden/swinir_c5.npz."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    from ciaosr_amd.metrics import psnr_tensors
+    from tests.test_host_logic import _swinir_ciaosr
+    fx = load_golden('swinir_c5')
+    model = _swinir_ciaosr(dict(scale=3.3))
+    assert seeded_init_(model, seed=int(fx['weight_seed']), gain=1.0, head_gain=SQRT6) == str(fx['sha'])
+    model = model.to(dev)
+    ht, wt = [int(v) for v in fx['target']]
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    with hip_ops.profile():
+        out = model(lq=_t(fx['lq']).to(dev), gt=None, test_mode=True, coord=coord, cell=cell)['output']
+    assert 'head_kv_fused' in hip_ops.profile.results()
+    ref = _t(fx['out'])
+    err = (out - ref).abs().max().item()
+    assert err < NORTH_STAR_TOL, err
+    _, gt = synthetic_pair(24, 24, 3.3)
+    assert abs(psnr_tensors(out, gt, crop_border=3) - psnr_tensors(ref, gt, crop_border=3)) <= 0.01
+
+
+def test_tools_test_cli_end_to_end(dev, tmp_path, capsys):
+    """tools/test.py CONFIG CHECKPOINT on a folder of synthetic PNGs: Eval-PSNR equals the CPU oracle's
+    pipeline (file decode -> restorer -> tensor2img -> Y-channel PSNR with crop_border) within 0.01 dB."""
+    import sys
+    from ciaosr_amd.imageio import imwrite
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    from ciaosr_amd import metrics
+    from ciaosr_amd.dataset import SRFolderDataset
+    from oracle import ciaosr_oracle as orc
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), '..'))
+    import tools.test as cli
+    (tmp_path / 'lq').mkdir(); (tmp_path / 'gt').mkdir()
+    for i, (h, w) in enumerate([(40, 56), (64, 48)]):
+        lq, gt = synthetic_pair(h, w, 4, seed=100 + i)
+        imwrite(metrics.tensor2img(lq), str(tmp_path / 'lq' / f'img{i}.png'))
+        imwrite(metrics.tensor2img(gt), str(tmp_path / 'gt' / f'img{i}.png'))
+    cfg_path = tmp_path / 'cfg.py'
+    cfg_path.write_text(
+        "from mmedited.models.restorers.ciaosr import CiaoSR\n"
+        "from mmedited.models.backbones.sr_backbones.ciaosr_net import LocalImplicitSREDSR\n"
+        "mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[256, 256, 256, 256])\n"
+        "model = dict(type=CiaoSR, generator=dict(type=LocalImplicitSREDSR, encoder=dict(type='EDSR', in_channels=3,"
+        " out_channels=3, mid_channels=64, num_blocks=4), imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64),"
+        " feat_unfold=True, eval_bsize=30000), rgb_mean=(0.4488, 0.4371, 0.4040), rgb_std=(1., 1., 1.),"
+        " pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'))\n"
+        "test_cfg = dict(metrics=['PSNR', 'SSIM'], crop_border=4, scale=4, tile=32, tile_overlap=8, convert_to='y')\n"
+        f"data = dict(test=dict(type='SRFolderDataset', lq_folder={str(tmp_path / 'lq')!r}, gt_folder={str(tmp_path / 'gt')!r},"
+        " scale=4, filename_tmpl='{}'))\n"
+        "dist_params = dict(backend='nccl')\n")
+    import ciaosr_amd
+    from ciaosr_amd.config import Config
+    cfg = Config.fromfile(str(cfg_path))
+    model = ciaosr_amd.build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    seeded_init_(model, seed=8, gain=1.25, head_gain=2.0)
+    torch.save({'state_dict': model.state_dict()}, tmp_path / 'ck.pth')
+    results = cli.main([str(cfg_path), str(tmp_path / 'ck.pth'), '--save-path', str(tmp_path / 'out')])
+    printed = capsys.readouterr().out
+    assert 'Eval-PSNR' in printed and 'Eval-SSIM' in printed
+    assert os.path.exists(tmp_path / 'out' / 'img0.png') and os.path.exists(tmp_path / 'out' / 'img1.png')
+    P = {k[len('generator.'):]: v.detach().cpu() for k, v in model.state_dict().items()}
+    ds = SRFolderDataset(tmp_path / 'lq', tmp_path / 'gt', scale=4)
+    for i in range(len(ds)):
+        d = ds[i]
+        want = orc.forward_test(d['lq'].unsqueeze(0), None, None, P, scale=4, tile=32, tile_overlap=8, hoist_nonlocal=True)
+        h, w = want.shape[-2:]
+        gt = d['gt'].view(1, h, w, 3).permute(0, 3, 1, 2)
+        ref_psnr = metrics.psnr(metrics.tensor2img(want), metrics.tensor2img(gt), crop_border=4, convert_to='y')
+        assert abs(results[i]['eval_result']['PSNR'] - ref_psnr) <= 0.01, (results[i]['eval_result'], ref_psnr)

@@ -101,3 +101,88 @@ def test_unfold_permutation_is_the_documented_one():
     x = torch.arange(C * 9).view(C, 3, 3)          # reference index c*9 + ki*3 + kj
     dev_order = x.permute(1, 2, 0).reshape(-1)     # (ki,kj,c)
     assert torch.equal(perm, dev_order)
+
+
+def _swinir_ciaosr(test_cfg):
+    from ciaosr_amd import CiaoSR, LocalImplicitSRSWINIR
+    from ciaosr_amd.encoders import SwinIR
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[256] * 4)
+    gen = dict(type=LocalImplicitSRSWINIR, window_size=8,
+               encoder=dict(type=SwinIR, upscale=4, in_chans=3, img_size=48, window_size=8, img_range=1.,
+                            depths=[6] * 6, embed_dim=180, num_heads=[6] * 6, mlp_ratio=2, upsampler='pixelshuffle',
+                            resi_connection='1conv', compress_ratio=3, squeeze_factor=30, conv_scale=0.01,
+                            overlap_ratio=0.5),
+               imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
+    return CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040),
+                  rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
+
+
+def test_swinir_names_and_trunk_match_reference():
+    """SwinIR-CiaoSR: state_dict names/shapes/order equal the reference's; the PyTorch trunk (gen_feature with
+    reflect padding to the window multiple) reproduces the reference's features on CPU."""
+    import numpy as np
+    from ciaosr_amd.init_utils import seeded_init_
+    from tests.helpers import load_golden, randn
+    fx = load_golden('swinir_c5')
+    m = _swinir_ciaosr(dict(scale=3.3))
+    names = json.load(open(os.path.join(GOLDEN, 'state_dict_names_swinir.json')))
+    mine = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert list(mine) == list(names) and mine == names
+    assert seeded_init_(m, seed=int(fx['weight_seed']), gain=1.0, head_gain=6 ** 0.5) == str(fx['sha'])
+    x = randn((1, 3, 20, 27), fx['x_seed']) * 0.3
+    with torch.no_grad():
+        feat = m.generator.gen_feature(x)[0]
+    assert feat.shape == (1, 180, 20, 27)
+    assert (feat[0] - torch.from_numpy(fx['feat'])).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize('kind', ['rdn', 'edsr', 'swinir'])
+def test_configs_build_through_the_shim_import_paths(kind):
+    """configs/001_* import `mmedited.models...` exactly like the reference's configs and build via build_model."""
+    import glob
+    import ciaosr_amd
+    from ciaosr_amd.config import Config
+    path = glob.glob(os.path.join(REPO, 'configs', f'001_localimplicitsr_{kind}_*.py'))[0]
+    cfg = Config.fromfile(path)
+    model = ciaosr_amd.build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    n = sum(p.numel() for p in model.parameters())
+    assert n == {'rdn': 23402566, 'edsr': 2649030, 'swinir': 14667218}[kind]     # SURVEY section 6
+    assert model.test_cfg.tile == 192 and model.test_cfg.tile_overlap == 32 and model.generator.eval_bsize == 30000
+
+
+def test_reference_rdn_config_loads_unmodified():
+    """The reference's own RDN config file executes unmodified against the shim packages (its EDSR and SwinIR
+    config files have an unbalanced parenthesis upstream and cannot be parsed by any loader)."""
+    ref = '/root/reference/configs/001_localimplicitsr_rdn_div2k_g1_c64b16_1000k_unfold_lec_mulwkv_res_nonlocal.py'
+    if not os.path.exists(ref):
+        pytest.skip('reference tree not present (GPU box)')
+    import ciaosr_amd
+    from ciaosr_amd.config import Config
+    cfg = Config.fromfile(ref)
+    model = ciaosr_amd.build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    assert type(model).__name__ == 'CiaoSR' and type(model.generator).__name__ == 'LocalImplicitSRRDN'
+    assert cfg.data.test.filename_tmpl == '{}' and cfg.dist_params.backend == 'nccl'
+
+
+def test_dataset_pipeline_and_checkpoint_roundtrip(tmp_path):
+    """SRFolderDataset (paired folders -> lq/gt/coord/cell) and mmcv-style checkpoint loading."""
+    from ciaosr_amd.checkpoint import load_checkpoint
+    from ciaosr_amd.dataset import SRFolderDataset
+    from ciaosr_amd.imageio import imwrite
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair, state_dict_sha256
+    from ciaosr_amd.metrics import tensor2img
+    (tmp_path / 'lq').mkdir(); (tmp_path / 'gt').mkdir()
+    lq, gt = synthetic_pair(12, 16, 2)
+    imwrite(tensor2img(lq), str(tmp_path / 'lq' / 'a.png'))
+    imwrite(tensor2img(gt), str(tmp_path / 'gt' / 'a.png'))
+    ds = SRFolderDataset(tmp_path / 'lq', tmp_path / 'gt', scale=2)
+    d = ds[0]
+    assert d['lq'].shape == (3, 12, 16) and d['gt'].shape == (24 * 32, 3) and d['coord'].shape == (768, 2)
+    assert (d['lq'] - (lq[0] * 255).round() / 255).abs().max() < 1e-6          # RGB order preserved through PNG
+    assert torch.allclose(d['cell'][0], torch.tensor([2 / 24, 2 / 32]))
+    m = _small_restorer(dict(scale=2))
+    sha = seeded_init_(m, 5)
+    torch.save({'state_dict': m.state_dict(), 'meta': {}}, tmp_path / 'ck.pth')
+    m2 = _small_restorer(dict(scale=2))
+    load_checkpoint(m2, str(tmp_path / 'ck.pth'), strict=True)
+    assert state_dict_sha256(m2) == sha

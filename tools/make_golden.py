@@ -242,9 +242,46 @@ def gen_tiling(ref):
     save('tiling_small', lq=lq, out=out, sha=np.array(sha), **w)
 
 
+def gen_swinir(ref):
+    """SwinIR-CiaoSR (config C5 shape: embed 180, 6x6 blocks, window 8): parameter names, trunk features on an
+    odd-sized input (reflect pad to the window multiple + crop, ciaosr_net.py:509-523) and the end-to-end
+    whole-image path at x3.3 (non-integer scale: no tiling, ciaosr.py:158)."""
+    import torch.nn as nn
+    from mmedited.models.backbones.sr_backbones.swinir_net import SwinIR
+    orig_cuda = nn.Module.cuda
+    nn.Module.cuda = lambda self, device=None: self          # swinir_net.py:684,723,725 hard-code .cuda()
+    try:
+        q, k, v = mlp_cfg((256,) * 4)
+        gen = dict(type=ref.LocalImplicitSRSWINIR, window_size=8,
+                   encoder=dict(type=SwinIR, upscale=4, in_chans=3, img_size=48, window_size=8, img_range=1.,
+                                depths=[6] * 6, embed_dim=180, num_heads=[6] * 6, mlp_ratio=2,
+                                upsampler='pixelshuffle', resi_connection='1conv'),
+                   imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+        model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040),
+                           rgb_std=(1., 1., 1.), test_cfg=ref.ConfigDict(scale=3.3)).eval()
+    finally:
+        nn.Module.cuda = orig_cuda
+    sha = seeded_init_(model, seed=2, gain=1.0, head_gain=SQRT6)
+    names = {k2: list(v2.shape) for k2, v2 in model.state_dict().items()}
+    with open(os.path.join(OUT, 'state_dict_names_swinir.json'), 'w') as f:
+        json.dump(names, f, indent=0)
+    x = randn((1, 3, 20, 27), 91) * 0.3
+    with torch.no_grad():
+        feat = model.generator.gen_feature(x)[0]
+    lq, gt = synthetic_pair(24, 24, 3.3)
+    coord, cell, (ht, wt) = coords_for(24, 24, 3.3)
+    with torch.no_grad():
+        res = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+    out = res['output']
+    print(f'  swinir: feat std {feat.std():.3f}, out range [{out.min():.3f},{out.max():.3f}] std {out.std():.3f} '
+          f'frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f}')
+    save('swinir_c5', feat=feat[0], x_seed=np.array(91), lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(2),
+         target=np.array([ht, wt]))
+
+
 ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
-           head_c180=gen_head_c180, e2e=gen_e2e, tiling=gen_tiling)
+           head_c180=gen_head_c180, e2e=gen_e2e, tiling=gen_tiling, swinir=gen_swinir)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
