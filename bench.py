@@ -51,6 +51,9 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     D, Dv, R = 9 * C, 10 * C, Q * J
     dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
     table = {
+        # fused kernels: phi_k + phi_v layers 2..5 per (query, shift) row; phi_q all layers per query
+        'head_kv_fused': (2.0 * R * (6 * hidden * hidden + hidden * D + hidden * Dv), 'flop'),
+        'head_decode_fused': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop'),
         'mlp_hidden': (6 * 2.0 * R * hidden * hidden, 'flop'),
         'mlp_out_k': (2.0 * R * hidden * D, 'flop'),
         'mlp_out_v': (2.0 * R * hidden * Dv, 'flop'),
@@ -101,6 +104,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3tile', 'c3'],
+                    help='c2 (default, BASELINE configs[1]): LR 48x48; c3tile: one 192x192 LR tile; c3: LR 1356x2040 (117 tiles)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -109,11 +114,19 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
     assert world == args.gpus, f'WORLD_SIZE {world} != --gpus {args.gpus}'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get('CIAOSR_DIST_BACKEND', 'nccl')   # 'gloo': rehearse the N-rank path on one GPU
+    if backend == 'nccl' and world > n_dev:
+        raise SystemExit(f'{world} ranks but only {n_dev} GPUs visible (RCCL needs one GPU per rank)')
+    local_dev = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ciaosr_amd import hip_ops, _lib
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
@@ -121,13 +134,16 @@ def main():
     _lib.load()
 
     scale, lr = 4, 48
+    if args.workload != 'c2':
+        assert world == 1, 'the c3 workloads are single-GPU measurements'
     test_cfg = dict(scale=scale, tile=192, tile_overlap=32) if world == 1 else dict(scale=scale, tile=lr, tile_overlap=0)
     model = rdn_ciaosr(test_cfg)
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
-    lq, _ = synthetic_pair(lr, lr * world, scale)     # identical on every rank (CPU-generated)
+    lr_h, lr_w = {'c2': (lr, lr * world), 'c3tile': (192, 192), 'c3': (1356, 2040)}[args.workload]
+    lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
     lq = lq.to(dev)
-    out_pixels = (lr * scale) * (lr * world * scale)
+    out_pixels = (lr_h * scale) * (lr_w * scale)
 
     def step():
         if world == 1:
@@ -144,6 +160,15 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    if world > 1:
+        # correctness of the sharded path before timing it: rank 0's blended image must be bitwise equal to the
+        # single-process clip_test of the same image on this GPU
+        out = step()
+        if rank == 0:
+            ref = model.restore(lq)[0]
+            assert torch.equal(out, ref), f'tile-sharded output differs from 1-GPU output by {(out - ref).abs().max().item()}'
+
 
     # warm-up; the last warm-up step is fully profiled to find the dominant kernel
     for _ in range(max(args.warmup - 1, 0)):
@@ -170,7 +195,7 @@ def main():
     lib.ciaosr_prof_filter(None)
 
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -178,8 +203,12 @@ def main():
         ms = elapsed / args.steps * 1e3
         roof = None
         if dominant and dominant in prof_dom:
-            Q, HW = (lr * scale) ** 2, lr * lr
+            tile_lr = lr if args.workload == 'c2' else 192
+            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117}[args.workload]
+            Q, HW = (tile_lr * scale) ** 2, tile_lr * tile_lr
             work = kernel_work(dominant, Q, HW)
+            if work:
+                work = (work[0] * n_tiles, work[1])
             avg_ms = prof_dom[dominant]['avg_ms']
             step_ms = prof_dom[dominant]['total_ms'] / args.steps      # all launches of the tag in one step
             if work:
@@ -198,7 +227,7 @@ def main():
                                                 max(sum(v['total_ms'] for v in prof_all.values()), 1e-9), 3))
                 la = prof_all.get('local_attention')
                 if la:                      # north-star side metric: K4 against the HBM roofline
-                    b = kernel_work('local_attention', Q, HW)[0]
+                    b = kernel_work('local_attention', Q, HW)[0] * n_tiles
                     roof['local_attention_hbm_frac'] = round(b / (la['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
         line = {
             'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
@@ -206,16 +235,17 @@ def main():
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init '
-                                   'weights, fp32' + ('' if world == 1 else f'; one {lr}x{lr * world} LR image, '
+            'config': {'workload': {'c2': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init weights, fp32',
+                                    'c3tile': 'C3 unit: RDN-CiaoSR x4, one 192x192 LR tile -> 768x768, random-init weights, fp32',
+                                    'c3': 'C3: RDN-CiaoSR x4, LR 1356x2040 -> 5424x8160, 117 tiles of 192 (overlap 32), random-init weights, fp32'}[args.workload] + ('' if world == 1 else f'; one {lr}x{lr * world} LR image, '
                                    f'{world} tiles sharded one per GPU, RCCL all_gather + rank-0 blend'),
-                       'lr': [lr, lr * world], 'scale': scale, 'queries_per_step': out_pixels,
+                       'lr': [lr_h, lr_w], 'scale': scale, 'queries_per_step': out_pixels,
                        'parallelism': f'tile-shard x{world}'},
             'roofline': roof,
             'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
                 prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'c2':
             line['cpu_baseline'] = cpu_baseline(scale)
         print(json.dumps(line), flush=True)
     if world > 1:

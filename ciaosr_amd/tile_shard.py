@@ -39,8 +39,15 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
         hi, wi = origins[t]
         slab[slot] = tile_fn(hi, wi, tile)
     if world > 1:
-        parts = [torch.empty_like(slab) for _ in range(world)]
-        dist.all_gather(parts, slab, group=group)          # the one exchange step (RCCL over xGMI)
+        if slab.is_cuda and dist.get_backend(group) == 'gloo':
+            # debugging / single-GPU rehearsal of the N-rank path: gloo gathers host copies
+            host = slab.cpu()
+            hparts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(hparts, host, group=group)
+            parts = [h.to(slab.device) for h in hparts]
+        else:
+            parts = [torch.empty_like(slab) for _ in range(world)]
+            dist.all_gather(parts, slab, group=group)      # the one exchange step (RCCL over xGMI)
     else:
         parts = [slab]
     if rank != 0 and not gather_to_all:
