@@ -225,10 +225,29 @@ def main():
                             launches=prof_dom[dominant]['launches'],
                             share_of_step=round(prof_all[dominant]['total_ms'] /
                                                 max(sum(v['total_ms'] for v in prof_all.values()), 1e-9), 3))
-                la = prof_all.get('local_attention')
-                if la:                      # north-star side metric: K4 against the HBM roofline
-                    b = kernel_work('local_attention', Q, HW)[0] * n_tiles
-                    roof['local_attention_hbm_frac'] = round(b / (la['total_ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+                # the other kernels of the step against their own rooflines (one fully profiled step)
+                others = {}
+                for tag, pr in prof_all.items():
+                    wk = kernel_work(tag, Q, HW)
+                    if tag == dominant or not wk or pr['total_ms'] < 0.02:
+                        continue
+                    amt, knd = wk[0] * n_tiles, wk[1]
+                    rate = amt / (pr['total_ms'] * 1e-3)
+                    others[tag] = dict(bound='mfma' if knd == 'flop' else 'hbm', ms_per_step=round(pr['total_ms'], 4),
+                                       frac=round(rate / 1e12 / PEAK_F32_MFMA_TFLOPS if knd == 'flop'
+                                                  else rate / 1e9 / PEAK_HBM_GBS, 4))
+                roof['other_kernels'] = others
+                # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
+                # WRITE_SIZE, tools/pmc_summary.py); offline evidence, null when the summary is absent
+                tag2fn = {'enc_dense_scatter': 'void ciaosr::conv_gemm_kernel<32, 32>', 'head_kv_fused': 'ciaosr::head_kv_fused_kernel',
+                          'head_decode_fused': 'ciaosr::head_decode_fused_kernel'}
+                pmc_path = os.path.join(REPO, 'profiles', 'r1_c2_pmc_hbm_traffic.json')
+                if args.workload == 'c2' and os.path.exists(pmc_path) and dominant in tag2fn:
+                    pmc = json.load(open(pmc_path)).get(tag2fn[dominant])
+                    if pmc:
+                        roof['traffic'] = pmc['hbm_bytes_per_launch']
+                        roof['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1_c2_pmc_hbm_traffic.json'
+                        roof['algorithmic_bytes_per_launch'] = round(HW * 4.0 * (64 + 9 * 64 * 288 / HW + 2 * 288))
         line = {
             'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
