@@ -31,6 +31,7 @@ sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA
 
 
 def rdn_ciaosr(test_cfg):
@@ -54,6 +55,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         # fused kernels: phi_k + phi_v layers 2..5 per (query, shift) row; phi_q all layers per query
         'head_kv_fused': (2.0 * R * (6 * hidden * hidden + hidden * D + hidden * Dv), 'flop'),
         'head_decode_fused': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop'),
+        'head_kv_fused_bf16': (2.0 * R * (6 * hidden * hidden + hidden * D + hidden * Dv), 'flop16'),
+        'head_decode_fused_bf16': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop16'),
         'mlp_hidden': (6 * 2.0 * R * hidden * hidden, 'flop'),
         'mlp_out_k': (2.0 * R * hidden * D, 'flop'),
         'mlp_out_v': (2.0 * R * hidden * Dv, 'flop'),
@@ -104,6 +107,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help='fp32 (default): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs in the fused head only')
     ap.add_argument('--workload', default='c2', choices=['c2', 'c3tile', 'c3'],
                     help='c2 (default, BASELINE configs[1]): LR 48x48; c3tile: one 192x192 LR tile; c3: LR 1356x2040 (117 tiles)')
     args = ap.parse_args()
@@ -132,6 +137,7 @@ def main():
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.tile_shard import clip_test_distributed
     _lib.load()
+    hip_ops.set_precision(args.precision)
 
     scale, lr = 4, 48
     if args.workload != 'c2':
@@ -213,10 +219,11 @@ def main():
             step_ms = prof_dom[dominant]['total_ms'] / args.steps      # all launches of the tag in one step
             if work:
                 amount, kind = work
-                if kind == 'flop':
+                if kind in ('flop', 'flop16'):
+                    peak = PEAK_F32_MFMA_TFLOPS if kind == 'flop' else PEAK_BF16_MFMA_TFLOPS
                     ach = amount / (step_ms * 1e-3) / 1e12
-                    roof = dict(bound='mfma', achieved=round(ach, 3), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None)
+                    roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
+                                frac=round(ach / peak, 4), traffic=None)
                 else:
                     ach = amount / (step_ms * 1e-3) / 1e9
                     roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
@@ -233,9 +240,9 @@ def main():
                         continue
                     amt, knd = wk[0] * n_tiles, wk[1]
                     rate = amt / (pr['total_ms'] * 1e-3)
-                    others[tag] = dict(bound='mfma' if knd == 'flop' else 'hbm', ms_per_step=round(pr['total_ms'], 4),
-                                       frac=round(rate / 1e12 / PEAK_F32_MFMA_TFLOPS if knd == 'flop'
-                                                  else rate / 1e9 / PEAK_HBM_GBS, 4))
+                    pk = {'flop': PEAK_F32_MFMA_TFLOPS * 1e12, 'flop16': PEAK_BF16_MFMA_TFLOPS * 1e12, 'byte': PEAK_HBM_GBS * 1e9}[knd]
+                    others[tag] = dict(bound='hbm' if knd == 'byte' else 'mfma', ms_per_step=round(pr['total_ms'], 4),
+                                       frac=round(rate / pk, 4))
                 roof['other_kernels'] = others
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
                 # WRITE_SIZE, tools/pmc_summary.py); offline evidence, null when the summary is absent
@@ -253,7 +260,8 @@ def main():
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs in the head (fp32 accumulate); encoder + cs_attn f32',
+            'data': 'synthetic',
             'config': {'workload': {'c2': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init weights, fp32',
                                     'c3tile': 'C3 unit: RDN-CiaoSR x4, one 192x192 LR tile -> 768x768, random-init weights, fp32',
                                     'c3': 'C3: RDN-CiaoSR x4, LR 1356x2040 -> 5424x8160, 117 tiles of 192 (overlap 32), random-init weights, fp32'}[args.workload] + ('' if world == 1 else f'; one {lr}x{lr * world} LR image, '

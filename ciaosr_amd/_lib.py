@@ -21,7 +21,8 @@ class CiaoSRHipError(RuntimeError):
 class MlpT(C.Structure):
     _fields_ = [('n_layers', C.c_int), ('in_dim', C.c_int), ('width', C.c_int * MAX_LAYERS),
                 ('weight', C.c_void_p * MAX_LAYERS), ('ld', C.c_int * MAX_LAYERS),
-                ('bias', C.c_void_p * MAX_LAYERS), ('frag', C.c_void_p * MAX_LAYERS)]
+                ('bias', C.c_void_p * MAX_LAYERS), ('frag', C.c_void_p * MAX_LAYERS),
+                ('frag16', C.c_void_p * MAX_LAYERS)]
 
 
 class HeadWeightsT(C.Structure):
@@ -77,6 +78,9 @@ SIGNATURES = {
     'ciaosr_fragment_floats': (_S, [_I, _I]),
     'ciaosr_pack_fragments_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_set_head_mode': (_I, [_I]),
+    'ciaosr_set_precision': (_I, [_I]),
+    'ciaosr_fragment_bf16_bytes': (_S, [_I, _I]),
+    'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
     'ciaosr_head_workspace_bytes': (_S, [_I, _I, C.POINTER(HeadWeightsT), _I]),

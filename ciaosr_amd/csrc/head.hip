@@ -75,24 +75,28 @@ static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA
 }
 
 static int g_head_mode = 0;
+static int g_precision = 0;   // 0 fp32 MFMA, 1 bf16 MFMA inputs
 
 // fused kernels: hidden width 256 everywhere, fragments packed, 4 key samples
-static bool chain_fused_ok(const ciaosr_mlp_t& m, bool is_q) {
+static bool chain_fused_ok(const ciaosr_mlp_t& m, bool is_q, bool bf16) {
     if (m.n_layers < 2) return false;
     for (int i = 0; i + 1 < m.n_layers; ++i)
         if (m.width[i] != 256) return false;
     for (int i = is_q ? 0 : 1; i < m.n_layers - (is_q ? 1 : 0); ++i)
-        if (!m.frag[i]) return false;
+        if (!(bf16 ? m.frag16[i] : (const void*)m.frag[i])) return false;
     return true;
 }
 
-static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table, int fan) {
+static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table, int fan, bool bf16) {
     c.table = table;
     c.tail = m.weight[0] + fan;
     c.ld_tail = m.ld[0];
     c.n_hidden = m.n_layers - 2;
-    for (int i = 0; i < c.n_hidden; ++i) { c.frag_hidden[i] = m.frag[i + 1]; c.bias_hidden[i] = m.bias[i + 1]; }
-    c.frag_out = m.frag[m.n_layers - 1];
+    for (int i = 0; i < c.n_hidden; ++i) {
+        c.frag_hidden[i] = bf16 ? m.frag16[i + 1] : (const void*)m.frag[i + 1];
+        c.bias_hidden[i] = m.bias[i + 1];
+    }
+    c.frag_out = bf16 ? m.frag16[m.n_layers - 1] : (const void*)m.frag[m.n_layers - 1];
     c.bias_out = m.bias[m.n_layers - 1];
     c.n_out = m.width[m.n_layers - 1];
 }
@@ -100,6 +104,12 @@ static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table,
 }  // namespace ciaosr
 
 using namespace ciaosr;
+
+extern "C" int ciaosr_set_precision(int mode) {
+    const int prev = g_precision;
+    g_precision = mode ? 1 : 0;
+    return prev;
+}
 
 extern "C" int ciaosr_set_head_mode(int mode) {
     g_head_mode = mode;
@@ -160,8 +170,10 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
     RUN(gemm_f32(U, p.Dv, w->v.weight[0], w->v.ld[0], false, Tv, p.wv0, w->v.bias[0], p.HW, p.wv0, p.Dv, 1.f,
                  CIAOSR_ACT_NONE, 0.f, s, "head_table"));
 
-    const bool fused = g_head_mode == 0 && w->local_size == 2 && chain_fused_ok(w->k, false) &&
-                       chain_fused_ok(w->v, false) && chain_fused_ok(w->q, true) && (p.Dv & 7) == 0;
+    const bool bf16 = g_precision == 1;
+    const bool fused = g_head_mode == 0 && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
+                       chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
+    if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the bf16 mode exists for the fused kernels only
     for (long q0 = 0; q0 < Q; q0 += p.qc) {
         const int nq = (int)((Q - q0) < p.qc ? (Q - q0) : p.qc);
         const long rows = (long)nq * p.J;
@@ -170,21 +182,25 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
             kp.coord = coord; kp.cell = cell; kp.q0 = q0; kp.nq = nq; kp.chunk = chunk; kp.H = H; kp.W = W;
             kp.U = U; kp.ldu = p.Dv; kp.D = p.D; kp.Dv = p.Dv;
             kp.u_bytes = (unsigned)((size_t)p.HW * p.Dv * sizeof(float));
-            fill_chain(kp.k, w->k, Tk, p.D);
-            fill_chain(kp.v, w->v, Tv, p.Dv);
+            fill_chain(kp.k, w->k, Tk, p.D, bf16);
+            fill_chain(kp.v, w->v, Tv, p.Dv, bf16);
             kp.softmax_scale = w->softmax_scale;
             kp.Z = Z; kp.ldz = p.Dv;
-            RUN(head_kv_fused(kp, s));
+            RUN(bf16 ? head_kv_fused_bf16(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;
             qp.Z = Z; qp.ldz = p.Dv; qp.Dv = p.Dv;
-            qp.frag_in = mq.frag[0]; qp.bias_in = mq.bias[0]; qp.nj_in = (p.Dv + 7) / 8;
+            qp.frag_in = bf16 ? mq.frag16[0] : (const void*)mq.frag[0]; qp.bias_in = mq.bias[0];
+            qp.nj_in = bf16 ? (p.Dv + 15) / 16 : (p.Dv + 7) / 8;
             qp.n_hidden = mq.n_layers - 2;
-            for (int i = 0; i < qp.n_hidden; ++i) { qp.frag_hidden[i] = mq.frag[i + 1]; qp.bias_hidden[i] = mq.bias[i + 1]; }
+            for (int i = 0; i < qp.n_hidden; ++i) {
+                qp.frag_hidden[i] = bf16 ? mq.frag16[i + 1] : (const void*)mq.frag[i + 1];
+                qp.bias_hidden[i] = mq.bias[i + 1];
+            }
             qp.w_last = mq.weight[mq.n_layers - 1]; qp.ld_last = mq.ld[mq.n_layers - 1];
             qp.b_last = mq.bias[mq.n_layers - 1];
             qp.x_lr = x_lr_nchw; qp.coord = coord; qp.q0 = q0; qp.nq = nq; qp.H = H; qp.W = W; qp.rgb = rgb;
-            RUN(head_decode_fused(qp, s));
+            RUN(bf16 ? head_decode_fused_bf16(qp, s) : head_decode_fused(qp, s));
             continue;
         }
         HeadRowsP hp;

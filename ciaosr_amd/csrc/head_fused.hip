@@ -135,7 +135,7 @@ __device__ __forceinline__ void store_relu_tile(float* X, const f32x16 (&acc)[2]
 }
 
 // hidden layer in place: X <- relu(X . W^T + b); wave w owns columns [64w, 64w+64)
-__device__ __forceinline__ void hidden_layer(float* X, const float* __restrict__ frag, const float* __restrict__ bias,
+__device__ __forceinline__ void hidden_layer(float* X, const void* __restrict__ frag, const float* __restrict__ bias,
                                              int w, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[2][2];

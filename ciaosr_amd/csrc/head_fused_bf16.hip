@@ -1,0 +1,436 @@
+// bf16-MFMA variant of the fused head kernels (precision mode 1): MFMA inputs bf16, fp32 accumulate;
+// coordinates, index math, layer-0 tables, logits, softmax, the attention-weighted sum and the decode output
+// stay fp32.  v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, which moves the kernel
+// from the MFMA roofline to the per-CU weight stream out of L2, so the row tile doubles to 128 rows
+// (= 32 queries x 4 key samples) per workgroup: bf16 activations [128][264] are 66 KB, two workgroups still
+// fit a CU, and every weight fragment fetched is used for twice as many rows.
+//
+// Same structure as head_fused.hip: swapped MFMA operands (weights = A operand from L2 in pre-packed fragment
+// order [n_tile][k16][lane][8 bf16], activations = B operand from LDS via ds_read_b128), a lane owns one
+// activation row and 4x4 consecutive output channels, hidden layers in place in LDS.
+#include "index_math.h"
+#include "ops.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HBM_ = 128;          // rows per workgroup
+constexpr int HMI = HBM_ / 32;     // 32-row MFMA tiles per workgroup
+constexpr int HH = 256;            // hidden width
+constexpr int HLD = HH + 8;        // LDS row stride in bf16 (528 B: conflict-free ds_read_b128)
+constexpr int HKS = HH / 16;       // k-steps of 16 per 256-wide layer
+constexpr unsigned kOobH = 0xFFFFFFF0u;
+
+__device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-nearest-even
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+
+__device__ __forceinline__ float4 hload4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+__device__ __forceinline__ void hstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, float4 v) {
+    i32x4 iv;
+    iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(iv, rsrc, (int)byte_off, 0, 0);
+}
+
+// ---- fragment packing: W [N][ld] fp32 (K valid columns) -> P[nt][ks][lane][8 bf16]; lane (i = lane&31,
+// g = lane>>5) holds W[32nt + i][16ks + 8g .. 16ks + 8g + 7]; zero padded.
+__global__ void pack_fragments_bf16_kernel(const float* __restrict__ W, int ld, int N, int K, uint4* __restrict__ P,
+                                           int n_tiles, int nks) {
+    const long total = (long)n_tiles * nks * 64;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long t = idx >> 6;
+        const int ks = (int)(t % nks), nt = (int)(t / nks);
+        const int n = nt * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (n < N && k + e < K) ? W[(size_t)n * ld + k + e] : 0.f;
+        P[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
+// acc[mi][ni] (+)= W_tile . X_tile^T over nks k-steps.  xa: &X[lane row][8g] (bf16), wf: fragment stream (+lane)
+template <int NT>
+__device__ __forceinline__ void mma_pass16(const unsigned short* xa, const uint4* __restrict__ wf, int nks, long tile_stride,
+                                           f32x16 (&acc)[HMI][NT]) {
+    uint4 fb[NT], fbn[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) fb[ni] = wf[ni * tile_stride];
+#pragma unroll 1
+    for (int ks = 0; ks < nks; ++ks) {
+        if (ks + 1 < nks) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fbn[ni] = wf[ni * tile_stride + (long)(ks + 1) * 64];
+        }
+        bf16x8 fa[HMI];
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi)
+            fa[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * ks));
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const bf16x8 w = __builtin_bit_cast(bf16x8, fb[ni]);
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fa[mi], acc[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) fb[ni] = fbn[ni];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc16(f32x16 (&acc)[HMI][NT]) {
+#pragma unroll
+    for (int mi = 0; mi < HMI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+}
+
+// X[m][n] <- bf16(relu(acc + bias[n])) for the wave's 64 columns
+__device__ __forceinline__ void store_relu_tile16(unsigned short* X, const f32x16 (&acc)[HMI][2], const float* __restrict__ bias,
+                                                  int w, int li, int lh) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) {
+                uint2 o;
+                o.x = pack2(fmaxf(acc[mi][ni][4 * g] + b.x, 0.f), fmaxf(acc[mi][ni][4 * g + 1] + b.y, 0.f));
+                o.y = pack2(fmaxf(acc[mi][ni][4 * g + 2] + b.z, 0.f), fmaxf(acc[mi][ni][4 * g + 3] + b.w, 0.f));
+                *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
+            }
+        }
+}
+
+__device__ __forceinline__ void hidden_layer16(unsigned short* X, const void* __restrict__ frag, const float* __restrict__ bias,
+                                               int w, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[HMI][2];
+    zero_acc16<2>(acc);
+    mma_pass16<2>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(frag) + (size_t)(2 * w) * HKS * 64 + lane, HKS,
+                  (long)HKS * 64, acc);
+    __syncthreads();
+    store_relu_tile16(X, acc, bias, w, li, lh);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void build_rows16(unsigned short* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
+    const int n4 = t & 63;
+    float4 tw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
+    for (int r = t >> 6; r < HBM_; r += 4) {
+        const float4 tv = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[r] * HH)[n4];
+        const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
+        uint2 o;
+        o.x = pack2(fmaxf(tv.x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f),
+                    fmaxf(tv.y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f));
+        o.y = pack2(fmaxf(tv.z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f),
+                    fmaxf(tv.w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f));
+        *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);                 // [128][264] bf16
+    float* s_t4 = reinterpret_cast<float*>(smem_raw + (size_t)HBM_ * HLD * 2);        // [128][4]
+    float* s_part = s_t4 + HBM_ * 4;                                                  // [4][128]
+    float* s_attn = s_part + 4 * HBM_;                                                // [128]
+    int* s_kpix = reinterpret_cast<int*>(s_attn + HBM_);                              // [128]
+    int* s_qpix = s_kpix + HBM_;                                                      // [32]
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * (HBM_ / 4);
+
+    if (t < HBM_) {
+        const int ql = qbase + (t >> 2), j = t & 3;
+        int kpix = 0;
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ql < p.nq) {
+            const long q = p.q0 + ql;
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            const long c0 = p.chunk > 0 ? (q / p.chunk) * p.chunk : 0;
+            const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, 2);
+            kpix = s.ky * p.W + s.kx;
+            t4[0] = s.rel_y; t4[1] = s.rel_x;
+            t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
+            t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
+            if (j == 0) {
+                const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+                s_qpix[t >> 2] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+            }
+        } else if (j == 0) {
+            s_qpix[t >> 2] = -1;
+        }
+        s_kpix[t] = kpix;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
+
+    // ================= phi_k =====================================================================
+    build_rows16(X, p.k, s_kpix, s_t4, t);
+    __syncthreads();
+    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    {
+        float part[HMI];
+        unsigned koff[HMI], qoff[HMI];
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) {
+            part[mi] = 0.f;
+            const int m = 32 * mi + li;
+            koff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
+            const int qp = s_qpix[m >> 2];
+            qoff[mi] = qp >= 0 ? (unsigned)qp * (unsigned)p.ldu * 4u : kOobH;
+        }
+        const int n_units = (p.k.n_out + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t rs_bk =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.k.bias_out), 0, (unsigned)p.k.n_out * 4u, 0x00020000);
+        for (int u = w; u < n_units; u += 4) {
+            f32x16 acc[HMI][1];
+            zero_acc16<1>(acc);
+            mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.k.frag_out) + (size_t)u * HKS * 64 + lane, HKS,
+                          0, acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.k.n_out ? (unsigned)d0 * 4u : kOobH;
+                const float4 bv = hload4(rs_bk, doff);
+                float4 kv[HMI], qv[HMI];
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) {
+                    kv[mi] = hload4(rs_u, doff == kOobH ? kOobH : koff[mi] + doff);
+                    qv[mi] = hload4(rs_u, (doff == kOobH || qoff[mi] == kOobH) ? kOobH : qoff[mi] + doff);
+                }
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi)
+                    part[mi] += qv[mi].x * (kv[mi].x * (acc[mi][0][4 * g] + bv.x)) + qv[mi].y * (kv[mi].y * (acc[mi][0][4 * g + 1] + bv.y)) +
+                                qv[mi].z * (kv[mi].z * (acc[mi][0][4 * g + 2] + bv.z)) + qv[mi].w * (kv[mi].w * (acc[mi][0][4 * g + 3] + bv.w));
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) {
+            part[mi] += __shfl_xor(part[mi], 32, 64);
+            if (lh == 0) s_part[w * HBM_ + 32 * mi + li] = part[mi];
+        }
+    }
+    __syncthreads();
+    if (t < HBM_ / 4) {
+        float lg[4], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * t + j;
+            lg[j] = (s_part[row] + s_part[HBM_ + row] + s_part[2 * HBM_ + row] + s_part[3 * HBM_ + row]) / p.softmax_scale;
+            m = fmaxf(m, lg[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lg[j] = expf(lg[j] - m); den += lg[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_attn[4 * t + j] = lg[j] / den;
+    }
+
+    // ================= phi_v =====================================================================
+    build_rows16(X, p.v, s_kpix, s_t4, t);
+    __syncthreads();
+    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer16(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    {
+        const int n_units = (p.v.n_out + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t rs_bv =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v.bias_out), 0, (unsigned)p.v.n_out * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z =
+            __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
+        unsigned voff[HMI], zoff[HMI];
+        float av[HMI];
+        const int jsel = li & 3;
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) {
+            const int m = 32 * mi + li;
+            voff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
+            av[mi] = s_attn[m];
+            const int ql = qbase + (m >> 2);
+            zoff[mi] = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 4u : kOobH;
+        }
+        for (int u = w; u < n_units; u += 4) {
+            f32x16 acc[HMI][1];
+            zero_acc16<1>(acc);
+            mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.v.frag_out) + (size_t)u * HKS * 64 + lane, HKS,
+                          0, acc);
+            float4 zsel[HMI];
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) zsel[mi] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.v.n_out ? (unsigned)d0 * 4u : kOobH;
+                const float4 bv = hload4(rs_bv, doff);
+                float4 vv[HMI];
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) vv[mi] = hload4(rs_u, doff == kOobH ? kOobH : voff[mi] + doff);
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) {
+                    float4 z;
+                    z.x = av[mi] * (vv[mi].x * (acc[mi][0][4 * g] + bv.x));
+                    z.y = av[mi] * (vv[mi].y * (acc[mi][0][4 * g + 1] + bv.y));
+                    z.z = av[mi] * (vv[mi].z * (acc[mi][0][4 * g + 2] + bv.z));
+                    z.w = av[mi] * (vv[mi].w * (acc[mi][0][4 * g + 3] + bv.w));
+                    z.x += __shfl_xor(z.x, 1, 64); z.y += __shfl_xor(z.y, 1, 64);
+                    z.z += __shfl_xor(z.z, 1, 64); z.w += __shfl_xor(z.w, 1, 64);
+                    z.x += __shfl_xor(z.x, 2, 64); z.y += __shfl_xor(z.y, 2, 64);
+                    z.z += __shfl_xor(z.z, 2, 64); z.w += __shfl_xor(z.w, 2, 64);
+                    if (jsel == g) zsel[mi] = z;
+                }
+            }
+            const int d0 = 32 * u + 8 * jsel + 4 * lh;
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi)
+                hstore4(rs_z, (zoff[mi] == kOobH || d0 >= p.v.n_out) ? kOobH : zoff[mi] + (unsigned)d0 * 4u, zsel[mi]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);   // [128][264] bf16
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * HBM_;
+
+    f32x16 acc[HMI][2];
+    zero_acc16<2>(acc);
+    const __amdgpu_buffer_rsrc_t rs_z =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
+    for (int k0 = 0; k0 < p.Dv; k0 += HH) {
+        const int kc = min(HH, p.Dv - k0);          // multiple of 8; the fragment stream is zero-padded to 16
+        if (k0 > 0) __syncthreads();
+        for (int idx = t; idx < HBM_ * (HH / 4); idx += 256) {
+            const int r = idx >> 6, c4 = (idx & 63) * 4;
+            const int ql = qbase + r;
+            const float4 v = hload4(rs_z, (ql < p.nq && c4 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c4)) * 4u : kOobH);
+            uint2 o;
+            o.x = pack2(v.x, v.y);
+            o.y = pack2(v.z, v.w);
+            *reinterpret_cast<uint2*>(X + r * HLD + c4) = o;
+        }
+        __syncthreads();
+        mma_pass16<2>(X + li * HLD + 8 * lh,
+                      reinterpret_cast<const uint4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 4)) * 64 + lane,
+                      (kc + 15) >> 4, (long)p.nj_in * 64, acc);
+    }
+    __syncthreads();
+    store_relu_tile16(X, acc, p.bias_in, w, li, lh);
+    __syncthreads();
+    for (int l = 0; l < p.n_hidden; ++l) hidden_layer16(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
+
+    // last Linear (256 -> 3) in fp32 on the bf16 activations: 2 threads per row, 128 columns each
+    const int row = t >> 1, part = t & 1;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    {
+        const unsigned short* xr = X + row * HLD + 128 * part;
+        const float* w0 = p.w_last + 128 * part;
+        const float* w1 = w0 + p.ld_last;
+        const float* w2 = w1 + p.ld_last;
+#pragma unroll 4
+        for (int n = 0; n < 128; n += 4) {
+            const uint2 xb = *reinterpret_cast<const uint2*>(xr + n);
+            const float x0 = __uint_as_float(xb.x << 16), x1 = __uint_as_float(xb.x & 0xFFFF0000u);
+            const float x2 = __uint_as_float(xb.y << 16), x3 = __uint_as_float(xb.y & 0xFFFF0000u);
+            const float4 u0 = *reinterpret_cast<const float4*>(w0 + n);
+            const float4 u1 = *reinterpret_cast<const float4*>(w1 + n);
+            const float4 u2 = *reinterpret_cast<const float4*>(w2 + n);
+            a0 += x0 * u0.x + x1 * u0.y + x2 * u0.z + x3 * u0.w;
+            a1 += x0 * u1.x + x1 * u1.y + x2 * u1.z + x3 * u1.w;
+            a2 += x0 * u2.x + x1 * u2.y + x2 * u2.z + x3 * u2.w;
+        }
+    }
+    a0 += __shfl_xor(a0, 1, 64);
+    a1 += __shfl_xor(a1, 1, 64);
+    a2 += __shfl_xor(a2, 1, 64);
+    const int ql = qbase + row;
+    if (part == 0 && ql < p.nq) {
+        const long q = p.q0 + ql;
+        float v[3] = {a0 + p.b_last[0], a1 + p.b_last[1], a2 + p.b_last[2]};
+        if (p.x_lr) {
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            float fy = sub_rn(mul_rn(add_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
+            float fx = sub_rn(mul_rn(add_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
+            fy = fminf((float)(p.H - 1), fmaxf(fy, 0.f));
+            fx = fminf((float)(p.W - 1), fmaxf(fx, 0.f));
+            const float y0f = floorf(fy), x0f = floorf(fx);
+            const int y0 = (int)y0f, x0 = (int)x0f;
+            const float wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
+            const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx;
+            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);     // weights of clamped taps are 0
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* img = p.x_lr + (size_t)c * p.H * p.W;
+                v[c] += img[(size_t)y0 * p.W + x0] * (wx0 * wy0) + img[(size_t)y0 * p.W + x1] * (wx1 * wy0) +
+                        img[(size_t)y1 * p.W + x0] * (wx0 * wy1) + img[(size_t)y1 * p.W + x1] * (wx1 * wy1);
+            }
+        }
+        p.rgb[q * 3] = v[0];
+        p.rgb[q * 3 + 1] = v[1];
+        p.rgb[q * 3 + 2] = v[2];
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------
+size_t fragment_bf16_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 64 * 16; }
+
+int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream_t s) {
+    const int n_tiles = (N + 31) / 32, nks = (K + 15) / 16;
+    const long total = (long)n_tiles * nks * 64;
+    int grid = (int)((total + 255) / 256);
+    ProfScope prof("pack_fragments_bf16", s);
+    hipLaunchKernelGGL(pack_fragments_bf16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, W, ld, N, K,
+                       reinterpret_cast<uint4*>(P), n_tiles, nks);
+    return launch_status("pack_fragments_bf16");
+}
+
+constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32) * sizeof(int);
+
+int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { allow_big_lds(head_kv_fused_bf16_kernel, kFused16Lds); attr = true; }
+    ProfScope prof("head_kv_fused_bf16", s);
+    hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
+    return launch_status("head_kv_fused_bf16");
+}
+
+int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
+    const size_t lds = (size_t)HBM_ * HLD * 2;
+    static bool attr = false;
+    if (!attr) { allow_big_lds(head_decode_fused_bf16_kernel, lds); attr = true; }
+    ProfScope prof("head_decode_fused_bf16", s);
+    hipLaunchKernelGGL(head_decode_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_)), dim3(256), lds, s, p);
+    return launch_status("head_decode_fused_bf16");
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+extern "C" size_t ciaosr_fragment_bf16_bytes(int N, int K) { return fragment_bf16_bytes(N, K); }
+
+extern "C" int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream) {
+    CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
+    return pack_fragments_bf16(W, ld, N, K, out, (hipStream_t)stream);
+}

@@ -70,10 +70,10 @@ struct FusedChain {
     const float* table;
     const float* tail;
     int ld_tail;
-    const float* frag_hidden[CIAOSR_MAX_LAYERS];
+    const void* frag_hidden[CIAOSR_MAX_LAYERS];
     const float* bias_hidden[CIAOSR_MAX_LAYERS];
     int n_hidden;
-    const float* frag_out;
+    const void* frag_out;
     const float* bias_out;
     int n_out;
 };
@@ -92,10 +92,10 @@ struct FusedKVP {
 };
 struct FusedQP {
     const float* Z; int ldz, Dv;
-    const float* frag_in;
+    const void* frag_in;
     const float* bias_in;
     int nj_in;
-    const float* frag_hidden[CIAOSR_MAX_LAYERS];
+    const void* frag_hidden[CIAOSR_MAX_LAYERS];
     const float* bias_hidden[CIAOSR_MAX_LAYERS];
     int n_hidden;
     const float* w_last; int ld_last;
@@ -107,6 +107,8 @@ struct FusedQP {
     float* rgb;
 };
 int head_kv_fused(const FusedKVP& p, hipStream_t s);
+int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s);
+int head_decode_fused_bf16(const FusedQP& p, hipStream_t s);
 int head_decode_fused(const FusedQP& p, hipStream_t s);
 
 // bump allocator over the caller-provided workspace (256-byte aligned carve-outs)

@@ -57,6 +57,7 @@ class PackedHead:
             st.ld[i] = w.stride(0)
             st.bias[i] = b.data_ptr()
             st.frag[i] = None
+            st.frag16[i] = None
             if i in frag_layers and w.shape[1] % 8 == 0:
                 # MFMA fragment order for the fused kernels, packed on the device by the library
                 n, k = w.shape
@@ -65,6 +66,11 @@ class PackedHead:
                           hip_ops.stream_ptr())
                 keep.append(frag)
                 st.frag[i] = frag.data_ptr()
+                f16 = torch.empty(_lib.load().ciaosr_fragment_bf16_bytes(n, k), dtype=torch.uint8, device=w.device)
+                _lib.call('ciaosr_pack_fragments_bf16', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(f16),
+                          hip_ops.stream_ptr())
+                keep.append(f16)
+                st.frag16[i] = f16.data_ptr()
         st.in_dim = lin[0].weight.shape[1]
         return st, keep
 

@@ -164,6 +164,14 @@ def set_head_mode(mode):
     _lib.call('ciaosr_set_head_mode', int(mode))
 
 
+def set_precision(mode):
+    """'fp32' (exact-fp32 MFMA, default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate) for the fused head.
+    Returns the previous mode name."""
+    m = {'fp32': 0, 'f32': 0, 0: 0, 'bf16': 1, 1: 1}[mode]
+    prev = _lib.load().ciaosr_set_precision(m)
+    return 'bf16' if prev else 'fp32'
+
+
 class profile:
     """Context manager around the library's per-kernel HIP-event timing."""
 

@@ -128,7 +128,19 @@ class CiaoSR(BasicRestorer):
     @torch.no_grad()
     def restore(self, lq, coord=None, cell=None):
         """forward_test body from normalised LR on device to de-normalised, clamped output
-        [B,3,round(h*s),round(w*s)] on device (ciaosr.py:142-169) -- the timed region of bench.py."""
+        [B,3,round(h*s),round(w*s)] on device (ciaosr.py:142-169) -- the timed region of bench.py.
+        `test_cfg.precision = 'bf16'` (an extension, absent from the reference) runs the fused head with bf16
+        MFMA inputs; the default is the exact-fp32 path."""
+        prec = self.test_cfg.get('precision', None) if self.test_cfg is not None else None
+        if prec is not None:
+            prev = hip_ops.set_precision(prec)
+            try:
+                return self._restore(lq, coord, cell)
+            finally:
+                hip_ops.set_precision(prev)
+        return self._restore(lq, coord, cell)
+
+    def _restore(self, lq, coord=None, cell=None):
         x = self.normalize(lq)
         if self.test_cfg.get('tile', None):
             pred = self.clip_test(x, self.generator)

@@ -111,12 +111,24 @@ typedef struct ciaosr_mlp {
      * packed).  With every hidden width 256, local_size 2 and fragments present the fused kernels run
      * (head_kv_fused / head_decode_fused); otherwise the staged per-layer GEMM path. */
     const float* frag[CIAOSR_MAX_LAYERS];
+    /* optional: the same layers packed as bf16 MFMA fragments by ciaosr_pack_fragments_bf16 (precision mode 1) */
+    const void* frag16[CIAOSR_MAX_LAYERS];
 } ciaosr_mlp_t;
 
 /* MFMA fragment packing of a Linear weight W[N][ld] (K valid columns): out[nt][j][lane][4] with
  * lane (i = lane&31, h = lane>>5) holding W[32nt+i][8j+4h .. 8j+4h+3]; zero padded. */
 size_t ciaosr_fragment_floats(int N, int K);
 int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, float* out, void* stream);
+
+/* bf16 fragment packing: out[nt][ks][lane][8 bf16], lane (i = lane&31, g = lane>>5) holds
+ * W[32nt+i][16ks+8g .. 16ks+8g+7] rounded to nearest-even bf16; zero padded. */
+size_t ciaosr_fragment_bf16_bytes(int N, int K);
+int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream);
+
+/* Arithmetic mode of the head's dense contractions: 0 = exact fp32 MFMA (default, |delta| <= 1e-3 contract),
+ * 1 = bf16 MFMA inputs with fp32 accumulation (coordinates, index math, layer-0 tables, logits, softmax and the
+ * decode output stay fp32); parity for mode 1 is PSNR-based.  Returns the previous mode. */
+int ciaosr_set_precision(int mode);
 
 /* 0 = automatic (fused kernels when eligible), 1 = force the staged per-layer path (tests, rooflines) */
 int ciaosr_set_head_mode(int mode);

@@ -415,3 +415,32 @@ def test_tools_test_cli_end_to_end(dev, tmp_path, capsys):
         gt = d['gt'].view(1, h, w, 3).permute(0, 3, 1, 2)
         ref_psnr = metrics.psnr(metrics.tensor2img(want), metrics.tensor2img(gt), crop_border=4, convert_to='y')
         assert abs(results[i]['eval_result']['PSNR'] - ref_psnr) <= 0.01, (results[i]['eval_result'], ref_psnr)
+
+
+@pytest.mark.parametrize('head_gain', [1.0, 2.0])
+def test_bf16_head_mode_vs_fp32(dev, head_gain):
+    """Precision mode 1 (bf16 MFMA inputs, fp32 accumulate) of the fused head against the exact-fp32 mode on the
+    same inputs.  bf16 carries 8 mantissa bits, so this is a PSNR-class check, not the 1e-3 contract:
+    >= 45 dB PSNR of the bf16 head output against the fp32 output (measured: 99.7 dB at default-init scale, 53.5 dB
+    with gain-2 MLPs whose large logits let a bf16 rounding flip an attention weight now and then: max |d| 6e-2)."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 5, head_gain=head_gain), dev, eval_bsize=30000)
+    feat = randn((1, 64, 24, 31), 13).to(dev)
+    ht, wt = 67, 90
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    x = (randn((1, 3, 24, 31), 14) * 0.3).to(dev)
+    ref = g._predict([feat], coord, cell, 30000, x).cpu()
+    try:
+        assert hip_ops.set_precision('bf16') == 'fp32'
+        with hip_ops.profile():
+            got = g._predict([feat], coord, cell, 30000, x).cpu()
+        assert 'head_kv_fused_bf16' in hip_ops.profile.results()
+    finally:
+        hip_ops.set_precision('fp32')
+    err = (got - ref).abs()
+    scale = ref.abs().max().item()
+    mse = (err ** 2).mean().item()
+    psnr = 10 * math.log10(max(scale, 1e-6) ** 2 / max(mse, 1e-20))
+    print(f'bf16 head: max|d| {err.max().item():.3e} (out scale {scale:.3f}), PSNR vs fp32 {psnr:.1f} dB')
+    assert err.max().item() < 0.15 * max(scale, 1.0) and psnr > 45.0
