@@ -444,3 +444,92 @@ def test_bf16_head_mode_vs_fp32(dev, head_gain):
     psnr = 10 * math.log10(max(scale, 1e-6) ** 2 / max(mse, 1e-20))
     print(f'bf16 head: max|d| {err.max().item():.3e} (out scale {scale:.3f}), PSNR vs fp32 {psnr:.1f} dB')
     assert err.max().item() < 0.15 * max(scale, 1.0) and psnr > 45.0
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases and size-independent properties
+# ------------------------------------------------------------------------------------------------
+def test_arbitrary_query_set_and_cells_vs_oracle(dev):
+    """The head takes ANY coordinate list (not only a regular grid): random coordinates incl. the exact
+    borders +-1, per-query random cells, Q = 1 and a Q that is not a multiple of any tile size."""
+    from oracle import ciaosr_oracle as orc
+    P = seeded_head(64, 17, head_gain=1.5)
+    g = _my_generator(64, (256,) * 4, P, dev, eval_bsize=None)
+    feat = randn((1, 64, 11, 14), 51)
+    gen = torch.Generator().manual_seed(3)
+    for Q in (1, 333):
+        coord = torch.rand(1, Q, 2, generator=gen) * 2 - 1
+        coord[0, 0] = torch.tensor([-1.0, 1.0])
+        cell = (torch.rand(1, Q, 2, generator=gen) * 0.2 + 0.01)
+        want = orc.query_rgb(feat, coord, cell, P)
+        got = g.query_rgb([feat.to(dev)], coord.to(dev), cell.to(dev)).cpu()
+        assert (got - want).abs().max() < 2e-4, (Q, (got - want).abs().max().item())
+
+
+def test_batch_of_two_images(dev):
+    """B = 2: batch items are independent (arch_csnln.py:491, ciaosr_net.py batching)."""
+    from ciaosr_amd.coords import make_coord, make_cell
+    P = seeded_head(64, 18, head_gain=1.5)
+    g = _my_generator(64, (256,) * 4, P, dev, eval_bsize=30000)
+    feat = randn((2, 64, 9, 12), 52).to(dev)
+    coord = make_coord((20, 27)).unsqueeze(0).expand(2, -1, 2).contiguous().to(dev)
+    cell = make_cell((20, 27)).unsqueeze(0).expand(2, -1, 2).contiguous().to(dev)
+    both = g.batched_predict([feat], coord, cell)
+    one = g.batched_predict([feat[1:2]], coord[1:2], cell[1:2])
+    assert torch.equal(both[1], one[0])
+
+
+def test_rerun_is_bitwise_deterministic(dev):
+    """No atomics anywhere: the same call twice gives identical bits (needed for the N-GPU == 1-GPU guarantee)."""
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=32, tile_overlap=8))
+    seeded_init_(model, 31, gain=1.4, head_gain=2.0)
+    model = model.to(dev)
+    lq, _ = synthetic_pair(40, 44, 4)
+    a = model.restore(lq.to(dev))
+    b = model.restore(lq.to(dev))
+    assert torch.equal(a, b)
+
+
+def test_linearity_of_the_decode_residual_at_full_tile_size(dev):
+    """Size-independent property at BASELINE's full tile size (LR 192x192 -> 768x768, Q = 589 824): the output is
+    head(feature) + bilinear(x); changing only x by dx changes the output by exactly bilinear(dx) (fp32 rounding),
+    and all 589 824 queries are finite.  Exercises the 192 tile (workspace sizes, 32-bit offsets, chunking)."""
+    from ciaosr_amd import hip_ops
+    P = seeded_head(64, 19, head_gain=1.0)
+    g = _my_generator(64, (256,) * 4, P, dev, eval_bsize=30000)
+    feat = (randn((1, 64, 192, 192), 53) * 0.5).to(dev)
+    coord, cell = hip_ops.make_coord_cell(768, 768, dev)
+    coord, cell = coord.unsqueeze(0), cell.unsqueeze(0)
+    x0 = torch.zeros(1, 3, 192, 192, device=dev)
+    x1 = (randn((1, 3, 192, 192), 54) * 0.3).to(dev)
+    y0 = g._predict([feat], coord, cell, 30000, x0)
+    y1 = g._predict([feat], coord, cell, 30000, x1)
+    assert torch.isfinite(y0).all() and y0.shape == (1, 589824, 3)
+    bil = torch.nn.functional.grid_sample(x1, coord.flip(-1).unsqueeze(1), mode='bilinear', padding_mode='border',
+                                          align_corners=False)[:, :, 0, :].permute(0, 2, 1)
+    assert ((y1 - y0) - bil).abs().max() < 5e-5          # two fp32 roundings on O(1) values
+    # and the staged path agrees with the fused path on a slice of this tile
+    sl = slice(300000, 300000 + 4096)
+    hip_ops.set_head_mode(1)
+    try:
+        ys = g._predict([feat], coord[:, sl].contiguous(), cell[:, sl].contiguous(), 0, x0)
+    finally:
+        hip_ops.set_head_mode(0)
+    yf = g._predict([feat], coord[:, sl].contiguous(), cell[:, sl].contiguous(), 0, x0)
+    assert (ys - yf).abs().max() < 5e-5 * max(1.0, yf.abs().max().item())
+
+
+def test_tiny_image_whole_path(dev):
+    """Smallest sensible LR image (4x6, odd sizes inside cs_attn after halving) at a big scale (x12)."""
+    from ciaosr_amd.coords import make_coord, make_cell
+    from ciaosr_amd.init_utils import seeded_init_
+    from oracle import ciaosr_oracle as orc
+    model = _restorer('edsr', 12, dev, dict(scale=12), mid=64, blocks=2)
+    seeded_init_(model, 41, gain=1.25, head_gain=2.0)
+    params = {k[len('generator.'):]: v.detach().clone() for k, v in model.state_dict().items()}
+    lq = torch.rand(1, 3, 4, 6, generator=torch.Generator().manual_seed(6))
+    coord, cell = make_coord((48, 72)).unsqueeze(0), make_cell((48, 72)).unsqueeze(0)
+    want = orc.forward_test(lq, coord, cell, params)
+    got = model.to(dev).restore(lq.to(dev), coord.to(dev), cell.to(dev)).cpu()
+    assert (got - want).abs().max() < 2e-4
