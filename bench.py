@@ -185,11 +185,14 @@ def main():
     prof_all = hip_ops.profile.results()
     dominant = max(prof_all, key=lambda k: prof_all[k]['total_ms']) if prof_all else None
 
-    # timed region: only the dominant kernel carries events
+    # timed region.  The dominant kernel carries HIP-event pairs inside it only when it is launched a few times
+    # per step: a pair costs ~4 us on the GPU timeline, and the 128 convolution launches of a 48x48 RDN pass
+    # would inflate a 5 ms step by ~1 ms.  Otherwise its duration is measured in a separate pass right after.
     lib = _lib.load()
+    live = bool(dominant) and prof_all[dominant]['launches'] <= 8
     lib.ciaosr_prof_filter(dominant.encode() if dominant else None)
     lib.ciaosr_prof_reset()
-    lib.ciaosr_prof_enable(1)
+    lib.ciaosr_prof_enable(1 if live else 0)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,6 +200,15 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     lib.ciaosr_prof_enable(0)
+    prof_steps = args.steps
+    if dominant and not live:
+        prof_steps = min(args.steps, 10)
+        lib.ciaosr_prof_reset()
+        lib.ciaosr_prof_enable(1)
+        for _ in range(prof_steps):
+            step()
+        sync()
+        lib.ciaosr_prof_enable(0)
     prof_dom = hip_ops.profile.results()
     lib.ciaosr_prof_filter(None)
 
@@ -216,7 +228,7 @@ def main():
             if work:
                 work = (work[0] * n_tiles, work[1])
             avg_ms = prof_dom[dominant]['avg_ms']
-            step_ms = prof_dom[dominant]['total_ms'] / args.steps      # all launches of the tag in one step
+            step_ms = prof_dom[dominant]['total_ms'] / prof_steps      # all launches of the tag in one step
             if work:
                 amount, kind = work
                 if kind in ('flop', 'flop16'):
@@ -228,7 +240,9 @@ def main():
                     ach = amount / (step_ms * 1e-3) / 1e9
                     roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-                roof.update(kernel=dominant, avg_launch_ms=round(avg_ms, 5),
+                roof.update(kernel=dominant, timing='HIP events inside the timed region' if live else
+                            f'HIP events in a separate pass of {prof_steps} steps (too many launches per step to bracket live)',
+                            avg_launch_ms=round(avg_ms, 5),
                             launches=prof_dom[dominant]['launches'],
                             share_of_step=round(prof_all[dominant]['total_ms'] /
                                                 max(sum(v['total_ms'] for v in prof_all.values()), 1e-9), 3))
