@@ -53,9 +53,11 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
     table = {
         # fused kernels: phi_k + phi_v layers 2..5 per (query, shift) row; phi_q all layers per query
-        'head_kv_fused': (2.0 * R * (6 * hidden * hidden + hidden * D + hidden * Dv), 'flop'),
+        # (imnet_k's output layer is folded exactly into the 9-rows-per-LR-pixel logit table: 'head_logit_table')
+        'head_kv_fused': (2.0 * R * (6 * hidden * hidden + hidden * Dv), 'flop'),
+        'head_logit_table': (2.0 * 9 * HW * D * hidden, 'flop'),
         'head_decode_fused': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop'),
-        'head_kv_fused_bf16': (2.0 * R * (6 * hidden * hidden + hidden * D + hidden * Dv), 'flop16'),
+        'head_kv_fused_bf16': (2.0 * R * (6 * hidden * hidden + hidden * Dv), 'flop16'),
         'head_decode_fused_bf16': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop16'),
         'mlp_hidden': (6 * 2.0 * R * hidden * hidden, 'flop'),
         'mlp_out_k': (2.0 * R * hidden * D, 'flop'),

@@ -13,6 +13,9 @@ struct HeadPlan {
     size_t csa_bytes;
 };
 
+constexpr int kLdG = 260;        // logit-table row: 256 coefficients + the bias term + pad
+constexpr int kQkChunk = 65536;  // rows of (q*key) products materialised at a time
+
 static int n_samples(int local_size) { return local_size == 1 ? 1 : (local_size == 2 ? 4 : 9); }
 
 static HeadPlan head_plan(int H, int W, const ciaosr_head_weights_t* w, int Q) {
@@ -41,6 +44,7 @@ static size_t head_ws_bytes(const HeadPlan& p) {
     n += R * p.D + R * p.Dv;                  // WK, WV
     n += (size_t)p.qc * p.Dv;                 // Z
     n += (size_t)p.qc + R;                    // q_idx, k_idx (ints, same size as float)
+    n += (size_t)p.HW * 9 * kLdG + (size_t)kQkChunk * p.D;   // logit table + one chunk of its GEMM rows
     return n * sizeof(float) + p.csa_bytes + 32 * 256;
 }
 
@@ -76,6 +80,7 @@ static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA
 
 static int g_head_mode = 0;
 static int g_precision = 0;   // 0 fp32 MFMA, 1 bf16 MFMA inputs
+static int g_logit_table = 1; // exact output-layer fold of imnet_k (head_ops.hip qk_rows)
 
 // fused kernels: hidden width 256 everywhere, fragments packed, 4 key samples
 static bool chain_fused_ok(const ciaosr_mlp_t& m, bool is_q, bool bf16) {
@@ -112,6 +117,9 @@ extern "C" int ciaosr_set_precision(int mode) {
 }
 
 extern "C" int ciaosr_set_head_mode(int mode) {
+    // bit 0: force the staged path; bit 1: disable the logit table of the fused path
+    g_logit_table = (mode & 2) ? 0 : 1;
+    mode &= 1;
     g_head_mode = mode;
     return CIAOSR_OK;
 }
@@ -155,6 +163,8 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
     float* Z = ar.take<float>((size_t)p.qc * p.Dv);
     int* q_idx = ar.take<int>(p.qc);
     int* k_idx = ar.take<int>(R);
+    float* G = ar.take<float>((size_t)p.HW * 9 * kLdG);
+    float* QK = ar.take<float>((size_t)kQkChunk * p.D);
     char* csa_ws = ar.take<char>(p.csa_bytes);
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
 
@@ -174,6 +184,20 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
     const bool fused = g_head_mode == 0 && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
                        chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
     if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the bf16 mode exists for the fused kernels only
+    // logit table of imnet_k's output layer (exact fold, head_ops.hip): pays off when queries outnumber LR pixels
+    const bool use_table = fused && g_logit_table && w->k.width[w->k.n_layers - 1] == p.D && w->k.width[w->k.n_layers - 2] == 256 &&
+                           (long)Q * p.J > (long)p.HW * 9 && (size_t)p.HW * 9 * kLdG * sizeof(float) < 0xFFFFFF00ull;
+    if (use_table) {
+        const int last = w->k.n_layers - 1;
+        const long total = (long)p.HW * 9;
+        for (long r0 = 0; r0 < total; r0 += kQkChunk) {
+            const int nr = (int)((total - r0) < kQkChunk ? (total - r0) : kQkChunk);
+            RUN(qk_rows(U, p.Dv, p.D, H, W, r0, nr, w->k.bias[last], QK, G, kLdG, s));
+            // G[r][n] = sum_d QK[r][d] * W5k[d][n]: the Linear weight [D][256] is the [K][N] operand as stored
+            RUN(gemm_f32(QK, p.D, w->k.weight[last], w->k.ld[last], true, G + (size_t)r0 * kLdG, kLdG, nullptr, nr, 256, p.D,
+                         1.f, CIAOSR_ACT_NONE, 0.f, s, "head_logit_table"));
+        }
+    }
     for (long q0 = 0; q0 < Q; q0 += p.qc) {
         const int nq = (int)((Q - q0) < p.qc ? (Q - q0) : p.qc);
         const long rows = (long)nq * p.J;
@@ -186,6 +210,7 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
             fill_chain(kp.v, w->v, Tv, p.Dv, bf16);
             kp.softmax_scale = w->softmax_scale;
             kp.Z = Z; kp.ldz = p.Dv;
+            kp.G = use_table ? G : nullptr; kp.ldg = kLdG; kp.g_bytes = (unsigned)((size_t)p.HW * 9 * kLdG * sizeof(float));
             RUN(bf16 ? head_kv_fused_bf16(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;

@@ -174,15 +174,17 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     float* s_attn = s_part + 4 * FBM;                  // [64]
     int* s_kpix = reinterpret_cast<int*>(s_attn + FBM);  // [64]
     int* s_qpix = s_kpix + FBM;                        // [16]
+    int* s_goff = s_qpix + FBM / 4;                    // [64]  logit-table row of each (query, sample) row
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (FBM / 4);          // local query index of row 0
 
     // ---- index math: one thread per row (ciaosr_net.py:145-193) ---------------------------------
+    int bad = 0;
     if (t < FBM) {
         const int ql = qbase + (t >> 2), j = t & 3;
-        int kpix = 0;
+        int kpix = 0, goff = -1;
         float t4[4] = {0.f, 0.f, 0.f, 0.f};
         if (ql < p.nq) {
             const long q = p.q0 + ql;
@@ -193,24 +195,57 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
             t4[0] = s.rel_y; t4[1] = s.rel_x;
             t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
             t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
-            if (j == 0) {
-                const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
-                s_qpix[t >> 2] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+            const bool qin = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (j == 0) s_qpix[t >> 2] = qin ? iy * p.W + ix : -1;
+            if (qin) {
+                const int oy = s.ky - iy, ox = s.kx - ix;      // key pixel relative to the query pixel
+                if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) goff = (iy * p.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
+                else bad = 1;                                   // exotic cell: not a 3x3 neighbour -> MFMA path
             }
         } else if (j == 0) {
             s_qpix[t >> 2] = -1;
         }
         s_kpix[t] = kpix;
+        s_goff[t] = goff;
 #pragma unroll
         for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
     }
-    __syncthreads();
+    const bool table = p.G != nullptr && !__syncthreads_or(bad);   // (also the barrier after the index phase)
+    if (p.G == nullptr) __syncthreads();
 
     // ================= phi_k =====================================================================
     build_rows(X, p.k, s_kpix, s_t4, t);
     __syncthreads();
     for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
 
+    if (table) {
+        // logit = h4 . G[query pixel, key offset] + c  (exact fold of the output layer, head_ops.hip qk_rows):
+        // 4 threads per row, float4-interleaved over the 256 hidden units
+        const int row = t >> 2, part = t & 3;
+        const int go = s_goff[row];
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+        const unsigned gbase = go >= 0 ? (unsigned)go * (unsigned)p.ldg * 4u : kOobF;
+        float4 gv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = bload4(rs_g, gbase == kOobF ? kOobF : gbase + (unsigned)(16 * i + 4 * part) * 4u);
+        const float cterm = (go >= 0 && part == 0) ? p.G[(size_t)go * p.ldg + 256] : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 x = *reinterpret_cast<const float4*>(X + row * FLD + 16 * i + 4 * part);
+            a += x.x * gv[i].x + x.y * gv[i].y + x.z * gv[i].z + x.w * gv[i].w;
+        }
+        a += cterm;
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        if (part == 0) {
+            s_part[row] = a;
+            s_part[FBM + row] = 0.f;
+            s_part[2 * FBM + row] = 0.f;
+            s_part[3 * FBM + row] = 0.f;
+        }
+    } else
     // output layer fused with the logit dot product: wave w takes 32-column units w, w+4, ...
     {
         float part[2] = {0.f, 0.f};
@@ -430,7 +465,7 @@ int pack_fragments(const float* W, int ld, int N, int K, float* P, hipStream_t s
     return launch_status("pack_fragments");
 }
 
-constexpr size_t kFusedLds = (size_t)(FBM * FLD + FBM * 4 + 4 * FBM + FBM) * sizeof(float) + (FBM + 16) * sizeof(int);
+constexpr size_t kFusedLds = (size_t)(FBM * FLD + FBM * 4 + 4 * FBM + FBM) * sizeof(float) + (FBM + 16 + FBM) * sizeof(int);
 
 int head_kv_fused(const FusedKVP& p, hipStream_t s) {
     static bool attr = false;

@@ -152,14 +152,16 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
     float* s_attn = s_part + 4 * HBM_;                                                // [128]
     int* s_kpix = reinterpret_cast<int*>(s_attn + HBM_);                              // [128]
     int* s_qpix = s_kpix + HBM_;                                                      // [32]
+    int* s_goff = s_qpix + HBM_ / 4;                                                  // [128]
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (HBM_ / 4);
 
+    int bad = 0;
     if (t < HBM_) {
         const int ql = qbase + (t >> 2), j = t & 3;
-        int kpix = 0;
+        int kpix = 0, goff = -1;
         float t4[4] = {0.f, 0.f, 0.f, 0.f};
         if (ql < p.nq) {
             const long q = p.q0 + ql;
@@ -170,18 +172,24 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
             t4[0] = s.rel_y; t4[1] = s.rel_x;
             t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
             t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
-            if (j == 0) {
-                const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
-                s_qpix[t >> 2] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+            const bool qin = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (j == 0) s_qpix[t >> 2] = qin ? iy * p.W + ix : -1;
+            if (qin) {
+                const int oy = s.ky - iy, ox = s.kx - ix;
+                if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) goff = (iy * p.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
+                else bad = 1;
             }
         } else if (j == 0) {
             s_qpix[t >> 2] = -1;
         }
         s_kpix[t] = kpix;
+        s_goff[t] = goff;
 #pragma unroll
         for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
     }
-    __syncthreads();
+    const bool table = p.G != nullptr && !__syncthreads_or(bad);
+    if (p.G == nullptr) __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
 
@@ -189,6 +197,29 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
     build_rows16(X, p.k, s_kpix, s_t4, t);
     __syncthreads();
     for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    if (table) {
+        // logit = h4 . G[query pixel, key offset] + c (fp32 table, bf16 activations): 2 threads per row
+        const int row = t >> 1, part = t & 1;
+        const int go = s_goff[row];
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+        const unsigned gbase = go >= 0 ? (unsigned)go * (unsigned)p.ldg * 4u : kOobH;
+        float a = (go >= 0 && part == 0) ? p.G[(size_t)go * p.ldg + 256] : 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int n = 8 * i + 4 * part;
+            const float4 gv = hload4(rs_g, gbase == kOobH ? kOobH : gbase + (unsigned)n * 4u);
+            const uint2 xb = *reinterpret_cast<const uint2*>(X + row * HLD + n);
+            a += __uint_as_float(xb.x << 16) * gv.x + __uint_as_float(xb.x & 0xFFFF0000u) * gv.y +
+                 __uint_as_float(xb.y << 16) * gv.z + __uint_as_float(xb.y & 0xFFFF0000u) * gv.w;
+        }
+        a += __shfl_xor(a, 1, 64);
+        if (part == 0) {
+            s_part[row] = a;
+            s_part[HBM_ + row] = 0.f;
+            s_part[2 * HBM_ + row] = 0.f;
+            s_part[3 * HBM_ + row] = 0.f;
+        }
+    } else
     {
         float part[HMI];
         unsigned koff[HMI], qoff[HMI];
@@ -405,7 +436,7 @@ int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream
     return launch_status("pack_fragments_bf16");
 }
 
-constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32) * sizeof(int);
+constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32 + HBM_) * sizeof(int);
 
 int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
     static bool attr = false;

@@ -202,6 +202,42 @@ __global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Rows of the logit-table GEMM (exact output-layer fold of imnet_k, SURVEY B.2 "analogous"):
+//   logit = sum_d q[d] key[d] (sum_n W5[d][n] h[n] + b5[d]) = sum_n h[n] G[n] + c,
+//   G = W5^T (q*key), c = b5 . (q*key), and (q*key) depends only on (query pixel, key pixel) with the key
+//   pixel one of the 3x3 neighbours of the query pixel: 9 rows per LR pixel instead of one 576-wide output
+//   layer per (query, sample) row.  Row r = p*9 + (oy+1)*3 + (ox+1): A[r][d] = U[p][d] * U[p+o][d].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ U, int ldu, int D, int H, int W, long row0,
+                                                      int nrows, const float* __restrict__ b5, float* __restrict__ A,
+                                                      float* __restrict__ G, int ldg) {
+    const int lane = threadIdx.x & 63;
+    const long rl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rl >= nrows) return;
+    const long r = row0 + rl;
+    const int pix = (int)(r / 9), o = (int)(r - (long)pix * 9);
+    const int y = pix / W, x = pix - y * W;
+    const int ky = y + o / 3 - 1, kx = x + o % 3 - 1;
+    float4* a = reinterpret_cast<float4*>(A + (size_t)rl * D);
+    float c = 0.f;
+    if (ky < 0 || ky >= H || kx < 0 || kx >= W) {          // this (query pixel, key pixel) pair cannot occur
+        for (int t = lane; t < (D >> 2); t += 64) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+        const float4* q = reinterpret_cast<const float4*>(U + (size_t)pix * ldu);
+        const float4* k = reinterpret_cast<const float4*>(U + ((size_t)ky * W + kx) * ldu);
+        const float4* b = reinterpret_cast<const float4*>(b5);
+        for (int t = lane; t < (D >> 2); t += 64) {
+            const float4 qv = q[t], kv = k[t], bv = b[t];
+            const float4 v = make_float4(qv.x * kv.x, qv.y * kv.y, qv.z * kv.z, qv.w * kv.w);
+            a[t] = v;
+            c += v.x * bv.x + v.y * bv.y + v.z * bv.z + v.w * bv.w;
+        }
+        c = wsum(c);
+    }
+    if (lane == 0) G[(size_t)r * ldg + 256] = c;
+}
+
+// ---------------------------------------------------------------------------------------------
 // make_coord + cell of an Ht x Wt target grid on the device (ciaosr.py:237-243, mmedit make_coord)
 // ---------------------------------------------------------------------------------------------
 __global__ void make_coord_cell_kernel(float* __restrict__ coord, float* __restrict__ cell, int Ht, int Wt) {
@@ -228,6 +264,14 @@ int head_rows(const HeadRowsP& p, hipStream_t s) {
     ProfScope prof("head_rows", s);
     hipLaunchKernelGGL(head_rows_kernel, dim3(ceil_div((long)p.nq * p.J, 4)), dim3(256), 0, s, p);
     return launch_status("head_rows");
+}
+
+int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
+            int ldg, hipStream_t s) {
+    ProfScope prof("head_qk_rows", s);
+    hipLaunchKernelGGL(qk_rows_kernel, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out, A,
+                       G, ldg);
+    return launch_status("qk_rows");
 }
 
 int local_attention(const LocalAttnP& p, hipStream_t s) {

@@ -62,6 +62,8 @@ int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s
 int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
                  int* q_idx, int* k_idx, float* rel, hipStream_t s);
 int head_rows(const HeadRowsP& p, hipStream_t s);
+int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
+            int ldg, hipStream_t s);
 int local_attention(const LocalAttnP& p, hipStream_t s);
 int decode_residual(const DecodeP& p, hipStream_t s);
 
@@ -89,6 +91,10 @@ struct FusedKVP {
     float softmax_scale;
     float* Z;
     int ldz;
+    // optional logit table (head.hip): G[(qpix*9 + (oy+1)*3 + (ox+1))][0..255] = W5k^T (q*key), [256] = b5k.(q*key)
+    const float* G;
+    int ldg;
+    unsigned g_bytes;
 };
 struct FusedQP {
     const float* Z; int ldz, Dv;

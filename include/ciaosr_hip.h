@@ -130,7 +130,8 @@ int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, 
  * decode output stay fp32); parity for mode 1 is PSNR-based.  Returns the previous mode. */
 int ciaosr_set_precision(int mode);
 
-/* 0 = automatic (fused kernels when eligible), 1 = force the staged per-layer path (tests, rooflines) */
+/* bit 0: force the staged per-layer path; bit 1: fused path without the logit table (imnet_k's output layer
+ * runs on the MFMA for every (query, sample) row instead of the exact 9-rows-per-LR-pixel fold); 0 = automatic */
 int ciaosr_set_head_mode(int mode);
 
 typedef struct ciaosr_head_weights {

@@ -237,13 +237,17 @@ def test_fused_and_staged_head_paths_agree(dev):
     try:
         hip_ops.set_head_mode(1)
         staged = g._predict([feat], coord, cell, 30000, x).cpu()
-        hip_ops.set_head_mode(0)
+        hip_ops.set_head_mode(2)                 # fused kernels, imnet_k output layer on the MFMA per row
+        fused_mfma = g._predict([feat], coord, cell, 30000, x).cpu()
+        hip_ops.set_head_mode(0)                 # fused kernels + exact logit table (9 rows per LR pixel)
         with hip_ops.profile():
             fused = g._predict([feat], coord, cell, 30000, x).cpu()
-        assert 'head_kv_fused' in hip_ops.profile.results(), 'fused kernels did not run'
+        prof = hip_ops.profile.results()
+        assert 'head_kv_fused' in prof and 'head_logit_table' in prof, 'fused kernels / logit table did not run'
     finally:
         hip_ops.set_head_mode(0)
-    assert (fused - staged).abs().max() < 5e-5 * max(1.0, staged.abs().max().item())
+    tol = 5e-5 * max(1.0, staged.abs().max().item())
+    assert (fused - staged).abs().max() < tol and (fused_mfma - staged).abs().max() < tol
 
 
 def test_staged_local_attention_kernel(dev):
