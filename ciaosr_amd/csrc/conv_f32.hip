@@ -82,6 +82,82 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, int row, int col, 
     if (p.dst2) p.dst2[(size_t)row * p.ld_dst2 + col] = v;
 }
 
+// ---- tile epilogue: 16 independent buffer accesses per lane (see the header comment).  rrow[r] = global output
+// row (pixel) of accumulator register r or 0xFFFFFFFF; col = this lane's output channel, col0 = the tile's first.
+__device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x16& acc, const unsigned (&rrow)[16], int col, int col0,
+                                                   bool cok, int split) {
+    auto off = [&](int r, int ld, int c) -> int {
+        return rrow[r] == 0xFFFFFFFFu ? (int)kOob : (int)((rrow[r] * (unsigned)ld + (unsigned)c) * 4u);
+    };
+    if (p.splitk > 1) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            p.partial + (size_t)split * p.M * p.Cout, 0, (unsigned)((size_t)p.M * p.Cout * 4), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[r]), rs, off(r, p.Cout, col), 0, 0);
+        return;
+    }
+    if (p.dense_step >= 0) {
+        const int nt = col0 >> 6;                              // wave-uniform: a 32-wide tile lies in one layer
+        const int c = col & 63, l = p.dense_step + nt;
+        const __amdgpu_buffer_rsrc_t rs_acc =
+            __builtin_amdgcn_make_buffer_rsrc(p.acc_buf, 0, (unsigned)((size_t)p.M * p.ld_acc * 4), 0x00020000);
+        if (p.dense_step > 0) {
+            float prev[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                prev[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_acc, off(r, p.ld_acc, 64 * l + c), 0, 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += prev[r];
+        }
+        if (nt == 0) {
+            const __amdgpu_buffer_rsrc_t rs_x =
+                __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, (unsigned)((size_t)p.M * p.ld_dst * 4), 0x00020000);
+            const float b = cok ? p.dense_bias[64 * l + c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(fmaxf(acc[r] + b, 0.f)), rs_x,
+                                                      off(r, p.ld_dst, 64 * (p.dense_step + 1) + c), 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[r]), rs_acc, off(r, p.ld_acc, 64 * l + c), 0, 0);
+        }
+        return;
+    }
+    {
+        const float b = (p.bias && cok) ? p.bias[col] : 0.f;
+        float resv[16];
+        if (p.res) {
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(p.res), 0, (unsigned)(((size_t)(p.M - 1) * p.ld_res + p.Cout) * 4), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                resv[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, off(r, p.ld_res, col), 0, 0));
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) resv[r] = 0.f;
+        }
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
+            p.dst, 0, (unsigned)(((size_t)(p.M - 1) * p.ld_dst + p.Cout) * 4), 0x00020000);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = (acc[r] + b) * p.alpha;
+            if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
+            v += resv[r];
+            acc[r] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs_d, off(r, p.ld_dst, col), 0, 0);
+        }
+        if (p.dst2) {
+            const __amdgpu_buffer_rsrc_t rs_2 = __builtin_amdgcn_make_buffer_rsrc(
+                p.dst2, 0, (unsigned)(((size_t)(p.M - 1) * p.ld_dst2 + p.Cout) * 4), 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[r]), rs_2, off(r, p.ld_dst2, col), 0, 0);
+        }
+    }
+}
+
 template <int TM, int TN>
 struct ConvCfg {
     static constexpr int NT = (TM / 32) * (TN / 32);   // MFMA tiles per workgroup: 1, 2 or 4
@@ -201,7 +277,6 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] += red[(((s - 1) * Cfg::NT + tl) * 16 + r) * 64 + lane];
 
-    // ---- epilogue: 16 independent buffer accesses per lane (see the header comment)
     const int col = n0 + wn * 32 + li;
     const bool cok = col < p.Cout;
     unsigned rrow[16];
@@ -210,76 +285,148 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvP p) {
         const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         rrow[r] = (cok && row < p.M) ? (unsigned)row : 0xFFFFFFFFu;
     }
-    auto off = [&](int r, int ld, int c) -> int {
-        return rrow[r] == 0xFFFFFFFFu ? (int)kOob : (int)((rrow[r] * (unsigned)ld + (unsigned)c) * 4u);
+    conv_tile_epilogue(p, acc, rrow, col, n0 + wn * 32, cok, split);
+}
+
+// ---- 3x3 convolution with a halo-resident A tile ------------------------------------------------------
+// The per-CU global-load path sustains only ~10-15 B/clk on this chip (PMC + timing of the tap-by-tap kernel
+// above: a 48x48 layer takes 12-26 us against an 8.6 us MFMA bound while L2 hits 92 %), and re-reading the
+// pixels once per tap is 9x redundant.  Here a workgroup owns an 8x8 pixel block x 32 output channels: the
+// 10x10-pixel halo of 64 input channels (27 KB) is loaded into LDS ONCE and all nine taps read shifted rows of it;
+// only the weights (8 KB per tap) are streamed.  Bytes per output drop from 141 (32x32 tile) to 48 and the
+// layer becomes MFMA-bound even at 48x48.  8 waves = 2 MFMA tiles (pixels 0-31 / 32-63 of the block) x 4 slices of
+// the 64-deep tap; K-slices are summed through LDS.  Channel groups of 64 (Cin = 64 g) reload the halo per group.
+#ifdef CIAOSR_PROBE
+__device__ unsigned long long g_probe[4096 * 8];
+#define PROBE(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_probe[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROBE(slot) do { } while (0)
+#endif
+
+constexpr int HT = 8, HHALO = HT + 2;                 // 8x8 pixels, 10x10 halo
+constexpr int HA_FLOATS = HHALO * HHALO * CLD;         // 6800
+constexpr int HBK = 3 * 64, HBLD = HBK + 4;            // a stage = one row of the 3x3 kernel (3 taps x 64 channels)
+constexpr int HB_FLOATS = 32 * HBLD;                   // 6272 per stage
+constexpr size_t kHaloLds = (size_t)(HA_FLOATS + 2 * HB_FLOATS) * sizeof(float);   // 77 376 B: two workgroups per CU
+
+__global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvP p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ah = smem;                       // [100][CLD]
+    float* Bs = smem + HA_FLOATS;           // [2][32][HBLD]
+    const int tiles_x = (p.W + HT - 1) / HT;
+    const int tile = blockIdx.x;
+    const int mt = tile / p.tiles_n, n0 = (tile % p.tiles_n) * 32;
+    const int ty0 = (mt / tiles_x) * HT, tx0 = (mt % tiles_x) * HT;
+    const int split = blockIdx.y;
+    const int nst_total = 3 * (p.Cin / 64);  // stages: (channel group, kernel row)
+    const int st0 = split * p.kt_per_split;
+    const int nst = min(nst_total, st0 + p.kt_per_split) - st0;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tl = w & 1, ks = w >> 1;                         // MFMA tile (pixel half) and K-slice (16 channels)
+    const int m = 32 * tl + li;                                // pixel of this lane inside the 8x8 block
+    const int hbase = ((m >> 3) + 1) * HHALO + (m & 7) + 1;    // its halo index for tap (0,0)
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.wgt), 0, p.wgt_bytes, 0x00020000);
+
+    // weight stage: 32 output channels x 3 taps x 64 channels = 1536 float4, three per thread.
+    // k index of (stage st = 3*cg + krow, tap-in-row j, channel c): (3*krow + j)*Cin + 64*cg + c
+    auto load_b = [&](int st, float4 (&rb)[3]) {
+        const int cg = st / 3, krow = st - 3 * cg;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int idx = t + 512 * e;                       // 0..1535
+            const int r = idx / 48, q = idx - 48 * r;          // row (output channel), float4 column 0..47
+            const int j = q >> 4, c4 = (q & 15) * 4;
+            const int n = n0 + r;
+            rb[e] = buf_load4(rs_b, n < p.Cout ? (unsigned)((n * p.ldw + (3 * krow + j) * p.Cin + 64 * cg + c4) * 4) : kOob);
+        }
     };
-    if (p.splitk > 1) {
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            p.partial + (size_t)split * p.M * p.Cout, 0, (unsigned)((size_t)p.M * p.Cout * 4), 0x00020000);
+    auto store_b = [&](int buf, const float4 (&rb)[3]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[r]), rs, off(r, p.Cout, col), 0, 0);
-        return;
-    }
-    if (p.dense_step >= 0) {
-        const int nt = (n0 + wn * 32) >> 6;                    // wave-uniform: a 32-wide tile lies in one layer
-        const int c = col & 63, l = p.dense_step + nt;
-        const __amdgpu_buffer_rsrc_t rs_acc =
-            __builtin_amdgcn_make_buffer_rsrc(p.acc_buf, 0, (unsigned)((size_t)p.M * p.ld_acc * 4), 0x00020000);
-        if (p.dense_step > 0) {
-            float prev[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                prev[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_acc, off(r, p.ld_acc, 64 * l + c), 0, 0));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] += prev[r];
+        for (int e = 0; e < 3; ++e) {
+            const int idx = t + 512 * e;
+            const int r = idx / 48, q = idx - 48 * r;
+            *reinterpret_cast<float4*>(Bs + buf * HB_FLOATS + r * HBLD + 4 * q) = rb[e];
         }
-        if (nt == 0) {
-            const __amdgpu_buffer_rsrc_t rs_x =
-                __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, (unsigned)((size_t)p.M * p.ld_dst * 4), 0x00020000);
-            const float b = cok ? p.dense_bias[64 * l + c] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(fmaxf(acc[r] + b, 0.f)), rs_x,
-                                                      off(r, p.ld_dst, 64 * (p.dense_step + 1) + c), 0, 0);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[r]), rs_acc, off(r, p.ld_acc, 64 * l + c), 0, 0);
+    };
+    auto load_halo = [&](int cg) {
+        for (int idx = t; idx < HHALO * HHALO * 16; idx += 512) {
+            const int hp = idx >> 4, c4 = (idx & 15) * 4;
+            const int y = ty0 - 1 + hp / HHALO, x = tx0 - 1 + hp % HHALO;
+            const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
+            const float4 v = buf_load4(rs_a, ok ? (unsigned)(((y * p.W + x) * p.ld_src + 64 * cg + c4) * 4) : kOob);
+            *reinterpret_cast<float4*>(Ah + hp * CLD + c4) = v;
         }
-        return;
-    }
-    {
-        const float b = (p.bias && cok) ? p.bias[col] : 0.f;
-        float resv[16];
-        if (p.res) {
-            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(p.res), 0, (unsigned)(((size_t)(p.M - 1) * p.ld_res + p.Cout) * 4), 0x00020000);
+    };
+
+    f32x16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                resv[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, off(r, p.ld_res, col), 0, 0));
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) resv[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    int cur_cg = -1;
+    float4 rb[3];
+    PROBE(0);
+    if (nst > 0) load_b(st0, rb);
+    for (int i = 0; i < nst; ++i) {
+        const int st = st0 + i;
+        const int cg = st / 3, krow = st - 3 * cg;
+        if (i == 1) PROBE(3);
+        if (cg != cur_cg) {                  // (block-uniform) new channel group: refill the halo tile
+            __syncthreads();                 // every wave is done with the previous group's halo
+            load_halo(cg);
+            cur_cg = cg;
         }
-        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(
-            p.dst, 0, (unsigned)(((size_t)(p.M - 1) * p.ld_dst + p.Cout) * 4), 0x00020000);
+        if (i == 0) PROBE(1);
+        store_b(i & 1, rb);
+        if (i + 1 < nst) load_b(st + 1, rb);
+        __syncthreads();
+        if (i == 0) PROBE(2);
+        const float* a = Ah + (hbase + (krow - 1) * HHALO - 1) * CLD + 16 * ks + 4 * lh;   // tap (krow-1, -1)
+        const float* b = Bs + (i & 1) * HB_FLOATS + li * HBLD + 16 * ks + 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float v = (acc[r] + b) * p.alpha;
-            if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
-            v += resv[r];
-            acc[r] = v;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs_d, off(r, p.ld_dst, col), 0, 0);
-        }
-        if (p.dst2) {
-            const __amdgpu_buffer_rsrc_t rs_2 = __builtin_amdgcn_make_buffer_rsrc(
-                p.dst2, 0, (unsigned)(((size_t)(p.M - 1) * p.ld_dst2 + p.Cout) * 4), 0x00020000);
+        for (int j = 0; j < 3; ++j) {        // the three taps of this kernel row: dx = -1, 0, +1
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc[r]), rs_2, off(r, p.ld_dst2, col), 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                const float4 fa = *reinterpret_cast<const float4*>(a + j * CLD + 8 * h);
+                const float4 fb = *reinterpret_cast<const float4*>(b + 64 * j + 8 * h);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+            }
         }
     }
+    PROBE(4);
+    __syncthreads();
+
+    // sum the 4 K-slices of each MFMA tile through LDS (halo / weight stages are free now)
+    float* red = smem;   // [3*2][16][64] = 6144 floats <= HA_FLOATS
+    if (ks > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((ks - 1) * 2 + tl) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll
+    for (int s = 1; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(((s - 1) * 2 + tl) * 16 + r) * 64 + lane];
+
+    const int col = n0 + li;
+    const bool cok = col < p.Cout;
+    unsigned rrow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int mm = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * lh;       // pixel of this accumulator register
+        const int y = ty0 + (mm >> 3), x = tx0 + (mm & 7);
+        rrow[r] = (cok && y < p.H && x < p.W) ? (unsigned)(y * p.W + x) : 0xFFFFFFFFu;
+    }
+    PROBE(5);
+    conv_tile_epilogue(p, acc, rrow, col, n0, cok, split);
+    PROBE(6);
 }
 
 __global__ void conv_reduce_kernel(ConvP p) {
@@ -311,6 +458,44 @@ static void launch_tile(const ConvP& p, int tiles, hipStream_t s) {
 static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStream_t s, const char* tag) {
     static const int force_tile = env_int("CIAOSR_CONV_TILE", 0);     // 32 or 64: tuning / experiments
     static const int target_wg = env_int("CIAOSR_CONV_TARGET_WG", 512);
+    static const int use_halo = env_int("CIAOSR_CONV_HALO", 1);
+    const long halo_tiles = (long)ceil_div(p.H, HT) * ceil_div(p.W, HT) * ceil_div(p.Cout, 32);
+    if (use_halo && p.taps == 9 && (p.Cin & 63) == 0 && halo_tiles <= 4096) {
+        // small 3x3 layers: halo-resident A tile, 8x8 pixels x 32 output channels per workgroup (the per-workgroup
+        // fixed costs -- halo fill, K-slice reduction, read-modify-write epilogue: ~55 % of its cycles by the
+        // in-kernel probe -- make the plain 64x64 tap kernel the faster one on big images, where tiles abound)
+        const int nst9 = 3 * (p.Cin / 64);      // stages of one kernel row (3 taps x 64 channels)
+        p.tiles_n = ceil_div(p.Cout, 32);
+        const int tiles = (int)halo_tiles;
+        int splitk = 1;
+        if (partial && tiles < 128) {
+            splitk = ceil_div(256, tiles);
+            if (splitk > nst9) splitk = nst9;
+            if (splitk > 16) splitk = 16;
+            const size_t per = (size_t)p.M * p.Cout;
+            if ((size_t)splitk * per > partial_floats) splitk = (int)(partial_floats / per);
+            if (splitk < 1) splitk = 1;
+        }
+        p.kt_per_split = ceil_div(nst9, splitk);
+        p.splitk = ceil_div(nst9, p.kt_per_split);
+        p.partial = partial;
+        {
+            ProfScope prof(tag, s);
+            static bool attr = false;
+            if (!attr) { allow_big_lds(conv3x3_halo_kernel, kHaloLds); attr = true; }
+            hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, p.splitk), dim3(512), kHaloLds, s, p);
+        }
+        int rc = launch_status("conv3x3_halo");
+        if (rc != CIAOSR_OK) return rc;
+        if (p.splitk > 1) {
+            ProfScope prof("conv_splitk_reduce", s);
+            const long n = (long)p.M * p.Cout;
+            int grid = (int)((n + 255) / 256);
+            hipLaunchKernelGGL(conv_reduce_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, s, p);
+            rc = launch_status("conv_reduce");
+        }
+        return rc;
+    }
     const int nst = (p.K + CBK - 1) / CBK;
     const long out32 = (long)ceil_div(p.M, 32) * ceil_div(p.Cout, 32);
     // small output (a 48x48 layer): 32x32 tiles spread it over every CU; large output: 64x64 tiles halve the
