@@ -211,12 +211,12 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvP p) {
         for (int s = 0; s < Cfg::RA; ++s) {
             const int y = py[s] + dy, x = px[s] + dx;
             const bool ok = kok && pv[s] && y >= 0 && y < p.H && x >= 0 && x < p.W;
-            R.a[s] = buf_load4(rs_a, ok ? (unsigned)(((y * p.W + x) * p.ld_src + cc) * 4) : kOob);
+            R.a[s] = buf_load4(rs_a, ok ? ((unsigned)(y * p.W + x) * (unsigned)p.ld_src + (unsigned)cc) * 4u : kOob);
         }
 #pragma unroll
         for (int s = 0; s < Cfg::RB; ++s) {
             const int n = n0 + r0 + 32 * s;
-            R.b[s] = buf_load4(rs_b, (kok && n < p.Cout) ? (unsigned)((n * p.ldw + k) * 4) : kOob);
+            R.b[s] = buf_load4(rs_b, (kok && n < p.Cout) ? ((unsigned)n * (unsigned)p.ldw + (unsigned)k) * 4u : kOob);
         }
     };
     auto store_stage = [&](int buf, const Regs& R) {
@@ -265,17 +265,19 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(ConvP p) {
     }
 
     // sum the K-slices through LDS (the stage buffers are free now): slice 0 of every tile collects
-    float* red = smem;   // [(KS-1)*NT][16][64]
-    if (ks > 0) {
+    if constexpr (Cfg::KS > 1) {
+        float* red = smem;   // [(KS-1)*NT][16][64]
+        if (ks > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((ks - 1) * Cfg::NT + tl) * 16 + r) * 64 + lane] = acc[r];
+            for (int r = 0; r < 16; ++r) red[(((ks - 1) * Cfg::NT + tl) * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int s = 1; s < Cfg::KS; ++s)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += red[(((s - 1) * Cfg::NT + tl) * 16 + r) * 64 + lane];
     }
-    __syncthreads();
-    if (ks > 0) return;
-#pragma unroll
-    for (int s = 1; s < Cfg::KS; ++s)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += red[(((s - 1) * Cfg::NT + tl) * 16 + r) * 64 + lane];
 
     const int col = n0 + wn * 32 + li;
     const bool cok = col < p.Cout;
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvP p) {
             const int r = idx / 48, q = idx - 48 * r;          // row (output channel), float4 column 0..47
             const int j = q >> 4, c4 = (q & 15) * 4;
             const int n = n0 + r;
-            rb[e] = buf_load4(rs_b, n < p.Cout ? (unsigned)((n * p.ldw + (3 * krow + j) * p.Cin + 64 * cg + c4) * 4) : kOob);
+            rb[e] = buf_load4(rs_b, n < p.Cout ? ((unsigned)n * (unsigned)p.ldw + (unsigned)((3 * krow + j) * p.Cin + 64 * cg + c4)) * 4u : kOob);
         }
     };
     auto store_b = [&](int buf, const float4 (&rb)[3]) {
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(512) void conv3x3_halo_kernel(ConvP p) {
             const int hp = idx >> 4, c4 = (idx & 15) * 4;
             const int y = ty0 - 1 + hp / HHALO, x = tx0 - 1 + hp % HHALO;
             const bool ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
-            const float4 v = buf_load4(rs_a, ok ? (unsigned)(((y * p.W + x) * p.ld_src + 64 * cg + c4) * 4) : kOob);
+            const float4 v = buf_load4(rs_a, ok ? ((unsigned)(y * p.W + x) * (unsigned)p.ld_src + (unsigned)(64 * cg + c4)) * 4u : kOob);
             *reinterpret_cast<float4*>(Ah + hp * CLD + c4) = v;
         }
     };
@@ -500,10 +502,10 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
     const long out32 = (long)ceil_div(p.M, 32) * ceil_div(p.Cout, 32);
     // small output (a 48x48 layer): 32x32 tiles spread it over every CU; large output: 64x64 tiles halve the
     // operand traffic per MAC
-    int tm = (out32 <= 4096) ? 32 : 64;
-    if (force_tile == 32 || force_tile == 64) tm = force_tile;
+    int tm = (out32 <= 4096) ? 32 : 64;        // (128x64, one workgroup per CU, measured 7 % slower than 64x64 at the 192 tile)
+    if (force_tile == 32 || force_tile == 64 || force_tile == 128) tm = force_tile;
     if (p.dense_step >= 0 && (p.Cout & 63)) return CIAOSR_ERR_BAD_ARG;
-    const int tn = tm;
+    const int tn = tm == 128 ? 64 : tm;        // 128x64: 8 MFMA tiles, one per wave, no K-slicing
     p.tiles_n = ceil_div(p.Cout, tn);
     const int tiles = ceil_div(p.M, tm) * p.tiles_n;
     int splitk = 1;
@@ -521,7 +523,8 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
     {
         ProfScope prof(tag, s);
         if (tm == 32) launch_tile<32, 32>(p, tiles, s);
-        else launch_tile<64, 64>(p, tiles, s);
+        else if (tm == 64) launch_tile<64, 64>(p, tiles, s);
+        else launch_tile<128, 64>(p, tiles, s);
     }
     int rc = launch_status("conv_gemm");
     if (rc != CIAOSR_OK) return rc;
