@@ -50,6 +50,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     (amount, 'flop'|'byte').  FLOPs = 2 x MACs of the contraction as the reference writes it, minus the
     exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query."""
     D, Dv, R = 9 * C, 10 * C, Q * J
+    side = HW ** 0.5
     dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
     table = {
         # fused kernels: phi_k + phi_v layers 2..5 per (query, shift) row; phi_q all layers per query
@@ -66,7 +67,11 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'mlp_hidden_q': (3 * 2.0 * Q * hidden * hidden, 'flop'),
         'head_table': (2.0 * HW * hidden * (D + Dv), 'flop'),
         'csa_scores': (2.0 * HW * (HW / 4) * 4.5 * C, 'flop'),
-        'csa_attn_v': (2.0 * HW * (HW / 4) * 36 * C, 'flop'),
+        # >= 64x64 maps run the composed fold+down tail (DESIGN 'cs_attn tail'): 16C value columns instead of 36C
+        'csa_attn_v': (2.0 * HW * (HW / 4) * (16 if HW >= 4096 else 36) * C, 'flop'),
+        'csa_attn_v_edge': (2.0 * (2 * side * 4 * C + C) * (HW / 4), 'flop'),
+        'csa_down_partial': (2.0 * (side / 2 + 3) ** 2 * 9 * C * 9 * C, 'flop'),
+        'csa_down': (2.0 * HW * 9 * C * C, 'flop'),
         'enc_conv3x3': (2 * 2.0 * HW * 9 * C * C, 'flop'),            # sfe2 + gff.1 (dense layers run in scatter form)
         'enc_dense_scatter': (dense, 'flop'),
         'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),

@@ -35,7 +35,7 @@ class CsAttnWeightsT(C.Structure):
                 ('w_match1', C.c_void_p), ('b_match1', C.c_void_p), ('slope_match1', C.c_float),
                 ('w_match2', C.c_void_p), ('b_match2', C.c_void_p), ('slope_match2', C.c_float),
                 ('w_assembly', C.c_void_p), ('b_assembly', C.c_void_p), ('slope_assembly', C.c_float),
-                ('w_down', C.c_void_p), ('b_down', C.c_void_p),
+                ('w_down', C.c_void_p), ('b_down', C.c_void_p), ('w_down_masked', C.c_void_p),
                 ('escape_nan', C.c_float), ('softmax_scale', C.c_float)]
 
 

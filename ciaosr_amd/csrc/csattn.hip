@@ -14,6 +14,8 @@
 //
 // The score matrix is materialised in HBM (1.36 GB at the 192x192 tile: < 1 % of 288 GB and two
 // passes at HBM speed, against 1.76 TFLOP of MFMA work).
+#include <cstdlib>
+
 #include "ops.h"
 
 namespace ciaosr {
@@ -21,6 +23,7 @@ namespace ciaosr {
 struct CsaPlan {
     int H, W, C, Hp, Wp, L, Lld, Ch;
     size_t n_xp, n_E, n_M, n_x2, n_R, n_Qp, n_Kn, n_V, n_S, n_O, n_Y, n_Yp;
+    size_t n_PE, n_Vp, n_Ov;   // composed fold+down form
 };
 
 static CsaPlan csa_plan(int H, int W, int C) {
@@ -42,6 +45,9 @@ static CsaPlan csa_plan(int H, int W, int C) {
     p.n_O = HW * 36 * C;
     p.n_Y = 4 * HW * C;
     p.n_Yp = (size_t)H * W * 9 * C;
+    p.n_PE = (size_t)(p.Hp / 2 + 3) * (p.Wp / 2 + 3) * 9 * C;
+    p.n_Vp = (size_t)p.L * 25 * C;
+    p.n_Ov = (size_t)(p.Hp + p.Wp) * 4 * C + C;
     return p;
 }
 
@@ -51,8 +57,9 @@ using namespace ciaosr;
 
 extern "C" size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C) {
     const CsaPlan p = csa_plan(H, W, C);
-    const size_t n = p.n_xp + p.n_E + p.n_M + p.n_x2 + p.n_R + p.n_Qp + p.n_Kn + p.n_V + p.n_S + p.n_O + p.n_Y + p.n_Yp;
-    return n * sizeof(float) + 16 * 256;
+    const size_t n = p.n_xp + p.n_E + p.n_M + p.n_x2 + p.n_R + p.n_Qp + p.n_Kn + p.n_V + p.n_S + p.n_O + p.n_Y + p.n_Yp +
+                     2 * p.n_PE + p.n_Vp + p.n_Ov;
+    return n * sizeof(float) + 24 * 256;
 }
 
 extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
@@ -75,6 +82,10 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
     float* O = ar.take<float>(p.n_O);
     float* Y = ar.take<float>(p.n_Y);
     float* Yp = ar.take<float>(p.n_Yp);
+    float* PE = ar.take<float>(p.n_PE);
+    float* Pc = ar.take<float>(p.n_PE);
+    float* Vp = ar.take<float>(p.n_Vp);
+    float* Ov = ar.take<float>(p.n_Ov);
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
 
     const int HWp = p.Hp * p.Wp;
@@ -91,10 +102,33 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
     RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
     RUN(patch_rows(R, p.Ch, p.Hp / 2, p.Wp / 2, p.Ch, 3, 1, 1, p.Hp / 2, p.Wp / 2, Kn, 9 * p.Ch, 1, w->escape_nan, s,
                    "csa_patch_k"));
-    RUN(patch_rows(E, C, p.Hp, p.Wp, C, 6, 2, 2, p.Hp / 2, p.Wp / 2, V, 36 * C, 0, 0.f, s, "csa_patch_v"));
     RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
                  CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
     RUN(softmax_rows(S, HWp, p.L, p.Lld, s));
+    static const int b3_min = [] { const char* e = getenv("CIAOSR_CSA_COMPOSED_MIN"); return e ? atoi(e) : 4096; }();
+    if (w->w_down_masked && HWp >= b3_min) {
+        // composed fold + down (patch_ops.hip): attn.V with N = 16C instead of 36C, no 2x map, no separate down conv
+        const int Hh = p.Hp / 2, Wh = p.Wp / 2;
+        float* Otop = Ov;
+        float* Oleft = Ov + (size_t)p.Wp * 4 * C;
+        float* Otl = Oleft + (size_t)p.Hp * 4 * C;
+        RUN(patch_rows(E, C, p.Hp, p.Wp, C, 3, 2, 3, Hh + 3, Wh + 3, PE, 9 * C, 0, 0.f, s, "csa_patch_down"));
+        RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
+                     CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));
+        RUN(csa_gather_vprime(Pc, Hh, Wh, C, Vp, s));
+        RUN(gemm_f32(S, p.Lld, Vp, 25 * C, true, O, 16 * C, nullptr, HWp, 16 * C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, s,
+                     "csa_attn_v"));
+        // the three edge variants are skinny (M = Wp, Hp, 1 rows; K = L): split-K over the (now free) 2x-map buffer
+        RUN(gemm_f32_splitk(S, p.Lld, Vp + 16 * C, 25 * C, true, Otop, 4 * C, nullptr, p.Wp, 4 * C, p.L, 1.f, CIAOSR_ACT_NONE,
+                            0.f, Y, p.n_Y, s, "csa_attn_v_edge"));
+        RUN(gemm_f32_splitk(S, p.Wp * p.Lld, Vp + 20 * C, 25 * C, true, Oleft, 4 * C, nullptr, p.Hp, 4 * C, p.L, 1.f,
+                            CIAOSR_ACT_NONE, 0.f, Y, p.n_Y, s, "csa_attn_v_edge"));
+        RUN(gemm_f32_splitk(S, p.Lld, Vp + 24 * C, 25 * C, true, Otl, C, nullptr, 1, C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, Y,
+                            p.n_Y, s, "csa_attn_v_edge"));
+        RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, s));
+        return CIAOSR_OK;
+    }
+    RUN(patch_rows(E, C, p.Hp, p.Wp, C, 6, 2, 2, p.Hp / 2, p.Wp / 2, V, 36 * C, 0, 0.f, s, "csa_patch_v"));
     RUN(gemm_f32(S, p.Lld, V, 36 * C, true, O, 36 * C, nullptr, HWp, 36 * C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, s,
                  "csa_attn_v"));
     RUN(fold(O, 36 * C, p.Hp, p.Wp, C, Y, s));

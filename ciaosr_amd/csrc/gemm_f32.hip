@@ -32,6 +32,8 @@ struct GemmP {
     int act;
     int tiles_n, n_wg;
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents (< 4 GiB)
+    int splitk, kt_per_split;    // skinny problems: the K loop is split over blockIdx.y into partial slabs
+    float* partial;              // [splitk][M][N]
 };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -73,7 +75,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     const int li = lane & 31, lh = lane >> 5;
 
     float4 ra[4], rb[4];
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int kt0 = blockIdx.y * p.kt_per_split;
+    const int kt1 = min(nk_total, kt0 + p.kt_per_split);
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
 
@@ -139,13 +143,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(0);
-    store_tiles(0, 0);
+    load_tiles(kt0);
+    store_tiles(0, kt0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tiles(kt + 1);
         const float* a = As + cur * A_TILE + (wm * 64 + li) * LDS_A + 4 * lh;
         const float* b = B_KN ? (Bs + cur * B_TILE + (4 * lh) * LDS_BKN + wn * 64 + li)
                               : (Bs + cur * B_TILE + (wn * 64 + li) * LDS_A + 4 * lh);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (kt + 1 < nk) store_tiles(cur ^ 1, kt + 1);
+        if (kt + 1 < kt1) store_tiles(cur ^ 1, kt + 1);
         __syncthreads();
     }
 
@@ -192,6 +196,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row >= p.M) continue;
+                if (p.splitk > 1) {
+                    p.partial[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[mi][ni][r];
+                    continue;
+                }
                 float v = (acc[mi][ni][r] + bv) * p.alpha;
                 if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
@@ -200,6 +208,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
         }
     }
 }
+
+__global__ void gemm_reduce_kernel(GemmP p) {
+    const long n = (long)p.M * p.N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < p.splitk; ++s) v += p.partial[(size_t)s * n + i];      // fixed order: deterministic
+        const int row = (int)(i / p.N), col = (int)(i - (long)row * p.N);
+        v = (v + (p.bias ? p.bias[col] : 0.f)) * p.alpha;
+        if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
+        p.C[(size_t)row * p.ldc + col] = v;
+    }
+}
+
+static int gemm_launch(GemmP& p, bool b_kn, hipStream_t stream, const char* tag);
+
+// skinny GEMM (few output tiles, long K): split the K loop over `partial` ([splits][M][N] floats available)
+int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc, const float* bias,
+                    int M, int N, int K, float alpha, int act, float slope, float* partial, size_t partial_floats,
+                    hipStream_t stream, const char* tag);
 
 int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc,
              const float* bias, int M, int N, int K, float alpha, int act, float slope,
@@ -220,19 +248,61 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
     }
     p.tiles_n = ceil_div(N, BN);
     p.n_wg = ceil_div(M, BM) * p.tiles_n;
+    p.splitk = 1;
+    p.kt_per_split = (K + BK - 1) / BK;
+    p.partial = nullptr;
+    return gemm_launch(p, b_kn, stream, tag);
+}
+
+static int gemm_launch(GemmP& p, bool b_kn, hipStream_t stream, const char* tag) {
     const size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);
-    ProfScope prof(tag ? tag : (b_kn ? "gemm_f32_nn" : "gemm_f32_nt"), stream);
     static bool attr_done = false;
     if (!attr_done) {
         allow_big_lds(gemm_f32_kernel<true>, smem);
         allow_big_lds(gemm_f32_kernel<false>, smem);
         attr_done = true;
     }
-    if (b_kn)
-        hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(p.n_wg), dim3(256), smem, stream, p);
-    else
-        hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(p.n_wg), dim3(256), smem, stream, p);
-    return launch_status("gemm_f32");
+    {
+        ProfScope prof(tag ? tag : (b_kn ? "gemm_f32_nn" : "gemm_f32_nt"), stream);
+        if (b_kn)
+            hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(p.n_wg, p.splitk), dim3(256), smem, stream, p);
+        else
+            hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(p.n_wg, p.splitk), dim3(256), smem, stream, p);
+    }
+    int rc = launch_status("gemm_f32");
+    if (rc != CIAOSR_OK || p.splitk == 1) return rc;
+    ProfScope prof("gemm_splitk_reduce", stream);
+    const long n = (long)p.M * p.N;
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, p);
+    return launch_status("gemm_reduce");
+}
+
+int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc, const float* bias,
+                    int M, int N, int K, float alpha, int act, float slope, float* partial, size_t partial_floats,
+                    hipStream_t stream, const char* tag) {
+    if (M <= 0 || N <= 0) return CIAOSR_OK;
+    CIAOSR_CHECK_ARG(K > 0 && A && B && C && partial);
+    CIAOSR_CHECK_ARG((lda & 3) == 0 && (ldb & 3) == 0 && aligned16(A) && aligned16(B));
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.slope = slope; p.act = act;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * sizeof(float);
+    const size_t bb = (b_kn ? ((size_t)(K - 1) * ldb + N) : ((size_t)(N - 1) * ldb + K)) * sizeof(float);
+    CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    p.tiles_n = ceil_div(N, BN);
+    p.n_wg = ceil_div(M, BM) * p.tiles_n;
+    const int nk = (K + BK - 1) / BK;
+    int splits = ceil_div(512, p.n_wg);
+    if (splits > nk / 4) splits = nk / 4 > 0 ? nk / 4 : 1;
+    if ((size_t)splits * M * N > partial_floats) splits = (int)(partial_floats / ((size_t)M * N));
+    if (splits < 1) splits = 1;
+    p.kt_per_split = ceil_div(nk, splits);
+    p.splitk = ceil_div(nk, p.kt_per_split);
+    p.partial = partial;
+    return gemm_launch(p, b_kn, stream, tag);
 }
 
 }  // namespace ciaosr

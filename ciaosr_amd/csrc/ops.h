@@ -49,6 +49,9 @@ struct DecodeP {
 // gemm_f32.hip
 int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc, const float* bias,
              int M, int N, int K, float alpha, int act, float slope, hipStream_t stream, const char* tag);
+int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc, const float* bias,
+                    int M, int N, int K, float alpha, int act, float slope, float* partial, size_t partial_floats,
+                    hipStream_t stream, const char* tag);
 // patch_ops.hip
 int nchw_to_hwc(const float* src, float* dst, int C, int H, int W, int ld, hipStream_t s);
 int hwc_to_nchw(const float* src, int ld, float* dst, int C, int H, int W, hipStream_t s);
@@ -58,6 +61,9 @@ int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int 
                float* out, int ld_out, int normalize, float floor_, hipStream_t s, const char* tag);
 int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s);
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s);
+int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStream_t s);
+int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const float* Otl, const float* bd, int H, int W,
+                   int Hp, int Wp, int C, float* out, int ld_out, hipStream_t s);
 // head_ops.hip
 int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
                  int* q_idx, int* k_idx, float* rel, hipStream_t s);

@@ -211,6 +211,71 @@ __global__ void fold_kernel(const float* __restrict__ O, int ldo, int Hp, int Wp
 }
 
 // ---------------------------------------------------------------------------------------------
+// Composed fold + down-convolution of CrossScaleAttention (exact).
+// conv_transpose2d(stride 2, pad 2) followed by the 3x3 stride-2 `down` conv means output pixel (y',x') only
+// receives from the 6x6 patches of LR pixels (y'+dy, x'+dx), dy,dx in {-2..1}, and the patch taps involved
+// collapse, through `down`'s weights, to C numbers per (l, offset):
+//   V'[l][(dy,dx)][co] = Pc_{R(dy),S(dx)}[(ly-dy, lx-dx)][co],
+//   Pc_{R,S}[l'][co]   = sum_ci sum_{a in R, b in S} Wd[co,ci,a,b] * E0[ci, 2ly'-1+a, 2lx'-1+b]   (E0 = E, zero outside)
+//   R(-2) = {0}, R(-1) = R(0) = {0,1,2}, R(1) = {1,2}
+// so attn.V shrinks from N = 36C to N = 16C columns.  Output row 0 / column 0 must not see the cropped row -1 of
+// the 2x map: there the dy = 0 (dx = 0) blocks use the {1,2} subset instead ("top", "left", "corner" variants).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int b3_subset(int d) { return d == -2 ? 0 : (d == 1 ? 2 : 1); }   // {0} / {0,1,2} / {1,2}
+
+// V'[l][blk*C + co]: blk 0..15 main (dy+2)*4+(dx+2); 16..19 top variants (0,dx); 20..23 left variants (dy,0); 24 corner
+__global__ void csa_gather_vprime_kernel(const float* __restrict__ Pc, int Hh, int Wh, int C, float* __restrict__ Vp) {
+    const int c4n = C >> 2;
+    const long n = (long)Hh * Wh * 25 * c4n;
+    const int We = Wh + 3;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long t = idx / c4n;
+        const int blk = (int)(t % 25);
+        const int l = (int)(t / 25);
+        const int ly = l / Wh, lx = l - ly * Wh;
+        int dy, dx, r, sct;
+        if (blk < 16) { dy = blk / 4 - 2; dx = blk % 4 - 2; r = b3_subset(dy); sct = b3_subset(dx); }
+        else if (blk < 20) { dy = 0; dx = blk - 16 - 2; r = 2; sct = b3_subset(dx); }
+        else if (blk < 24) { dy = blk - 20 - 2; dx = 0; r = b3_subset(dy); sct = 2; }
+        else { dy = 0; dx = 0; r = 2; sct = 2; }
+        const size_t src = ((size_t)(ly - dy + 1) * We + (lx - dx + 1)) * (9 * C) + (size_t)(3 * r + sct) * C + 4 * c4;
+        reinterpret_cast<float4*>(Vp)[idx] = *reinterpret_cast<const float4*>(Pc + src);
+    }
+}
+
+// out[(y',x')][co] = (bd[co] + sum over the 16 offsets of O'[(y'+dy, x'+dx)][blk*C + co] (variants on row/column 0)) / 6
+__global__ void csa_gather_out_kernel(const float* __restrict__ Op, const float* __restrict__ Otop, const float* __restrict__ Oleft,
+                                      const float* __restrict__ Otl, const float* __restrict__ bd, int H, int W, int Hp, int Wp,
+                                      int C, float* __restrict__ out, int ld_out) {
+    const int c4n = C >> 2;
+    const long n = (long)H * W * c4n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        const int x = (int)(pix % W), y = (int)(pix / W);
+        float4 acc = *reinterpret_cast<const float4*>(bd + 4 * c4);
+        for (int dy = -2; dy <= 1; ++dy) {
+            const int py = y + dy;
+            if (py < 0 || py >= Hp) continue;
+            for (int dx = -2; dx <= 1; ++dx) {
+                const int px = x + dx;
+                if (px < 0 || px >= Wp) continue;
+                const float* src;
+                if (dy == 0 && y == 0 && dx == 0 && x == 0) src = Otl + 4 * c4;
+                else if (dy == 0 && y == 0) src = Otop + ((size_t)px * 4 + (dx + 2)) * C + 4 * c4;          // py == 0
+                else if (dx == 0 && x == 0) src = Oleft + ((size_t)py * 4 + (dy + 2)) * C + 4 * c4;         // px == 0
+                else src = Op + ((size_t)py * Wp + px) * (16 * C) + (size_t)((dy + 2) * 4 + (dx + 2)) * C + 4 * c4;
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        acc.x /= 6.f; acc.y /= 6.f; acc.z /= 6.f; acc.w /= 6.f;
+        *reinterpret_cast<float4*>(out + (size_t)pix * ld_out + 4 * c4) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // restorer plumbing
 // ---------------------------------------------------------------------------------------------
 struct Vec3 { float v[3]; };
@@ -303,6 +368,20 @@ int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s) {
     ProfScope prof("softmax_rows", s);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld);
     return launch_status("softmax_rows");
+}
+
+int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStream_t s) {
+    ProfScope prof("csa_gather_vprime", s);
+    hipLaunchKernelGGL(csa_gather_vprime_kernel, dim3(ew_grid((long)Hh * Wh * 25 * C / 4)), dim3(256), 0, s, Pc, Hh, Wh, C, Vp);
+    return launch_status("csa_gather_vprime");
+}
+
+int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const float* Otl, const float* bd, int H, int W,
+                   int Hp, int Wp, int C, float* out, int ld_out, hipStream_t s) {
+    ProfScope prof("csa_gather_out", s);
+    hipLaunchKernelGGL(csa_gather_out_kernel, dim3(ew_grid((long)H * W * C / 4)), dim3(256), 0, s, Op, Otop, Oleft, Otl, bd, H,
+                       W, Hp, Wp, C, out, ld_out);
+    return launch_status("csa_gather_out");
 }
 
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s) {

@@ -55,6 +55,18 @@ class CrossScaleAttention(nn.Module):
             # down.weight [co][ci][a][b] -> [co][(a*3+b)*C + ci]
             wd=self.down.weight.detach().permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous().float(),
             bd=self.down.bias.detach().contiguous().float())
+        # composed fold+down form: `down` masked per tap subset, [9][C][9C] (include/ciaosr_hip.h)
+        wdm = []
+        subsets = ([0], [0, 1, 2], [1, 2])
+        wd4 = self.down.weight.detach().float()                      # [co][ci][a][b]
+        for R in subsets:
+            for S in subsets:
+                m = torch.zeros_like(wd4)
+                for a in R:
+                    for b in S:
+                        m[:, :, a, b] = wd4[:, :, a, b]
+                wdm.append(m.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc))
+        keep['wdm'] = torch.stack(wdm).contiguous()
         hip_ops.require_gpu(*keep.values())
         st = _lib.CsAttnWeightsT()
         st.channels = Cc
@@ -62,6 +74,7 @@ class CrossScaleAttention(nn.Module):
         st.w_match2, st.b_match2 = keep['w2'].data_ptr(), keep['b2'].data_ptr()
         st.w_assembly, st.b_assembly = keep['wa'].data_ptr(), keep['ba'].data_ptr()
         st.w_down, st.b_down = keep['wd'].data_ptr(), keep['bd'].data_ptr()
+        st.w_down_masked = keep['wdm'].data_ptr()
         st.slope_match1 = float(self.conv_match_1[1].weight.detach().float().cpu()[0])
         st.slope_match2 = float(self.conv_match_2[1].weight.detach().float().cpu()[0])
         st.slope_assembly = float(self.conv_assembly[1].weight.detach().float().cpu()[0])

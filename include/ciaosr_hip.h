@@ -89,6 +89,10 @@ typedef struct ciaosr_csattn_weights {
     float slope_assembly;
     const float* w_down;          /* [C][9C]   down.weight (csa:428) packed [co][(a*3+b)*C + ci] */
     const float* b_down;          /* [C] */
+    /* optional (NULL = off): `down` weights masked per tap subset for the composed fold+down form (csattn.hip):
+     * [9][C][9C], block 3r+s keeps taps a in R_r, b in S_s with R_0 = {0}, R_1 = {0,1,2}, R_2 = {1,2}; same
+     * column packing as w_down.  Used on tiles of >= 4096 LR pixels, where it shrinks attn.V from 36C to 16C columns. */
+    const float* w_down_masked;
     float escape_nan;             /* 1e-4 (csa:415) */
     float softmax_scale;          /* 10   (csa:408) */
 } ciaosr_csattn_weights_t;
