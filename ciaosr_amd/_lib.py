@@ -78,14 +78,19 @@ SIGNATURES = {
     'ciaosr_fragment_floats': (_S, [_I, _I]),
     'ciaosr_pack_fragments_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_set_head_mode': (_I, [_I]),
-    'ciaosr_set_precision': (_I, [_I]),
     'ciaosr_fragment_bf16_bytes': (_S, [_I, _I]),
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
+    'ciaosr_gather_rows_f32': (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
+    'ciaosr_mlp_workspace_bytes': (_S, [C.POINTER(MlpT), _I]),
+    'ciaosr_mlp_forward_f32': (_I, [_P, _I, C.POINTER(MlpT), _I, _I, _P, _I, _P, _S, _P]),
+    'ciaosr_decode_residual_f32': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'ciaosr_head_workspace_bytes': (_S, [_I, _I, C.POINTER(HeadWeightsT), _I]),
     'ciaosr_head_forward_f32': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
                                      _I, _I, _P, _P, _S, _P]),
+    'ciaosr_head_forward_bf16': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
+                                      _I, _I, _P, _P, _S, _P]),
     'ciaosr_rdn_workspace_bytes': (_S, [_I, _I, C.POINTER(RdnWeightsT)]),
     'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
     'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),

@@ -79,7 +79,6 @@ static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA
 }
 
 static int g_head_mode = 0;
-static int g_precision = 0;   // 0 fp32 MFMA, 1 bf16 MFMA inputs
 static int g_logit_table = 1; // exact output-layer fold of imnet_k (head_ops.hip qk_rows)
 
 // fused kernels: hidden width 256 everywhere, fragments packed, 4 key samples
@@ -110,12 +109,6 @@ static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table,
 
 using namespace ciaosr;
 
-extern "C" int ciaosr_set_precision(int mode) {
-    const int prev = g_precision;
-    g_precision = mode ? 1 : 0;
-    return prev;
-}
-
 extern "C" int ciaosr_set_head_mode(int mode) {
     // bit 0: force the staged path; bit 1: disable the logit table of the fused path
     g_logit_table = (mode & 2) ? 0 : 1;
@@ -129,10 +122,10 @@ extern "C" size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_we
     return head_ws_bytes(head_plan(H, W, w, Q));
 }
 
-extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
-                                       const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
-                                       const float* coord, const float* cell, int Q, int chunk, float* rgb,
-                                       void* workspace, size_t workspace_bytes, void* stream_) {
+static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                        const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw, const float* coord,
+                        const float* cell, int Q, int chunk, float* rgb, void* workspace, size_t workspace_bytes,
+                        void* stream_, bool bf16) {
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
     CIAOSR_CHECK_ARG(w->local_size >= 1 && w->local_size <= 3 && w->softmax_scale != 0.f);
@@ -180,7 +173,6 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
     RUN(gemm_f32(U, p.Dv, w->v.weight[0], w->v.ld[0], false, Tv, p.wv0, w->v.bias[0], p.HW, p.wv0, p.Dv, 1.f,
                  CIAOSR_ACT_NONE, 0.f, s, "head_table"));
 
-    const bool bf16 = g_precision == 1;
     const bool fused = g_head_mode == 0 && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
                        chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
     if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the bf16 mode exists for the fused kernels only
@@ -261,5 +253,57 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
         RUN(decode_residual(dp, s));
     }
 #undef RUN
+    return CIAOSR_OK;
+}
+
+extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                                       const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                                       const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, workspace, workspace_bytes,
+                        stream, false);
+}
+
+extern "C" int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                                        const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                                        const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, workspace, workspace_bytes,
+                        stream, true);
+}
+
+// ---- staged MLPRefiner (mlp_refiner.py:87-102), layer by layer, no hoist -------------------------------------
+static int mlp_wmax(const ciaosr_mlp_t* m) {
+    int w = 0;
+    for (int i = 0; i + 1 < m->n_layers; ++i) w = m->width[i] > w ? m->width[i] : w;
+    return (w + 3) & ~3;
+}
+
+extern "C" size_t ciaosr_mlp_workspace_bytes(const ciaosr_mlp_t* m, int rows) {
+    if (!m || rows <= 0 || m->n_layers < 1 || m->n_layers > CIAOSR_MAX_LAYERS) return 0;
+    return 2 * ((size_t)rows * mlp_wmax(m) * sizeof(float) + 256);
+}
+
+extern "C" int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp_t* m, int n_run, int rows, float* out,
+                                      int ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+    CIAOSR_CHECK_ARG(x && m && out && rows > 0 && mlp_ok(*m) && ld_x >= m->in_dim);
+    CIAOSR_CHECK_ARG(n_run >= 0 && n_run <= m->n_layers);
+    const int n = n_run ? n_run : m->n_layers;
+    if (workspace_bytes < ciaosr_mlp_workspace_bytes(m, rows)) return CIAOSR_ERR_WORKSPACE;
+    Arena ar(workspace, workspace_bytes);
+    const int wmax = mlp_wmax(m);
+    float* pp[2] = {ar.take<float>((size_t)rows * wmax), ar.take<float>((size_t)rows * wmax)};
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+    const float* cur = x;
+    int ld_cur = ld_x, k_cur = m->in_dim;
+    for (int i = 0; i < n; ++i) {
+        const bool last = i + 1 == n;
+        float* dst = last ? out : pp[i & 1];
+        const int ldd = last ? ld_out : wmax;
+        int rc = gemm_f32(cur, ld_cur, m->weight[i], m->ld[i], false, dst, ldd, m->bias[i], rows, m->width[i], k_cur, 1.f,
+                          i + 1 == m->n_layers ? CIAOSR_ACT_NONE : CIAOSR_ACT_RELU, 0.f, (hipStream_t)stream, "mlp_layer");
+        if (rc != CIAOSR_OK) return rc;
+        cur = dst; ld_cur = ldd; k_cur = m->width[i];
+    }
     return CIAOSR_OK;
 }

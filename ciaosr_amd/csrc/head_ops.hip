@@ -100,6 +100,54 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadRowsP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1 gather rows: the MLP inputs as the reference assembles them (net:176-196), one wavefront per (query, sample).
+// HBM traffic per query (fp32, C=64): write 4*580*4 + 4*644*4 + 576*4 B (21 936 B incl. coords).
+// ---------------------------------------------------------------------------------------------
+struct GatherRowsP {
+    const float* U; int ldu, D, Dv;
+    const float* coord; const float* cell;
+    int Q, chunk, H, W, local_size, J;
+    float* q_rows; int ldq;
+    float* inp_k; int ldk;
+    float* inp_v; int ldv;
+    int* q_idx; int* k_idx;
+};
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherRowsP p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)p.Q * p.J) return;
+    const long q = row / p.J;
+    const int j = (int)(row - q * p.J);
+    const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+    const long c0 = cell0_index(q, p.chunk);
+    const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, p.local_size);
+    const int kpix = s.ky * p.W + s.kx;
+    const float4* src = reinterpret_cast<const float4*>(p.U + (size_t)kpix * p.ldu);
+    float4* ok = reinterpret_cast<float4*>(p.inp_k + (size_t)row * p.ldk);
+    float4* ov = reinterpret_cast<float4*>(p.inp_v + (size_t)row * p.ldv);
+    for (int t = lane; t < (p.Dv >> 2); t += 64) {
+        const float4 v = src[t];
+        ov[t] = v;
+        if (t < (p.D >> 2)) ok[t] = v;
+    }
+    if (lane == 0) {
+        const float4 tail = make_float4(s.rel_y, s.rel_x, mul_rn(p.cell[2 * q], (float)p.H), mul_rn(p.cell[2 * q + 1], (float)p.W));
+        ok[p.D >> 2] = tail;
+        ov[p.Dv >> 2] = tail;
+        p.k_idx[row] = kpix;
+    }
+    if (j == 0) {
+        const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+        const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        if (lane == 0) p.q_idx[q] = inside ? iy * p.W + ix : -1;
+        float4* oq = reinterpret_cast<float4*>(p.q_rows + (size_t)q * p.ldq);
+        const float4* qs = reinterpret_cast<const float4*>(p.U + (size_t)(inside ? iy * p.W + ix : 0) * p.ldu);
+        for (int t = lane; t < (p.D >> 2); t += 64) oq[t] = inside ? qs[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4 local attention.  HBM traffic per query (fp32, C=64): wk 4*576*4 + wv 4*640*4 + z 640*4 B.
 // ---------------------------------------------------------------------------------------------
 
@@ -324,4 +372,30 @@ extern "C" int ciaosr_local_attention_f32(const float* unfold, int ld_u, int C, 
     LocalAttnP p{unfold, ld_u, 9 * C, 9 * C + Cn, q_idx, k_idx, wk, ld_wk, wv, ld_wv, z, ld_z, Q, J,
                  softmax_scale};
     return local_attention(p, (hipStream_t)stream);
+}
+
+extern "C" int ciaosr_gather_rows_f32(const float* unfold, int ld_u, int C, int Cn, const float* coord, const float* cell,
+                                      int Q, int chunk, int H, int W, int local_size, float* q_rows, int ld_q,
+                                      float* inp_k, int ld_k, float* inp_v, int ld_v, int* q_idx, int* k_idx,
+                                      void* stream) {
+    CIAOSR_CHECK_ARG(unfold && coord && cell && q_rows && inp_k && inp_v && q_idx && k_idx && Q > 0 && H > 0 && W > 0);
+    CIAOSR_CHECK_ARG(local_size >= 1 && local_size <= 3 && (C & 3) == 0 && (Cn & 3) == 0 && C > 0 && Cn >= 0);
+    const int D = 9 * C, Dv = D + Cn;
+    CIAOSR_CHECK_ARG((ld_u & 3) == 0 && (ld_q & 3) == 0 && (ld_k & 3) == 0 && (ld_v & 3) == 0);
+    CIAOSR_CHECK_ARG(ld_u >= Dv && ld_q >= D && ld_k >= D + 4 && ld_v >= Dv + 4);
+    const int J = local_size == 1 ? 1 : (local_size == 2 ? 4 : 9);
+    GatherRowsP p{unfold, ld_u, D, Dv, coord, cell, Q, chunk, H, W, local_size, J, q_rows, ld_q, inp_k, ld_k, inp_v, ld_v,
+                  q_idx, k_idx};
+    ProfScope prof("gather_rows", (hipStream_t)stream);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long)Q * J, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status("gather_rows");
+}
+
+extern "C" int ciaosr_decode_residual_f32(const float* h, int ld_h, int width, const float* w_last, int ld_w,
+                                          const float* b_last, const float* x_lr_nchw, const float* coord, int Q, int H,
+                                          int W, float* rgb, void* stream) {
+    CIAOSR_CHECK_ARG(h && w_last && b_last && coord && rgb && Q > 0 && H > 0 && W > 0);
+    CIAOSR_CHECK_ARG(width > 0 && (width & 3) == 0 && (ld_h & 3) == 0 && (ld_w & 3) == 0 && ld_h >= width && ld_w >= width);
+    DecodeP p{h, ld_h, width, w_last, ld_w, b_last, x_lr_nchw, coord, 0, Q, H, W, rgb};
+    return decode_residual(p, (hipStream_t)stream);
 }

@@ -52,6 +52,7 @@ class PackedHead:
             w, b = w.contiguous(), b.contiguous()
             hip_ops.require_gpu(w, b)
             keep += [w, b]
+            self._last_wb = (w, b)
             st.width[i] = w.shape[0]
             st.weight[i] = w.data_ptr()
             st.ld[i] = w.stride(0)
@@ -96,6 +97,7 @@ class PackedHead:
         st.k, kk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
         st.v, kv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
         st.q, kq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
+        self._q_last = self._last_wb
         self._keep = kk + kv + kq
         self._st, self._key = st, key
         return st
@@ -125,8 +127,44 @@ class PackedHead:
         nbytes = _lib.load().ciaosr_head_workspace_bytes(H, W, C.byref(st), Q)
         ws = hip_ops.workspace(nbytes, coord.device)
         rgb = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)
-        _lib.call('ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W, C.byref(st),
+        _lib.call('ciaosr_head_forward_bf16' if hip_ops.precision() == 'bf16' else 'ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W, C.byref(st),
                   C.byref(cs) if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
                   hip_ops.ptr(cell), Q, int(chunk or 0), hip_ops.ptr(rgb), hip_ops.ptr(ws), ws.numel(),
                   hip_ops.stream_ptr())
         return rgb
+
+    @torch.no_grad()
+    def forward_as_written(self, feature_chw, x_lr_chw, coord, cell, chunk=None):
+        """The reference's op order, stage by stage through the staged C entry points, with NO algebraic
+        restructuring (no layer-1 hoist, no logit table, no fusion): K1 gather rows (net:145-196) ->
+        imnet_k / imnet_v on every (query, sample) row (net:202-206) -> K4 local attention (net:211-216) ->
+        imnet_q hidden layers -> last Linear + bilinear residual (net:221, 107-108); one pass per
+        eval_bsize chunk like batched_predict (net:238-246), cs_attn once.
+        Used by the parity tests as a third evaluation route and to measure K1/K4 against the HBM roofline."""
+        net = self.net
+        feature_chw = feature_chw.contiguous().float()
+        coord, cell = coord.contiguous().float(), cell.contiguous().float()
+        x_lr_chw = x_lr_chw.contiguous().float() if x_lr_chw is not None else None
+        Cc, H, W = feature_chw.shape
+        st = self.struct()
+        Cn = st.nonlocal_channels
+        feat_hwc = hip_ops.nchw_to_hwc(feature_chw)
+        U = hip_ops.patch_rows(feat_hwc, 3, 1, 1, H, W)
+        if net.non_local_attn:
+            nl = hip_ops.nchw_to_hwc(net.cs_attn(feature_chw.unsqueeze(0))[0].contiguous())
+            U = torch.cat([U, nl.view(H * W, Cn)], dim=1).contiguous()
+        Q = coord.shape[0]
+        step = int(chunk) if chunk else Q
+        out = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)
+        nq = st.q.n_layers
+        w_last, b_last = self._q_last
+        for q0 in range(0, Q, step):
+            q1 = min(Q, q0 + step)
+            cq, cl = coord[q0:q1].contiguous(), cell[q0:q1].contiguous()
+            q_rows, inp_k, inp_v, q_idx, k_idx = hip_ops.gather_rows(U, Cc, Cn, cq, cl, H, W, st.local_size)
+            wk = hip_ops.mlp_forward(inp_k, st.k)
+            wv = hip_ops.mlp_forward(inp_v, st.v)
+            z = hip_ops.local_attention(U, Cc, Cn, q_idx, k_idx, wk, wv, softmax_scale=st.softmax_scale)
+            h = hip_ops.mlp_forward(z, st.q, n_run=nq - 1)
+            out[q0:q1] = hip_ops.decode_residual(h, w_last, b_last, x_lr_chw, cq, H, W)
+        return out

@@ -164,12 +164,61 @@ def set_head_mode(mode):
     _lib.call('ciaosr_set_head_mode', int(mode))
 
 
+_precision = 'fp32'
+
+
 def set_precision(mode):
-    """'fp32' (exact-fp32 MFMA, default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate) for the fused head.
-    Returns the previous mode name."""
-    m = {'fp32': 0, 'f32': 0, 0: 0, 'bf16': 1, 1: 1}[mode]
-    prev = _lib.load().ciaosr_set_precision(m)
-    return 'bf16' if prev else 'fp32'
+    """'fp32' (exact-fp32 MFMA, default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate): selects which C entry
+    point the host classes call (ciaosr_head_forward_f32 / _bf16).  Host-side switch; the library itself keeps
+    no precision state.  Returns the previous mode name."""
+    global _precision
+    prev = _precision
+    _precision = {'fp32': 'fp32', 'f32': 'fp32', 0: 'fp32', 'bf16': 'bf16', 1: 'bf16'}[mode]
+    return prev
+
+
+def precision():
+    return _precision
+
+
+def gather_rows(unfold, C_, Cn, coord, cell, H, W, local_size=2, chunk=0):
+    """K1 as the reference assembles it: (q_rows [Q,9C], inp_k [Q*J,9C+4], inp_v [Q*J,9C+Cn+4], q_idx, k_idx)."""
+    require_gpu(unfold, coord, cell)
+    Q = coord.shape[0]
+    J = {1: 1, 2: 4, 3: 9}[local_size]
+    D, Dv = 9 * C_, 9 * C_ + Cn
+    dev = unfold.device
+    q_rows = torch.empty(Q, D, dtype=torch.float32, device=dev)
+    inp_k = torch.empty(Q * J, D + 4, dtype=torch.float32, device=dev)
+    inp_v = torch.empty(Q * J, Dv + 4, dtype=torch.float32, device=dev)
+    q_idx = torch.empty(Q, dtype=torch.int32, device=dev)
+    k_idx = torch.empty(Q, J, dtype=torch.int32, device=dev)
+    _lib.call('ciaosr_gather_rows_f32', ptr(unfold), unfold.stride(0), C_, Cn, ptr(coord), ptr(cell), Q, int(chunk or 0),
+              H, W, local_size, ptr(q_rows), D, ptr(inp_k), D + 4, ptr(inp_v), Dv + 4, ptr(q_idx), ptr(k_idx),
+              stream_ptr())
+    return q_rows, inp_k, inp_v, q_idx, k_idx
+
+
+def mlp_forward(x, mlp_struct, n_run=0):
+    """MLPRefiner.forward layer by layer (no hoist); n_run > 0 stops after that many layers (ReLU applied)."""
+    require_gpu(x)
+    rows = x.shape[0]
+    n = n_run or mlp_struct.n_layers
+    out = torch.empty(rows, mlp_struct.width[n - 1], dtype=torch.float32, device=x.device)
+    nbytes = _lib.load().ciaosr_mlp_workspace_bytes(C.byref(mlp_struct), rows)
+    ws = workspace(nbytes, x.device, slot='mlp')
+    _lib.call('ciaosr_mlp_forward_f32', ptr(x), x.stride(0), C.byref(mlp_struct), int(n_run), rows, ptr(out),
+              out.stride(0), ptr(ws), ws.numel(), stream_ptr())
+    return out
+
+
+def decode_residual(h, w_last, b_last, x_lr_chw, coord, H, W):
+    require_gpu(h, w_last, b_last, x_lr_chw, coord)
+    Q = h.shape[0]
+    rgb = torch.empty(Q, 3, dtype=torch.float32, device=h.device)
+    _lib.call('ciaosr_decode_residual_f32', ptr(h), h.stride(0), h.shape[1], ptr(w_last), w_last.stride(0), ptr(b_last),
+              ptr(x_lr_chw), ptr(coord), Q, H, W, ptr(rgb), stream_ptr())
+    return rgb
 
 
 class profile:

@@ -129,11 +129,6 @@ int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, float* out, 
 size_t ciaosr_fragment_bf16_bytes(int N, int K);
 int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream);
 
-/* Arithmetic mode of the head's dense contractions: 0 = exact fp32 MFMA (default, |delta| <= 1e-3 contract),
- * 1 = bf16 MFMA inputs with fp32 accumulation (coordinates, index math, layer-0 tables, logits, softmax and the
- * decode output stay fp32); parity for mode 1 is PSNR-based.  Returns the previous mode. */
-int ciaosr_set_precision(int mode);
-
 /* bit 0: force the staged per-layer path; bit 1: fused path without the logit table (imnet_k's output layer
  * runs on the MFMA for every (query, sample) row instead of the exact 9-rows-per-LR-pixel fold); 0 = automatic */
 int ciaosr_set_head_mode(int mode);
@@ -167,6 +162,30 @@ int ciaosr_local_attention_f32(const float* unfold, int ld_u, int C, int Cn, con
                                const int* k_idx, const float* wk, int ld_wk, const float* wv, int ld_wv,
                                float* z, int ld_z, int Q, int J, float softmax_scale, void* stream);
 
+/* Staged K1 "gather rows" (net:145-146,176-196), the MLP inputs exactly as the reference assembles them:
+ *   q_rows [Q][ld_q]      = unfold[q_idx[q]][0:9C]                     (zeros when the query falls outside, net:145)
+ *   inp_k  [Q*J][ld_k]    = [ unfold[k_idx][0:9C]      | rel_y rel_x | scale_y scale_x ]      (net:195)
+ *   inp_v  [Q*J][ld_v]    = [ unfold[k_idx][0:9C+Cn]   | rel_y rel_x | scale_y scale_x ]      (net:196)
+ * row r = q*J + j (the reference stacks per shift j; same rows, query-major here).  q_idx [Q], k_idx [Q*J] are
+ * written for ciaosr_local_attention_f32.  unfold rows are in the library's (ki,kj,c) column order. */
+int ciaosr_gather_rows_f32(const float* unfold, int ld_u, int C, int Cn, const float* coord, const float* cell, int Q,
+                           int chunk, int H, int W, int local_size, float* q_rows, int ld_q, float* inp_k, int ld_k,
+                           float* inp_v, int ld_v, int* q_idx, int* k_idx, void* stream);
+
+/* Staged MLPRefiner.forward (mlp_refiner.py:87-102): y = L_n(relu(...relu(L_1 x))) on `rows` rows through the
+ * fp32 MFMA GEMM, layer by layer, no hoist.  x [rows][ld_x] (in_dim columns), out [rows][ld_out];
+ * n_run = 0 runs every layer; 0 < n_run < n_layers stops after layer n_run (ReLU applied) so that the
+ * remaining tail can go through ciaosr_decode_residual_f32.  workspace >= ciaosr_mlp_workspace_bytes(m, rows). */
+size_t ciaosr_mlp_workspace_bytes(const ciaosr_mlp_t* m, int rows);
+int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp_t* m, int n_run, int rows, float* out, int ld_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Staged decode tail (net:107-108,221): rgb[q] = W_last . h[q] + b_last + bilinear_border(x_lr_nchw; coord[q]).
+ * h [Q][ld_h] (width columns), w_last [3][ld_w]; x_lr_nchw NULL = no residual. */
+int ciaosr_decode_residual_f32(const float* h, int ld_h, int width, const float* w_last, int ld_w, const float* b_last,
+                               const float* x_lr_nchw, const float* coord, int Q, int H, int W, float* rgb,
+                               void* stream);
+
 size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w, int Q);
 
 /* query_rgb + batched_predict + bilinear residual (net:88-248) given the encoder feature map.
@@ -181,6 +200,14 @@ int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_he
                             const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                             const float* coord, const float* cell, int Q, int chunk, float* rgb,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* Same path with bf16 MFMA inputs (fp32 accumulation) in the fused kernels' dense layers; coordinates, index
+ * math, the layer-0 tables, logits, softmax and the decode output stay fp32.  Needs the bf16 fragments
+ * (ciaosr_mlp_t.frag16); CIAOSR_ERR_UNSUPPORTED when the fused kernels do not apply.  Parity is PSNR-based. */
+int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                             const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                             const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- encoder trunks: gen_feature (net:321-342 RDN, net:393-408 EDSR) -------------------------- */
 typedef struct ciaosr_conv {

@@ -250,6 +250,47 @@ def test_fused_and_staged_head_paths_agree(dev):
     assert (fused - staged).abs().max() < tol and (fused_mfma - staged).abs().max() < tol
 
 
+def test_as_written_staged_route_vs_golden_and_fused(dev):
+    """Third evaluation route: the reference's op order through the staged C entry points with no algebraic
+    restructuring (ciaosr_gather_rows_f32 -> ciaosr_mlp_forward_f32 x2 -> ciaosr_local_attention_f32 ->
+    ciaosr_mlp_forward_f32 -> ciaosr_decode_residual_f32) against the reference fixture, and against the
+    fused path at full width on a ragged query count with eval_bsize chunks."""
+    from ciaosr_amd.coords import make_coord, make_cell
+    fx = load_golden('tiny_head_s2p7')
+    g = _my_generator(8, (32, 32), weights_from(fx), dev, eval_bsize=int(fx['eval_bsize']))
+    feat, coord, cell = _t(fx['feature']).to(dev), _t(fx['coord']).to(dev), _t(fx['cell']).to(dev)
+    out = g._head.forward_as_written(feat[0], None, coord[0], cell[0], chunk=int(fx['eval_bsize'])).cpu()
+    assert (out - _t(fx['out'])[0]).abs().max() < TOL
+
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 3, head_gain=2.0), dev, eval_bsize=2000)
+    feat = randn((1, 64, 21, 30), 11).to(dev)
+    ht, wt = 59, 83
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    x = (randn((1, 3, 21, 30), 12) * 0.3).to(dev)
+    fused = g._predict([feat], coord, cell, 2000, x).cpu()[0]
+    written = g._head.forward_as_written(feat[0], x[0], coord[0], cell[0], chunk=2000).cpu()
+    assert (fused - written).abs().max() < 5e-5 * max(1.0, written.abs().max().item())
+
+
+def test_gather_rows_matches_reference_assembly(dev):
+    """K1 alone: inp_k / inp_v / q rows against torch indexing of the same unfold rows (net:145,176-196)."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    C, Cn, H, W = 8, 8, 7, 9
+    U = randn((H * W, 9 * C + Cn), 50).to(dev)
+    ht, wt = 19, 25
+    coord, cell = make_coord((ht, wt)).to(dev), make_cell((ht, wt)).to(dev)
+    q_rows, inp_k, inp_v, q_idx, k_idx = hip_ops.gather_rows(U, C, Cn, coord, cell, H, W, local_size=2)
+    qi, ki, rel = hip_ops.head_indices(coord, cell, H, W, local_size=2)
+    assert torch.equal(q_idx, qi) and torch.equal(k_idx, ki)
+    kl = k_idx.long().view(-1)
+    assert torch.equal(q_rows, U[q_idx.long(), :9 * C])
+    assert torch.equal(inp_k[:, :9 * C], U[kl, :9 * C]) and torch.equal(inp_v[:, :9 * C + Cn], U[kl])
+    assert torch.equal(inp_k[:, 9 * C:9 * C + 2], rel.view(-1, 2)) and torch.equal(inp_k[:, 9 * C:], inp_v[:, 9 * C + Cn:])
+    scale = (cell * torch.tensor([H, W], dtype=torch.float32, device=dev)).repeat_interleave(4, 0)
+    assert torch.equal(inp_k[:, 9 * C + 2:], scale)
+
+
 def test_staged_local_attention_kernel(dev):
     """K4 alone: ciaosr_local_attention_f32 against a direct torch evaluation of net:211-216."""
     from ciaosr_amd import hip_ops
