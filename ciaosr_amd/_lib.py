@@ -40,7 +40,8 @@ class CsAttnWeightsT(C.Structure):
 
 
 class ConvT(C.Structure):
-    _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int)]
+    _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int),
+                ('frag16', C.c_void_p)]
 
 
 class RdnWeightsT(C.Structure):
@@ -93,6 +94,7 @@ SIGNATURES = {
                                       _I, _I, _P, _P, _S, _P]),
     'ciaosr_rdn_workspace_bytes': (_S, [_I, _I, C.POINTER(RdnWeightsT)]),
     'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
+    'ciaosr_rdn_forward_bf16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
     'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),
     'ciaosr_edsr_forward_f32': (_I, [_P, _I, _I, C.POINTER(EdsrWeightsT), _P, _P, _S, _P]),
     'ciaosr_normalize_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),

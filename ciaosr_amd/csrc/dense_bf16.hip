@@ -1,0 +1,237 @@
+// bf16-MFMA dense-block convolution (precision mode "bf16" of the RDN trunk, big tiles only).
+//
+// One 3x3 dense layer l of a residual dense block (mmedit RDB.layers[l].conv over cat(x, d_0 .. d_{l-1}),
+// called from ciaosr_net.py:330-337) in GATHER form: K = 9 * 64 (l+1), N = 64 output channels,
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Inputs are the bf16 copy Xb [HW][64*9] of the block's
+// feature buffer; the output relu(conv + b) is written as fp32 (for the fp32 LFF / residual path) and as bf16
+// (for the following dense layers).
+//
+// The fp32 convolution of conv_f32.hip is bound by its operand stream (one 64-channel K-stage of A and B is
+// fetched per 64x64x64 MACs), not by the MFMA, so a 16x faster MFMA alone would buy nothing.  Here the traffic
+// per MAC is cut instead:
+//   * workgroup = 12x12 output pixels x all 64 output channels; a 192x192 tile is exactly 256 workgroups,
+//     one per CU;
+//   * the 14x14-pixel halo patch of one 64-channel input group (bf16, 25 KB) is loaded into LDS ONCE and
+//     serves all 9 taps (the next group's patch is prefetched into registers meanwhile, two LDS buffers);
+//   * the 4 waves split K (wave w owns channels 16w..16w+15 of every group): each wave accumulates the whole
+//     160(144 used) x 64 tile -- 5x2 MFMA tiles, 160 accumulator registers -- so one 16-B LDS read per pixel
+//     tile feeds two MFMAs and one 1-KB weight fragment read from L2 (pre-packed, coalesced, no LDS) feeds five;
+//     LDS traffic is ~75 B/clk/CU at the full MFMA rate, under the 128 B/clk limit;
+//   * the K-slices are summed through LDS once per layer (fixed order: deterministic) in the epilogue.
+// Swapped operands (weights = A, activations = B): a lane owns one pixel and 4x4 consecutive channels.
+#include <cstdlib>
+
+#include "ops.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DT = 12;                       // output tile edge (pixels)
+constexpr int DP = DT + 2;                   // patch edge with the 1-pixel halo
+constexpr int DPS = 144;                     // bytes per patch pixel: 64 bf16 + 16 B pad (conflict-free ds_read_b128)
+constexpr int DPATCH = DP * DP * DPS;        // 28 224 B per buffer
+constexpr int DCHUNKS = DP * DP * 8;         // 16-byte chunks of a patch
+constexpr int DLOADS = (DCHUNKS + 255) / 256;
+constexpr int DMT = 5;                       // 32-pixel MFMA tiles per workgroup (160 rows, 144 used)
+constexpr size_t kDenseLds = 81920;          // max(2 patches, K-slice reduction scratch 4 x 5 x 4 x 64 x 16 B)
+constexpr unsigned kOobD = 0xFFFFFFF0u;
+
+struct DenseBf16P {
+    const unsigned short* xb; int ldxb;      // bf16 feature buffer [HW][ldxb], 64-channel groups
+    unsigned xb_bytes;
+    int H, W, tiles_x;
+    int groups;                              // input groups of this layer (l + 1)
+    const uint4* wf; int nks;                // ciaosr_pack_fragments_bf16 of the conv weight [64][9*cin]: [2][nks][64 lanes]
+    const float* bias;                       // [64]
+    float* x; int ldx;                       // fp32 feature buffer (written at column col_out)
+    unsigned short* xb_out;                  // == xb (written at column col_out)
+    int col_out;
+};
+
+__device__ __forceinline__ unsigned short f2bf_d(float f) {    // round-to-nearest-even
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int ty0 = (blockIdx.x / p.tiles_x) * DT, tx0 = (blockIdx.x % p.tiles_x) * DT;
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xb), 0, p.xb_bytes, 0x00020000);
+
+    // patch staging: thread -> 16-byte chunks t + 256 s  (pixel = chunk / 8, 8 chunks = 64 channels)
+    unsigned goff[DLOADS];
+    int loff[DLOADS];
+#pragma unroll
+    for (int s = 0; s < DLOADS; ++s) {
+        const int c = t + 256 * s;
+        const int px = c >> 3, part = c & 7;
+        const int py = px / DP, pxx = px - py * DP;
+        const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
+        const bool ok = c < DCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        goff[s] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)p.ldxb * 2u + (unsigned)part * 16u) : kOobD;
+        loff[s] = c < DCHUNKS ? px * DPS + part * 16 : -1;
+    }
+    i32x4 P[DLOADS];
+    auto load_chunk = [&](int s, int g) {
+        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobD ? (int)kOobD : (int)(goff[s] + (unsigned)g * 128u), 0, 0);
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < DLOADS; ++s)
+            if (loff[s] >= 0) *reinterpret_cast<i32x4*>(lds + buf * DPATCH + loff[s]) = P[s];
+    };
+
+    // B operand (activations): pixel of lane li in each of the 5 pixel tiles, this wave's 16-channel K slice
+    int poff[DMT];
+#pragma unroll
+    for (int r = 0; r < DMT; ++r) {
+        int idx = 32 * r + li;
+        idx = idx < DT * DT ? idx : DT * DT - 1;
+        const int y = idx / DT, x = idx - y * DT;
+        poff[r] = ((y + 1) * DP + (x + 1)) * DPS + (16 * w + 8 * lh) * 2;
+    }
+    const uint4* wl = p.wf + lane;
+    const int kpt = 4 * p.groups;            // k16-steps per tap (cin / 16)
+    auto frag = [&](int nt, int g, int tap) -> uint4 { return wl[(size_t)(nt * p.nks + tap * kpt + 4 * g + w) * 64]; };
+
+    f32x16 acc[2][DMT];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < DMT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < DLOADS; ++s) load_chunk(s, 0);
+    store_patch(0);
+    uint4 w0[2], w1[2], w2[2];               // weight fragments of the current tap and the next two
+    w0[0] = frag(0, 0, 0); w0[1] = frag(1, 0, 0);
+    w1[0] = frag(0, 0, 1); w1[1] = frag(1, 0, 1);
+    __syncthreads();
+
+    const int G = p.groups;
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const bool more = g + 1 < G;
+        const unsigned char* pb = lds + (g & 1) * DPATCH;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            {   // weights two taps ahead
+                int ng = g, ntap = tap + 2;
+                if (ntap >= 9) { ntap -= 9; ng = g + 1; }
+                if (ng < G) { w2[0] = frag(0, ng, ntap); w2[1] = frag(1, ng, ntap); }
+            }
+            if (more && tap < DLOADS) load_chunk(tap, g + 1);      // next group's patch, one chunk per tap
+            const int toff = ((tap / 3 - 1) * DP + (tap % 3 - 1)) * DPS;
+            bf16x8 b[DMT];
+#pragma unroll
+            for (int r = 0; r < DMT; ++r)
+                b[r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + poff[r] + toff));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, w0[nt]);
+#pragma unroll
+                for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[r], acc[nt][r], 0, 0, 0);
+            }
+            w0[0] = w1[0]; w0[1] = w1[1];
+            w1[0] = w2[0]; w1[1] = w2[1];
+        }
+        if (more) store_patch((g + 1) & 1);
+        __syncthreads();
+    }
+
+    // K-slice reduction + epilogue, one 32-channel half at a time through LDS:
+    // red[w][r][q][lane] = float4 of accumulator registers 4q..4q+3 (= channels 8q + 4lh .. +3 of pixel li of tile r)
+    float4* red = reinterpret_cast<float4*>(lds);
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int r = 0; r < DMT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                red[((w * DMT + r) * 4 + q) * 64 + lane] =
+                    make_float4(acc[nt][r][4 * q], acc[nt][r][4 * q + 1], acc[nt][r][4 * q + 2], acc[nt][r][4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < DMT; ++u) {
+            const int unit = t + 256 * u;                 // (r, q, lane)
+            const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
+            float4 v = red[((0 * DMT + r) * 4 + q) * 64 + ul];
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const float4 o = red[((ww * DMT + r) * 4 + q) * 64 + ul];
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            const int idx = 32 * r + (ul & 31);
+            const int y = ty0 + idx / DT, x = tx0 + idx % DT;
+            if (idx < DT * DT && y < p.H && x < p.W) {
+                const int co = 32 * nt + 8 * q + 4 * (ul >> 5);
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
+                v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+                const size_t pix = (size_t)y * p.W + x;
+                *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
+                *reinterpret_cast<uint2*>(p.xb_out + pix * p.ldxb + p.col_out + co) =
+                    make_uint2((unsigned)f2bf_d(v.x) | ((unsigned)f2bf_d(v.y) << 16),
+                               (unsigned)f2bf_d(v.z) | ((unsigned)f2bf_d(v.w) << 16));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// fp32 columns [col, col+64) of X -> the same columns of the bf16 copy
+__global__ void cast_group_bf16_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ Xb, int ldxb, int col,
+                                       long HW) {
+    const long n = HW * 16;                   // float4 units
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i >> 4;
+        const int c = (int)(i & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(X + pix * ldx + col + c);
+        *reinterpret_cast<uint2*>(Xb + pix * ldxb + col + c) =
+            make_uint2((unsigned)f2bf_d(v.x) | ((unsigned)f2bf_d(v.y) << 16), (unsigned)f2bf_d(v.z) | ((unsigned)f2bf_d(v.w) << 16));
+    }
+}
+
+int dense_bf16_min_tiles() {
+    const char* e = getenv("CIAOSR_DENSE_BF16_MIN_TILES");     // read per call: tests lower it for small maps
+    return e ? atoi(e) : 128;
+}
+
+int dense_bf16_tiles(int H, int W) { return ceil_div(H, DT) * ceil_div(W, DT); }
+
+int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s) {
+    ProfScope prof("enc_cast_bf16", s);
+    const long n = HW * 16;
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(cast_group_bf16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, X, ldx, Xb, ldxb, col, HW);
+    return launch_status("cast_group_bf16");
+}
+
+// dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb)
+int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
+                     const float* bias, hipStream_t s) {
+    CIAOSR_CHECK_ARG(X && Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);
+    const size_t xb_bytes = (size_t)H * W * ldxb * 2;
+    CIAOSR_CHECK_ARG(xb_bytes < 0xFFFFFF00ull);
+    DenseBf16P p;
+    p.xb = Xb; p.ldxb = ldxb; p.xb_bytes = (unsigned)xb_bytes;
+    p.H = H; p.W = W; p.tiles_x = ceil_div(W, DT);
+    p.groups = l + 1;
+    p.wf = reinterpret_cast<const uint4*>(frag16); p.nks = 9 * 64 * (l + 1) / 16;
+    p.bias = bias;
+    p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
+    static bool attr = false;
+    if (!attr) { allow_big_lds(dense_bf16_kernel, kDenseLds); attr = true; }
+    ProfScope prof("enc_dense_bf16", s);
+    hipLaunchKernelGGL(dense_bf16_kernel, dim3(dense_bf16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+    return launch_status("dense_bf16");
+}
+
+}  // namespace ciaosr

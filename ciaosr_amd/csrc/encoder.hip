@@ -13,6 +13,13 @@ int conv2d_hwc(const float* src, int ld_src, int H, int W, int Cin, const float*
 int dense_scatter_step(float* X, int ldx, int H, int W, int step, int num_layers, const float* wgt, const float* bias_all,
                        float* acc_buf, float* partial, size_t partial_floats, hipStream_t s);
 
+// dense_bf16.hip
+int dense_bf16_min_tiles();
+int dense_bf16_tiles(int H, int W);
+int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);
+int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
+                     const float* bias, hipStream_t s);
+
 __global__ void image_to_hwc4_kernel(const float* __restrict__ x, float* __restrict__ out, long HW) {
     // [3][H][W] -> [H*W][4] with a zero 4th channel (so the first conv moves float4 taps)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x)
@@ -50,12 +57,12 @@ extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weig
     const int C = w->mid_channels, G = w->growth, cb = C + G * w->num_layers;
     size_t n = HW * 4 + HW * 36 + HW * C /*sfe1*/ + 2 * HW * cb /*block buffers*/ +
                HW * (size_t)G * w->num_blocks /*global concat*/ + HW * C /*gff0*/ + HW * (size_t)G * w->num_layers /*scatter sums*/ +
-               16 * HW * (size_t)(C > G ? C : G);
+               16 * HW * (size_t)(C > G ? C : G) + HW * cb / 2 + 64 /*bf16 copy of one block buffer*/;
     return n * sizeof(float) + 16 * 256;
 }
 
-extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
-                                      float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream_) {
+static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc, void* workspace,
+                       size_t workspace_bytes, void* stream_, bool bf16) {
     CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
     const int C = w->mid_channels, G = w->growth, NB = w->num_blocks, NL = w->num_layers;
     CIAOSR_CHECK_ARG(C % 32 == 0 && G % 32 == 0 && NB >= 1 && NL >= 1 && w->dense && w->lff);
@@ -76,7 +83,13 @@ extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const c
     float* accb = ar.take<float>(HW * (size_t)G * NL);
     const size_t pf = 16 * HW * (size_t)(C > G ? C : G);
     float* part = ar.take<float>(pf);
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(ar.take<float>(HW * cb / 2 + 64));
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+    // bf16 mode: the dense layers (97 % of the trunk's MACs) run on the bf16 MFMA when the map is big enough to give
+    // every CU a tile (dense_bf16.hip); first/last convolutions, LFF/GFF 1x1 and all residual sums stay fp32
+    bool dense16 = bf16 && C == 64 && G == 64 && dense_bf16_tiles(H, W) >= dense_bf16_min_tiles();
+    if (bf16)
+        for (int i = 0; i < NB * NL && dense16; ++i) dense16 = w->dense[i].frag16 != nullptr;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
     RUN(first_conv(x_nchw, H, W, w->sfe1, img4, rows, sfe1, C, s));
@@ -86,7 +99,14 @@ extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const c
     for (int b = 0; b < NB; ++b) {
         float* x = X[b & 1];
         float* xn = X[(b + 1) & 1];
-        if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
+        if (dense16) {
+            RUN(cast_group_bf16(x, cb, Xb, cb, 0, (long)HW, s));
+            for (int l = 0; l < NL; ++l) {
+                const ciaosr_conv_t& c = w->dense[b * NL + l];
+                CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
+                RUN(dense_layer_bf16(x, cb, Xb, cb, H, W, l, c.frag16, c.bias, s));
+            }
+        } else if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
             // scatter form: input group s (64 channels) feeds every later dense layer in ONE convolution with
             // N = 64*(NL-s) output channels and K = 576: no split-K slabs, 8 launches instead of 16
             for (int st = 0; st < NL; ++st)
@@ -114,6 +134,16 @@ extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const c
                    CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
 #undef RUN
     return CIAOSR_OK;
+}
+
+extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
+                                      float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
+                                       float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w) {

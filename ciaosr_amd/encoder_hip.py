@@ -9,7 +9,7 @@ import torch
 from . import _lib, hip_ops
 
 
-def _pack_conv(conv, keep, pad_cin_to=None):
+def _pack_conv(conv, keep, pad_cin_to=None, frag16=False):
     w = conv.weight.detach().float()
     co, ci, kh, kw = w.shape
     w = w.permute(0, 2, 3, 1)
@@ -21,6 +21,14 @@ def _pack_conv(conv, keep, pad_cin_to=None):
     keep += [w, b]
     st = _lib.ConvT()
     st.weight, st.bias, st.cin, st.cout, st.ksize = w.data_ptr(), b.data_ptr(), ci, co, kh
+    st.frag16 = None
+    if frag16:
+        # bf16 MFMA fragments of the [cout][k*k*cin] matrix for the bf16 trunk mode (dense_bf16.hip)
+        n_, k_ = w.shape
+        f16 = torch.empty(_lib.load().ciaosr_fragment_bf16_bytes(n_, k_), dtype=torch.uint8, device=w.device)
+        _lib.call('ciaosr_pack_fragments_bf16', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f16), hip_ops.stream_ptr())
+        keep.append(f16)
+        st.frag16 = f16.data_ptr()
     return st
 
 
@@ -57,7 +65,7 @@ class PackedEncoder:
             lff = (_lib.ConvT * nb)()
             for b in range(nb):
                 for l in range(nl):
-                    dense[b * nl + l] = _pack_conv(n.rdbs[b].layers[l].conv, keep)
+                    dense[b * nl + l] = _pack_conv(n.rdbs[b].layers[l].conv, keep, frag16=True)
                 lff[b] = _pack_conv(n.rdbs[b].lff, keep)
             st.dense, st.lff = dense, lff
             keep += [dense, lff]
@@ -115,7 +123,7 @@ class PackedEncoder:
         lib = _lib.load()
         if self.kind == 'rdn':
             nbytes = lib.ciaosr_rdn_workspace_bytes(H, W, C.byref(st))
-            fn = 'ciaosr_rdn_forward_f32'
+            fn = 'ciaosr_rdn_forward_bf16' if hip_ops.precision() == 'bf16' else 'ciaosr_rdn_forward_f32'
         else:
             nbytes = lib.ciaosr_edsr_workspace_bytes(H, W, C.byref(st))
             fn = 'ciaosr_edsr_forward_f32'

@@ -214,6 +214,8 @@ typedef struct ciaosr_conv {
     const float* weight; /* [cout][k*k*cin'] packed (a*k+b)*cin' + ci; cin' = cin (4 for the 3-channel first conv, zero padded) */
     const float* bias;   /* [cout] */
     int cin, cout, ksize;
+    const void* frag16;  /* optional: ciaosr_pack_fragments_bf16(weight, ld = k*k*cin, N = cout, K = k*k*cin); used by
+                          * ciaosr_rdn_forward_bf16 for the dense layers, NULL otherwise */
 } ciaosr_conv_t;
 
 typedef struct ciaosr_rdn_weights {
@@ -242,6 +244,11 @@ size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weights_t* w);
 /* x_nchw [3][H][W] normalised LR image -> feat_hwc [H][W][mid_channels] */
 int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                            void* workspace, size_t workspace_bytes, void* stream);
+/* Same trunk with the dense layers (RDB.layers[l].conv) on the bf16 MFMA, fp32 accumulation, when the map has at
+ * least 128 tiles of 12x12 pixels (else identical to the f32 entry); first/last convolutions, LFF/GFF and all
+ * residual sums stay fp32.  Needs ciaosr_conv_t.frag16 on every dense layer.  Parity is PSNR-based. */
+int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                            void* workspace, size_t workspace_bytes, void* stream);
 size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w);
 int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w, float* feat_hwc,
                             void* workspace, size_t workspace_bytes, void* stream);

@@ -311,6 +311,60 @@ def test_staged_local_attention_kernel(dev):
 # ------------------------------------------------------------------------------------------------
 # encoder trunks (implicit-GEMM convolutions)
 # ------------------------------------------------------------------------------------------------
+def _rdn_trunk_bf16_emulation(x, P, nb, nl):
+    """torch-CPU RDN trunk with the bf16 mode's rounding points: dense-layer inputs and weights rounded to bf16
+    (products are then exact in fp32), fp32 accumulation, everything else fp32."""
+    F = torch.nn.functional
+    bf = lambda t: t.bfloat16().float()
+    sfe1 = F.conv2d(x, P['sfe1.weight'], P['sfe1.bias'], padding=1)
+    cur = F.conv2d(sfe1, P['sfe2.weight'], P['sfe2.bias'], padding=1)
+    outs = []
+    for b in range(nb):
+        feats = [cur]
+        for l in range(nl):
+            inp = torch.cat([bf(f) for f in feats], 1)
+            feats.append(F.relu(F.conv2d(inp, bf(P[f'rdbs.{b}.layers.{l}.conv.weight']), P[f'rdbs.{b}.layers.{l}.conv.bias'], padding=1)))
+        cur = cur + F.conv2d(torch.cat(feats, 1), P[f'rdbs.{b}.lff.weight'], P[f'rdbs.{b}.lff.bias'])
+        outs.append(cur)
+    g = F.conv2d(torch.cat(outs, 1), P['gff.0.weight'], P['gff.0.bias'])
+    return F.conv2d(g, P['gff.1.weight'], P['gff.1.bias'], padding=1) + sfe1
+
+
+@pytest.mark.parametrize('hw,blocks,layers,tol', [((37, 53), 1, 1, 1e-4), ((29, 40), 2, 3, 5e-4), ((48, 60), 16, 8, 6e-3)])
+def test_rdn_trunk_bf16_dense_layers(dev, hw, blocks, layers, tol, monkeypatch):
+    """ciaosr_rdn_forward_bf16 (dense layers on the bf16 MFMA, dense_bf16.hip; ragged 12x12 tiles) against a torch
+    emulation with the same rounding points, and its distance from the fp32 trunk.  The two sides round nearly
+    equal fp32 activations to bf16, and the rare value that lands on the other side of a rounding boundary (1 bf16
+    ulp = 0.4 %) moves a few outputs by ~1e-4 and propagates with depth: the max bound loosens with depth while the
+    mean error stays at summation-order level for the one-layer case."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_init_
+    from oracle import ciaosr_oracle as orc
+    monkeypatch.setenv('CIAOSR_DENSE_BF16_MIN_TILES', '1')
+    model = _restorer('rdn', 4, dev, dict(scale=4), blocks=blocks, layers=layers)
+    seeded_init_(model, seed=23, gain=1.6)
+    params = {k[len('generator.'):]: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    x = randn((1, 3) + hw, 78) * 0.3
+    gen = model.generator.to(dev)
+    nb, nl = len(gen.rdbs), len(gen.rdbs[0].layers)
+    want = _rdn_trunk_bf16_emulation(x, params, nb, nl)
+    f32 = orc.encoder_features(x, params)
+    try:
+        hip_ops.set_precision('bf16')
+        with hip_ops.profile():
+            got = gen.gen_feature(x.to(dev))[0].cpu()
+        assert 'enc_dense_bf16' in hip_ops.profile.results(), 'bf16 dense kernel did not run'
+    finally:
+        hip_ops.set_precision('fp32')
+    scale = want.abs().max().item()
+    err, dist = (got - want).abs().max().item(), (got - f32).abs().max().item()
+    print(f'bf16 trunk {hw}: max|d| vs emulation {err:.3e}, vs fp32 trunk {dist:.3e} (feature scale {scale:.3f})')
+    assert err < tol * scale, (err, scale)
+    if blocks == 1:
+        assert (got - want).abs().mean().item() < 2e-6 * scale
+    assert dist < 5e-2 * scale, (dist, scale)
+
+
 @pytest.mark.parametrize('kind,hw', [('rdn', (48, 48)), ('edsr', (48, 48)), ('rdn', (37, 53)), ('edsr', (19, 70))])
 def test_encoder_features_vs_oracle(dev, kind, hw):
     """HIP gen_feature (split-K implicit GEMM, concat-by-leading-dimension) vs the torch-CPU trunk."""
@@ -334,7 +388,7 @@ def test_encoder_features_vs_oracle(dev, kind, hw):
 # ------------------------------------------------------------------------------------------------
 # restorer end to end
 # ------------------------------------------------------------------------------------------------
-def _restorer(kind, scale, dev, test_cfg, mid=64, blocks=16, hidden=(256,) * 4):
+def _restorer(kind, scale, dev, test_cfg, mid=64, blocks=16, hidden=(256,) * 4, layers=8):
     from ciaosr_amd import CiaoSR, LocalImplicitSREDSR, LocalImplicitSRRDN
     mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=list(hidden))
     if kind == 'edsr':
@@ -343,8 +397,8 @@ def _restorer(kind, scale, dev, test_cfg, mid=64, blocks=16, hidden=(256,) * 4):
                    imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
     else:
         gen = dict(type=LocalImplicitSRRDN,
-                   encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
-                                upscale_factor=4, num_layers=8, channel_growth=64),
+                   encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=blocks,
+                                upscale_factor=4, num_layers=layers, channel_growth=64),
                    imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000)
     return CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
                   rgb_mean=(0.4488, 0.4371, 0.4040), rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
