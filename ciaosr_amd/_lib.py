@@ -75,6 +75,7 @@ SIGNATURES = {
     'ciaosr_patch_rows_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P]),
     'ciaosr_cs_attn_workspace_bytes': (_S, [_I, _I, _I]),
     'ciaosr_cs_attn_f32': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _P, _S, _P]),
+    'ciaosr_cs_attn_bf16': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _P, _S, _P]),
     'ciaosr_make_coord_cell_f32': (_I, [_P, _P, _I, _I, _P]),
     'ciaosr_fragment_floats': (_S, [_I, _I]),
     'ciaosr_pack_fragments_f32': (_I, [_P, _I, _I, _I, _P, _P]),

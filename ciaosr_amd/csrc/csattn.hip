@@ -24,6 +24,7 @@ struct CsaPlan {
     int H, W, C, Hp, Wp, L, Lld, Ch;
     size_t n_xp, n_E, n_M, n_x2, n_R, n_Qp, n_Kn, n_V, n_S, n_O, n_Y, n_Yp;
     size_t n_PE, n_Vp, n_Ov;   // composed fold+down form
+    int Lld8; size_t n_P16;    // bf16 mode: probabilities [HpWp][Lld8] bf16
 };
 
 static CsaPlan csa_plan(int H, int W, int C) {
@@ -48,6 +49,8 @@ static CsaPlan csa_plan(int H, int W, int C) {
     p.n_PE = (size_t)(p.Hp / 2 + 3) * (p.Wp / 2 + 3) * 9 * C;
     p.n_Vp = (size_t)p.L * 25 * C;
     p.n_Ov = (size_t)(p.Hp + p.Wp) * 4 * C + C;
+    p.Lld8 = (int)round_up(p.L, 8);
+    p.n_P16 = HW * p.Lld8 / 2 + 64;
     return p;
 }
 
@@ -58,12 +61,12 @@ using namespace ciaosr;
 extern "C" size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C) {
     const CsaPlan p = csa_plan(H, W, C);
     const size_t n = p.n_xp + p.n_E + p.n_M + p.n_x2 + p.n_R + p.n_Qp + p.n_Kn + p.n_V + p.n_S + p.n_O + p.n_Y + p.n_Yp +
-                     2 * p.n_PE + p.n_Vp + p.n_Ov;
+                     2 * p.n_PE + p.n_Vp + p.n_Ov + p.n_P16;
     return n * sizeof(float) + 24 * 256;
 }
 
-extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
-                                  float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream_) {
+static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w, float* out, int ld_out,
+                   void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
     CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
     const int C = w->channels;
     CIAOSR_CHECK_ARG(C >= 4 && (C & 3) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
@@ -86,6 +89,7 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
     float* Pc = ar.take<float>(p.n_PE);
     float* Vp = ar.take<float>(p.n_Vp);
     float* Ov = ar.take<float>(p.n_Ov);
+    unsigned short* P16 = reinterpret_cast<unsigned short*>(ar.take<float>(p.n_P16));
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
 
     const int HWp = p.Hp * p.Wp;
@@ -102,6 +106,30 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
     RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
     RUN(patch_rows(R, p.Ch, p.Hp / 2, p.Wp / 2, p.Ch, 3, 1, 1, p.Hp / 2, p.Wp / 2, Kn, 9 * p.Ch, 1, w->escape_nan, s,
                    "csa_patch_k"));
+    static const int b3_min_16 = [] { const char* e = getenv("CIAOSR_CSA_COMPOSED_MIN"); return e ? atoi(e) : 4096; }();
+    // bf16 mode (big maps, composed tail): Q.K^T and P.V' on the bf16 MFMA (gemm_bf16.hip); logits and softmax in fp32,
+    // probabilities rounded to bf16; 1x1 convolutions, the partial down-convolutions and the final gather stay fp32
+    const size_t qk16_bytes = ((size_t)HWp + p.L) * 9 * p.Ch * 2 + 512;
+    if (bf16 && w->w_down_masked && HWp >= b3_min_16 && (9 * p.Ch) % 8 == 0 && (p.Lld & 3) == 0 &&
+        qk16_bytes <= p.n_Y * sizeof(float) && (size_t)25 * C * p.Lld8 * 2 <= p.n_V * sizeof(float)) {
+        const int Hh = p.Hp / 2, Wh = p.Wp / 2, Kq = 9 * p.Ch;
+        unsigned short* Qb = reinterpret_cast<unsigned short*>(Y);
+        unsigned short* Kb = Qb + round_up((size_t)HWp * Kq, 128);
+        unsigned short* VpT = reinterpret_cast<unsigned short*>(V);
+        RUN(cast_rows_bf16(Qp, Kq, Qb, Kq, HWp, Kq, s));
+        RUN(cast_rows_bf16(Kn, Kq, Kb, Kq, p.L, Kq, s));
+        RUN(gemm_bf16_nt(Qb, Kq, Kb, Kq, S, p.Lld, false, HWp, p.L, Kq, w->softmax_scale, s, "csa_scores_bf16"));
+        RUN(softmax_rows_bf16(S, HWp, p.L, p.Lld, P16, p.Lld8, s));
+        RUN(patch_rows(E, C, p.Hp, p.Wp, C, 3, 2, 3, Hh + 3, Wh + 3, PE, 9 * C, 0, 0.f, s, "csa_patch_down"));
+        RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
+                     CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));
+        RUN(csa_gather_vprime_t_bf16(Pc, Hh, Wh, C, VpT, p.Lld8, s));
+        // all 25C columns for every row (the 9C edge-variant columns are only read for row 0 / column 0 pixels)
+        RUN(gemm_bf16_nt(P16, p.Lld8, VpT, p.Lld8, O, 25 * C, false, HWp, 25 * C, p.Lld8, 1.f, s, "csa_attn_v_bf16"));
+        RUN(csa_gather_out(O, O + 16 * C, O + 20 * C, O + 24 * C, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 25L * C, 25L * C,
+                           (long)p.Wp * 25 * C, s));
+        return CIAOSR_OK;
+    }
     RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
                  CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
     RUN(softmax_rows(S, HWp, p.L, p.Lld, s));
@@ -125,7 +153,7 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
                             CIAOSR_ACT_NONE, 0.f, Y, p.n_Y, s, "csa_attn_v_edge"));
         RUN(gemm_f32_splitk(S, p.Lld, Vp + 24 * C, 25 * C, true, Otl, C, nullptr, 1, C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, Y,
                             p.n_Y, s, "csa_attn_v_edge"));
-        RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, s));
+        RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 16L * C, 4L * C, 4L * C, s));
         return CIAOSR_OK;
     }
     RUN(patch_rows(E, C, p.Hp, p.Wp, C, 6, 2, 2, p.Hp / 2, p.Wp / 2, V, 36 * C, 0, 0.f, s, "csa_patch_v"));
@@ -138,4 +166,14 @@ extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int
                  CIAOSR_ACT_NONE, 0.f, s, "csa_down"));
 #undef RUN
     return CIAOSR_OK;
+}
+
+extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                                  float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, workspace, workspace_bytes, stream, false);
+}
+
+extern "C" int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                                   float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, workspace, workspace_bytes, stream, true);
 }

@@ -1,0 +1,253 @@
+// bf16-MFMA NT GEMM (precision mode "bf16" of CrossScaleAttention's two big contractions):
+//   C[M][N] = alpha * A[M][K] . B[N][K]^T,  A and B bf16 in memory, fp32 accumulation, C fp32 or bf16.
+// Used for the correlation scores Q.K^T (arch_csnln.py:497-499, K = 9C/2) and the attention-weighted patch sum
+// P.V' (arch_csnln.py:511 in the composed form of patch_ops.hip, K = L) when the host asks for bf16.
+//
+// v_mfma_f32_32x32x16_bf16 is 16x the fp32 MFMA rate, so the tile is sized for the operand streams instead:
+// workgroup tile 256 x 128 x 64 (one per CU, 108 KB of LDS double-buffered), 4 waves in a 2 x 2 grid, each wave a
+// 128 x 64 sub-tile = 4 x 2 MFMA tiles (128 accumulator registers): per 16-deep k-step a wave reads 6 KB from LDS
+// for 8 MFMAs (24 B/clk/SIMD, under the 128 B/clk/CU LDS limit) and the workgroup fetches 48 KB from L2/HBM per
+// 4.2 MFLOP stage (12 B/clk at the full MFMA rate).  Rows are padded to 144 B in LDS (conflict-free ds_read_b128).
+// Swapped MFMA operands (B rows = A operand, A rows = B operand): a lane owns one output row and 4 consecutive
+// columns per accumulator quad, so the epilogue stores 16 B (fp32) / 8 B (bf16) pieces.
+// Out-of-range rows / k-chunks are buffer loads with an out-of-range offset (return 0, no branches).
+#include "ops.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GM = 256, GN = 128, GK = 64;
+constexpr int GRS = 144;                                  // LDS row stride in bytes (64 bf16 + 16 B pad)
+constexpr int GA_T = GM * GRS, GB_T = GN * GRS;           // bytes per stage
+constexpr size_t kGemm16Lds = 2 * (size_t)(GA_T + GB_T);  // 110 592 B
+constexpr unsigned kOob16 = 0xFFFFFFF0u;
+
+struct Gemm16P {
+    const unsigned short* A; int lda;
+    const unsigned short* B; int ldb;
+    unsigned a_bytes, b_bytes;
+    void* C; int ldc; int c_bf16;
+    int M, N, K;
+    float alpha;
+    int tiles_n, n_wg;
+};
+
+__device__ __forceinline__ unsigned short f2bf_g(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(Gemm16P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
+    unsigned char* As = lds16;                    // [2][GM][GRS]
+    unsigned char* Bs = lds16 + 2 * GA_T;         // [2][GN][GRS]
+
+    // XCD-aware remap (as gemm_f32.hip): each XCD walks a contiguous run of tiles sharing A row panels
+    const int bid = blockIdx.x;
+    const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int m0 = (lid / p.tiles_n) * GM, n0 = (lid % p.tiles_n) * GN;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1, li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.B), 0, p.b_bytes, 0x00020000);
+
+    // staging: 16-byte chunk c = t + 256 s -> row c >> 3, k-part c & 7
+    const int part = t & 7, row0 = t >> 3;        // rows row0 + 32 s
+    unsigned a_off[8], b_off[4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int gm = m0 + row0 + 32 * s;
+        a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 2u + (unsigned)part * 16u : kOob16;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int gn = n0 + row0 + 32 * s;
+        b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u : kOob16;
+    }
+    i32x4 ra[8], rb[4];
+    auto load_stage = [&](int kt) {
+        const int k0 = kt * GK;
+        const bool kok = k0 + part * 8 < p.K;     // K % 8 == 0: a chunk is entirely in or out
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            ra[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (kok && a_off[s] != kOob16) ? (int)(a_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            rb[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (kok && b_off[s] != kOob16) ? (int)(b_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) *reinterpret_cast<i32x4*>(As + buf * GA_T + (row0 + 32 * s) * GRS + part * 16) = ra[s];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<i32x4*>(Bs + buf * GB_T + (row0 + 32 * s) * GRS + part * 16) = rb[s];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    const int nk = (p.K + GK - 1) / GK;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_stage(kt + 1);
+        const unsigned char* a = As + cur * GA_T + (128 * wm + li) * GRS + lh * 16;
+        const unsigned char* b = Bs + cur * GB_T + (64 * wn + li) * GRS + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 fb[2], fa[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + ks * 32));
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + mt * 32 * GRS + ks * 32));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li, columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 128 * wm + 32 * mt + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
+                if (n >= p.N) continue;
+                const float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
+                const float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
+                if (n + 3 >= p.N) {                                        // ragged last columns
+                    const float v[4] = {v0, v1, v2, v3};
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                        if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = f2bf_g(v[e]);
+                        else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = v[e];
+                    }
+                } else if (p.c_bf16)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
+                        make_uint2((unsigned)f2bf_g(v0) | ((unsigned)f2bf_g(v1) << 16), (unsigned)f2bf_g(v2) | ((unsigned)f2bf_g(v3) << 16));
+                else
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
+            }
+    }
+}
+
+// fp32 rows -> bf16 rows (first `cols` columns, cols % 4 == 0); pad columns [cols, ld_dst) are zeroed
+__global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int ld_src, unsigned short* __restrict__ dst, int ld_dst,
+                                      long rows, int cols) {
+    const int c4n = ld_dst >> 2;
+    const long n = rows * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        *reinterpret_cast<uint2*>(dst + r * ld_dst + c) =
+            make_uint2((unsigned)f2bf_g(v.x) | ((unsigned)f2bf_g(v.y) << 16), (unsigned)f2bf_g(v.z) | ((unsigned)f2bf_g(v.w) << 16));
+    }
+}
+
+// row softmax of fp32 logits S [rows][ld] (first L columns) -> bf16 probabilities P [rows][ldp]; pad columns zeroed
+__global__ __launch_bounds__(256) void softmax_rows_bf16_kernel(const float* __restrict__ S, long rows, int L, int ld,
+                                                                unsigned short* __restrict__ P, int ldp) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* s = reinterpret_cast<const float4*>(S + (size_t)row * ld);
+    const int n4 = ldp >> 2;
+    float m = -INFINITY;
+    for (int t = lane; t < n4; t += 64) {
+        const int c = 4 * t;
+        if (c >= L) break;
+        const float4 v = s[t];
+        m = fmaxf(m, v.x);
+        if (c + 1 < L) m = fmaxf(m, v.y);
+        if (c + 2 < L) m = fmaxf(m, v.z);
+        if (c + 3 < L) m = fmaxf(m, v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    float sum = 0.f;
+    for (int t = lane; t < n4; t += 64) {
+        const int c = 4 * t;
+        if (c >= L) break;
+        const float4 v = s[t];
+        sum += expf(v.x - m);
+        if (c + 1 < L) sum += expf(v.y - m);
+        if (c + 2 < L) sum += expf(v.z - m);
+        if (c + 3 < L) sum += expf(v.w - m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    uint2* po = reinterpret_cast<uint2*>(P + (size_t)row * ldp);
+    for (int t = lane; t < n4; t += 64) {
+        const int c = 4 * t;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < L) {
+            const float4 x = s[t];
+            v.x = expf(x.x - m) / sum;
+            v.y = c + 1 < L ? expf(x.y - m) / sum : 0.f;
+            v.z = c + 2 < L ? expf(x.z - m) / sum : 0.f;
+            v.w = c + 3 < L ? expf(x.w - m) / sum : 0.f;
+        }
+        po[t] = make_uint2((unsigned)f2bf_g(v.x) | ((unsigned)f2bf_g(v.y) << 16), (unsigned)f2bf_g(v.z) | ((unsigned)f2bf_g(v.w) << 16));
+    }
+}
+
+int gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,
+                 int K, float alpha, hipStream_t s, const char* tag) {
+    if (M <= 0 || N <= 0) return CIAOSR_OK;
+    CIAOSR_CHECK_ARG(A && B && C && K > 0 && (K & 7) == 0);
+    CIAOSR_CHECK_ARG((lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 3) == 0 && aligned16(A) && aligned16(B) && aligned16(C));
+    Gemm16P p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.c_bf16 = c_bf16 ? 1 : 0;
+    p.M = M; p.N = N; p.K = K; p.alpha = alpha;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldb + K) * 2;
+    CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    p.tiles_n = ceil_div(N, GN);
+    p.n_wg = ceil_div(M, GM) * p.tiles_n;
+    static bool attr = false;
+    if (!attr) { allow_big_lds(gemm_bf16_kernel, kGemm16Lds); attr = true; }
+    ProfScope prof(tag ? tag : "gemm_bf16", s);
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    return launch_status("gemm_bf16");
+}
+
+int cast_rows_bf16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s) {
+    CIAOSR_CHECK_ARG(src && dst && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && (cols & 3) == 0 && cols <= ld_dst);
+    ProfScope prof("cast_rows_bf16", s);
+    const long n = rows * (ld_dst >> 2);
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3(grid > 8192 ? 8192 : grid), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+    return launch_status("cast_rows_bf16");
+}
+
+int softmax_rows_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s) {
+    CIAOSR_CHECK_ARG(S && P && (ld & 3) == 0 && (ldp & 3) == 0 && ldp <= ld && L <= ldp);
+    ProfScope prof("softmax_rows", s);
+    hipLaunchKernelGGL(softmax_rows_bf16_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, P, ldp);
+    return launch_status("softmax_rows_bf16");
+}
+
+}  // namespace ciaosr

@@ -166,7 +166,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     // unfold rows U[:, :9C] (net:132-136) and the non-local map into U[:, 9C:] (net:134-137)
     RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
     if (csattn)
-        RUN(ciaosr_cs_attn_f32(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, csa_ws, p.csa_bytes, stream_));
+        RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, csa_ws, p.csa_bytes, stream_));
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     RUN(gemm_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], false, Tk, p.wk0, w->k.bias[0], p.HW, p.wk0, p.D, 1.f,
                  CIAOSR_ACT_NONE, 0.f, s, "head_table"));

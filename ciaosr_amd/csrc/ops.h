@@ -63,7 +63,13 @@ int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s);
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s);
 int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStream_t s);
 int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const float* Otl, const float* bd, int H, int W,
-                   int Hp, int Wp, int C, float* out, int ld_out, hipStream_t s);
+                   int Hp, int Wp, int C, float* out, int ld_out, long ld_main, long ld_top, long ld_left, hipStream_t s);
+int csa_gather_vprime_t_bf16(const float* Pc, int Hh, int Wh, int C, unsigned short* VpT, int ldt, hipStream_t s);
+// gemm_bf16.hip
+int gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,
+                 int K, float alpha, hipStream_t s, const char* tag);
+int cast_rows_bf16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s);
+int softmax_rows_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s);
 // head_ops.hip
 int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
                  int* q_idx, int* k_idx, float* rel, hipStream_t s);

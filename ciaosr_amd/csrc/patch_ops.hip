@@ -244,10 +244,36 @@ __global__ void csa_gather_vprime_kernel(const float* __restrict__ Pc, int Hh, i
     }
 }
 
+// bf16 mode: the same matrix transposed, VpT[blk*C + co][l] (bf16, row stride ldt >= L, pad columns zeroed), the
+// [N][K] operand of the bf16 NT GEMM (gemm_bf16.hip)
+__global__ void csa_gather_vprime_t_bf16_kernel(const float* __restrict__ Pc, int Hh, int Wh, int C, unsigned short* __restrict__ VpT,
+                                                int ldt) {
+    const long n = (long)25 * C * ldt;
+    const int We = Wh + 3, L = Hh * Wh;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int l = (int)(idx % ldt);
+        const int col = (int)(idx / ldt);
+        float v = 0.f;
+        if (l < L) {
+            const int blk = col / C, co = col - blk * C;
+            const int ly = l / Wh, lx = l - ly * Wh;
+            int dy, dx, r, sct;
+            if (blk < 16) { dy = blk / 4 - 2; dx = blk % 4 - 2; r = b3_subset(dy); sct = b3_subset(dx); }
+            else if (blk < 20) { dy = 0; dx = blk - 16 - 2; r = 2; sct = b3_subset(dx); }
+            else if (blk < 24) { dy = blk - 20 - 2; dx = 0; r = b3_subset(dy); sct = 2; }
+            else { dy = 0; dx = 0; r = 2; sct = 2; }
+            v = Pc[((size_t)(ly - dy + 1) * We + (lx - dx + 1)) * (9 * C) + (size_t)(3 * r + sct) * C + co];
+        }
+        unsigned u = __float_as_uint(v);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        VpT[idx] = (unsigned short)(u >> 16);
+    }
+}
+
 // out[(y',x')][co] = (bd[co] + sum over the 16 offsets of O'[(y'+dy, x'+dx)][blk*C + co] (variants on row/column 0)) / 6
 __global__ void csa_gather_out_kernel(const float* __restrict__ Op, const float* __restrict__ Otop, const float* __restrict__ Oleft,
                                       const float* __restrict__ Otl, const float* __restrict__ bd, int H, int W, int Hp, int Wp,
-                                      int C, float* __restrict__ out, int ld_out) {
+                                      int C, float* __restrict__ out, int ld_out, long ld_main, long ld_top, long ld_left) {
     const int c4n = C >> 2;
     const long n = (long)H * W * c4n;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -263,9 +289,9 @@ __global__ void csa_gather_out_kernel(const float* __restrict__ Op, const float*
                 if (px < 0 || px >= Wp) continue;
                 const float* src;
                 if (dy == 0 && y == 0 && dx == 0 && x == 0) src = Otl + 4 * c4;
-                else if (dy == 0 && y == 0) src = Otop + ((size_t)px * 4 + (dx + 2)) * C + 4 * c4;          // py == 0
-                else if (dx == 0 && x == 0) src = Oleft + ((size_t)py * 4 + (dy + 2)) * C + 4 * c4;         // px == 0
-                else src = Op + ((size_t)py * Wp + px) * (16 * C) + (size_t)((dy + 2) * 4 + (dx + 2)) * C + 4 * c4;
+                else if (dy == 0 && y == 0) src = Otop + (size_t)px * ld_top + (size_t)(dx + 2) * C + 4 * c4;   // py == 0
+                else if (dx == 0 && x == 0) src = Oleft + (size_t)py * ld_left + (size_t)(dy + 2) * C + 4 * c4; // px == 0
+                else src = Op + ((size_t)py * Wp + px) * ld_main + (size_t)((dy + 2) * 4 + (dx + 2)) * C + 4 * c4;
                 const float4 v = *reinterpret_cast<const float4*>(src);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
@@ -377,11 +403,17 @@ int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStre
 }
 
 int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const float* Otl, const float* bd, int H, int W,
-                   int Hp, int Wp, int C, float* out, int ld_out, hipStream_t s) {
+                   int Hp, int Wp, int C, float* out, int ld_out, long ld_main, long ld_top, long ld_left, hipStream_t s) {
     ProfScope prof("csa_gather_out", s);
     hipLaunchKernelGGL(csa_gather_out_kernel, dim3(ew_grid((long)H * W * C / 4)), dim3(256), 0, s, Op, Otop, Oleft, Otl, bd, H,
-                       W, Hp, Wp, C, out, ld_out);
+                       W, Hp, Wp, C, out, ld_out, ld_main, ld_top, ld_left);
     return launch_status("csa_gather_out");
+}
+
+int csa_gather_vprime_t_bf16(const float* Pc, int Hh, int Wh, int C, unsigned short* VpT, int ldt, hipStream_t s) {
+    ProfScope prof("csa_gather_vprime", s);
+    hipLaunchKernelGGL(csa_gather_vprime_t_bf16_kernel, dim3(ew_grid((long)25 * C * ldt)), dim3(256), 0, s, Pc, Hh, Wh, C, VpT, ldt);
+    return launch_status("csa_gather_vprime_t");
 }
 
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s) {

@@ -97,7 +97,7 @@ class CrossScaleAttention(nn.Module):
         for b in range(B):
             f = hip_ops.nchw_to_hwc(x[b])
             o = torch.empty(H, W, Cc, dtype=torch.float32, device=x.device)
-            _lib.call('ciaosr_cs_attn_f32', hip_ops.ptr(f), Cc, H, W, C.byref(st), hip_ops.ptr(o), Cc,
+            _lib.call('ciaosr_cs_attn_bf16' if hip_ops.precision() == 'bf16' else 'ciaosr_cs_attn_f32', hip_ops.ptr(f), Cc, H, W, C.byref(st), hip_ops.ptr(o), Cc,
                       hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
             out[b] = hip_ops.hwc_to_nchw(o)
         return out

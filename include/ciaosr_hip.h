@@ -102,6 +102,11 @@ size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C);
  * (lets the caller write straight into the tail columns of the unfold rows, net:137). */
 int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
                        float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream);
+/* Same, with the two big contractions (correlation scores csa:497-500 and the attention-weighted patch sum csa:511)
+ * on the bf16 MFMA when the composed tail applies (>= 4096 LR pixels, w_down_masked given): inputs rounded to bf16,
+ * fp32 accumulation, logits and softmax in fp32, probabilities rounded to bf16.  Smaller maps: identical to _f32. */
+int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                        float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- head ---------------------------------------------------------------------------------- */
 typedef struct ciaosr_mlp {

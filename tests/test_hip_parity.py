@@ -291,6 +291,61 @@ def test_gather_rows_matches_reference_assembly(dev):
     assert torch.equal(inp_k[:, 9 * C + 2:], scale)
 
 
+def test_e2e_bf16_precision_mode_psnr(dev, monkeypatch):
+    """Whole restore() with test_cfg.precision='bf16' (bf16 trunk dense layers + bf16 cs_attn contractions + bf16
+    fused head) against the fp32 path: RDN x4 on a 96x96 LR image (9216 LR pixels: every bf16 kernel engages)."""
+    import math
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    monkeypatch.setenv('CIAOSR_DENSE_BF16_MIN_TILES', '1')
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
+    seeded_init_(model, seed=0, gain=1.7)             # network term rms 0.07 next to the bilinear residual, nothing saturates
+    model = model.to(dev)
+    lq, _ = synthetic_pair(96, 96, 4)
+    lq = lq.to(dev)
+    ref = model.restore(lq)
+    model.test_cfg['precision'] = 'bf16'
+    try:
+        with hip_ops.profile():
+            got = model.restore(lq)
+        prof = hip_ops.profile.results()
+    finally:
+        model.test_cfg.pop('precision')
+    for tag in ('enc_dense_bf16', 'csa_attn_v_bf16', 'csa_scores_bf16', 'head_kv_fused_bf16', 'head_decode_fused_bf16'):
+        assert tag in prof, (tag, sorted(prof))
+    assert hip_ops.precision() == 'fp32'
+    err = (got - ref).abs()
+    psnr = 10 * math.log10(1.0 / max((err ** 2).mean().item(), 1e-20))
+    print(f'bf16 e2e: max|d| {err.max().item():.3e}, PSNR vs fp32 output {psnr:.1f} dB')
+    assert psnr > 55.0 and err.max().item() < 0.03          # measured: 64.1 dB, 7.6e-3 (0.9 % rms of the network term)
+
+
+def test_cs_attn_bf16_mode_vs_fp32(dev, monkeypatch):
+    """ciaosr_cs_attn_bf16 (scores and P.V' on the bf16 MFMA, gemm_bf16.hip; odd map size -> reflect pad, ragged GEMM
+    tiles) against the fp32 path on the same input; PSNR-gated like the other bf16 kernels."""
+    import math
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.nonlocal_attn import CrossScaleAttention
+    from ciaosr_amd.init_utils import seeded_init_
+    att = CrossScaleAttention(channel=64, scale=[2]).to(dev).eval()
+    seeded_init_(att, seed=31, gain=1.5)
+    x = randn((1, 64, 67, 70), 32).to(dev)             # Hp x Wp = 68 x 70 = 4760 >= 4096: composed tail
+    ref = att(x)
+    try:
+        hip_ops.set_precision('bf16')
+        with hip_ops.profile():
+            got = att(x)
+        prof = hip_ops.profile.results()
+        assert 'csa_attn_v_bf16' in prof and 'csa_scores_bf16' in prof, sorted(prof)
+    finally:
+        hip_ops.set_precision('fp32')
+    err = (got - ref).abs()
+    scale = ref.abs().max().item()
+    psnr = 10 * math.log10(scale ** 2 / max((err ** 2).mean().item(), 1e-20))
+    print(f'bf16 cs_attn: max|d| {err.max().item():.3e} (scale {scale:.3f}), PSNR vs fp32 {psnr:.1f} dB')
+    assert err.max().item() < 0.05 * scale and psnr > 45.0
+
+
 def test_staged_local_attention_kernel(dev):
     """K4 alone: ciaosr_local_attention_f32 against a direct torch evaluation of net:211-216."""
     from ciaosr_amd import hip_ops
