@@ -270,7 +270,7 @@ def main():
                 roof['other_kernels'] = others
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
                 # WRITE_SIZE, tools/pmc_summary.py); offline evidence, null when the summary is absent
-                tag2fn = {'enc_dense_scatter': 'void ciaosr::conv_gemm_kernel<32, 32>', 'head_kv_fused': 'ciaosr::head_kv_fused_kernel',
+                tag2fn = {'enc_dense_scatter': 'ciaosr::conv3x3_halo_kernel', 'head_kv_fused': 'ciaosr::head_kv_fused_kernel',
                           'head_decode_fused': 'ciaosr::head_decode_fused_kernel'}
                 pmc_path = os.path.join(REPO, 'profiles', 'r1_c2_pmc_hbm_traffic.json')
                 if args.workload == 'c2' and os.path.exists(pmc_path) and dominant in tag2fn:
@@ -278,7 +278,8 @@ def main():
                     if pmc:
                         roof['traffic'] = pmc['hbm_bytes_per_launch']
                         roof['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1_c2_pmc_hbm_traffic.json'
-                        roof['algorithmic_bytes_per_launch'] = round(HW * 4.0 * (64 + 9 * 64 * 288 / HW + 2 * 288))
+                        if dominant == 'enc_dense_scatter':   # input group + stacked weights + read-modify-write of the running sums (mean N = 288)
+                            roof['algorithmic_bytes_per_launch'] = round(HW * 4.0 * (64 + 9 * 64 * 288 / HW + 2 * 288))
         line = {
             'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
