@@ -297,6 +297,28 @@ def main():
             'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
                 prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
         }
+        if world == 1 and args.precision == 'fp32' and roof is not None:
+            # the HBM-bound kernels of the staged route (north star: >= 40 % of the HBM roofline on the local-attention
+            # kernel K4), measured on the same workload right after the timed region: one staged step, HIP events
+            try:
+                hip_ops.set_head_mode(1)
+                step()
+                with hip_ops.profile():
+                    step()
+                    torch.cuda.synchronize(dev)
+                st = hip_ops.profile.results()
+            finally:
+                hip_ops.set_head_mode(0)
+            tile_lr = lr if args.workload == 'c2' else 192
+            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117}[args.workload]
+            hb = {}
+            for tag in ('local_attention', 'head_rows'):
+                wk = kernel_work(tag, (tile_lr * scale) ** 2, tile_lr * tile_lr)
+                if tag in st and wk:
+                    gbs = wk[0] * n_tiles / (st[tag]['total_ms'] * 1e-3) / 1e9
+                    hb[tag] = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                   frac=round(gbs / PEAK_HBM_GBS, 4), ms_per_step=round(st[tag]['total_ms'], 4))
+            roof['staged_path_hbm_kernels'] = hb
         if world == 1 and not args.no_cpu_baseline and args.workload == 'c2':
             line['cpu_baseline'] = cpu_baseline(scale)
         print(json.dumps(line), flush=True)

@@ -15,6 +15,8 @@
 
 namespace ciaosr {
 
+bool softmax_rows_reg_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s);   // patch_ops.hip
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -246,6 +248,7 @@ int cast_rows_bf16(const float* src, int ld_src, unsigned short* dst, int ld_dst
 int softmax_rows_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s) {
     CIAOSR_CHECK_ARG(S && P && (ld & 3) == 0 && (ldp & 3) == 0 && ldp <= ld && L <= ldp);
     ProfScope prof("softmax_rows", s);
+    if (softmax_rows_reg_bf16(S, rows, L, ld, P, ldp, s)) return launch_status("softmax_rows_reg_bf16");
     hipLaunchKernelGGL(softmax_rows_bf16_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, P, ldp);
     return launch_status("softmax_rows_bf16");
 }

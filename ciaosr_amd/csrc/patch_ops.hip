@@ -180,6 +180,51 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
     }
 }
 
+// Single-pass variant for rows of up to 64 x SMV float4: the whole row lives in registers (one HBM read, one write).
+// OUT16: write bf16 probabilities to P (row stride ldp) instead of fp32 in place.
+constexpr int SMV = 36;          // 36 float4 per lane = rows of up to 9216 floats (the 192x192 tile's L)
+template <bool OUT16>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict__ S, long rows, int L, int ld,
+                                                               unsigned short* __restrict__ P, int ldp) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float4* s = reinterpret_cast<float4*>(S + (size_t)row * ld);
+    const int n4 = (OUT16 ? ldp : ld) >> 2;
+    float4 v[SMV];
+#pragma unroll
+    for (int i = 0; i < SMV; ++i) {
+        const int t = lane + 64 * i, c = 4 * t;
+        v[i] = (t < n4 && c < L) ? s[t] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (c + 1 >= L) v[i].y = -INFINITY;
+        if (c + 2 >= L) v[i].z = -INFINITY;
+        if (c + 3 >= L) v[i].w = -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SMV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    m = wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMV; ++i) {                      // exp(-inf) = 0 for the masked tail
+        v[i].x = expf(v[i].x - m); v[i].y = expf(v[i].y - m); v[i].z = expf(v[i].z - m); v[i].w = expf(v[i].w - m);
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    sum = wave_sum(sum);
+#pragma unroll
+    for (int i = 0; i < SMV; ++i) {
+        const int t = lane + 64 * i;
+        if (t >= n4) continue;
+        const float4 o = make_float4(v[i].x / sum, v[i].y / sum, v[i].z / sum, v[i].w / sum);
+        if (OUT16) {
+            auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };
+            reinterpret_cast<uint2*>(P + (size_t)row * ldp)[t] = make_uint2(bf(o.x) | (bf(o.y) << 16), bf(o.z) | (bf(o.w) << 16));
+        } else {
+            s[t] = o;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // fold: gather form of F.conv_transpose2d(P, V, stride=2, padding=2) (arch_csnln.py:511).
 // O[(y,x)][(i*6+j)*C + c] holds the 6x6xC patch weighted for LR pixel (y,x); output pixel (u,v) of
@@ -392,8 +437,19 @@ int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int 
 
 int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s) {
     ProfScope prof("softmax_rows", s);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld);
+    if ((ld >> 2) <= 64 * SMV && (ld >> 2) > 64 * 8)       // long rows that still fit the register file: one pass
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<false>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, nullptr, 0);
+    else
+        hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld);
     return launch_status("softmax_rows");
+}
+
+// fp32 logits -> bf16 probabilities, single pass; false when the row does not fit the register file
+bool softmax_rows_reg_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s) {
+    if ((ldp >> 2) > 64 * SMV) return false;
+    hipLaunchKernelGGL(softmax_rows_reg_kernel<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, const_cast<float*>(S), rows, L, ld,
+                       P, ldp);
+    return true;
 }
 
 int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStream_t s) {
