@@ -57,6 +57,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         # (imnet_k's output layer is folded exactly into the 9-rows-per-LR-pixel logit table: 'head_logit_table')
         'head_kv_fused': (2.0 * R * (6 * hidden * hidden + hidden * Dv), 'flop'),
         'head_logit_table': (2.0 * 9 * HW * D * hidden, 'flop'),
+        'head_logit_table_bf16': (2.0 * 9 * HW * D * hidden, 'flop16'),
         'head_decode_fused': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop'),
         'head_kv_fused_bf16': (2.0 * R * (6 * hidden * hidden + hidden * Dv), 'flop16'),
         'head_decode_fused_bf16': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop16'),

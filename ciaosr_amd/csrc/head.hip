@@ -45,6 +45,7 @@ static size_t head_ws_bytes(const HeadPlan& p) {
     n += (size_t)p.qc * p.Dv;                 // Z
     n += (size_t)p.qc + R;                    // q_idx, k_idx (ints, same size as float)
     n += (size_t)p.HW * 9 * kLdG + (size_t)kQkChunk * p.D;   // logit table + one chunk of its GEMM rows
+    n += (size_t)128 * p.D + 64;                             // bf16 mode: transposed bf16 copy of imnet_k's output layer
     return n * sizeof(float) + p.csa_bytes + 32 * 256;
 }
 
@@ -158,6 +159,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     int* k_idx = ar.take<int>(R);
     float* G = ar.take<float>((size_t)p.HW * 9 * kLdG);
     float* QK = ar.take<float>((size_t)kQkChunk * p.D);
+    unsigned short* W5T = reinterpret_cast<unsigned short*>(ar.take<float>((size_t)128 * p.D + 64));
     char* csa_ws = ar.take<char>(p.csa_bytes);
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
 
@@ -182,9 +184,16 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     if (use_table) {
         const int last = w->k.n_layers - 1;
         const long total = (long)p.HW * 9;
+        const bool table16 = bf16 && (p.D & 7) == 0;   // bf16 mode: the table GEMM on the bf16 MFMA (fp32 table out)
+        if (table16) RUN(transpose_cast_bf16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, s));
         for (long r0 = 0; r0 < total; r0 += kQkChunk) {
             const int nr = (int)((total - r0) < kQkChunk ? (total - r0) : kQkChunk);
-            RUN(qk_rows(U, p.Dv, p.D, H, W, r0, nr, w->k.bias[last], QK, G, kLdG, s));
+            RUN(qk_rows(U, p.Dv, p.D, H, W, r0, nr, w->k.bias[last], QK, G, kLdG, table16, s));
+            if (table16) {
+                RUN(gemm_bf16_nt(reinterpret_cast<const unsigned short*>(QK), p.D, W5T, p.D, G + (size_t)r0 * kLdG, kLdG, false, nr,
+                                 256, p.D, 1.f, s, "head_logit_table_bf16"));
+                continue;
+            }
             // G[r][n] = sum_d QK[r][d] * W5k[d][n]: the Linear weight [D][256] is the [K][N] operand as stored
             RUN(gemm_f32(QK, p.D, w->k.weight[last], w->k.ld[last], true, G + (size_t)r0 * kLdG, kLdG, nullptr, nr, 256, p.D,
                          1.f, CIAOSR_ACT_NONE, 0.f, s, "head_logit_table"));

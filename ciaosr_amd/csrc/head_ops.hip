@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
 //   pixel one of the 3x3 neighbours of the query pixel: 9 rows per LR pixel instead of one 576-wide output
 //   layer per (query, sample) row.  Row r = p*9 + (oy+1)*3 + (ox+1): A[r][d] = U[p][d] * U[p+o][d].
 // ---------------------------------------------------------------------------------------------
+template <bool B16>       // B16: rows written as bf16 (operand of the bf16 GEMM) instead of fp32
 __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ U, int ldu, int D, int H, int W, long row0,
                                                       int nrows, const float* __restrict__ b5, float* __restrict__ A,
                                                       float* __restrict__ G, int ldg) {
@@ -267,9 +268,14 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
     const int y = pix / W, x = pix - y * W;
     const int ky = y + o / 3 - 1, kx = x + o % 3 - 1;
     float4* a = reinterpret_cast<float4*>(A + (size_t)rl * D);
+    uint2* a16 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(A) + (size_t)rl * D);
+    auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };
     float c = 0.f;
     if (ky < 0 || ky >= H || kx < 0 || kx >= W) {          // this (query pixel, key pixel) pair cannot occur
-        for (int t = lane; t < (D >> 2); t += 64) a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int t = lane; t < (D >> 2); t += 64) {
+            if (B16) a16[t] = make_uint2(0u, 0u);
+            else a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     } else {
         const float4* q = reinterpret_cast<const float4*>(U + (size_t)pix * ldu);
         const float4* k = reinterpret_cast<const float4*>(U + ((size_t)ky * W + kx) * ldu);
@@ -277,7 +283,8 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
         for (int t = lane; t < (D >> 2); t += 64) {
             const float4 qv = q[t], kv = k[t], bv = b[t];
             const float4 v = make_float4(qv.x * kv.x, qv.y * kv.y, qv.z * kv.z, qv.w * kv.w);
-            a[t] = v;
+            if (B16) a16[t] = make_uint2(bf(v.x) | (bf(v.y) << 16), bf(v.z) | (bf(v.w) << 16));
+            else a[t] = v;
             c += v.x * bv.x + v.y * bv.y + v.z * bv.z + v.w * bv.w;
         }
         c = wsum(c);
@@ -315,11 +322,33 @@ int head_rows(const HeadRowsP& p, hipStream_t s) {
 }
 
 int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
-            int ldg, hipStream_t s) {
+            int ldg, bool rows_bf16, hipStream_t s) {
     ProfScope prof("head_qk_rows", s);
-    hipLaunchKernelGGL(qk_rows_kernel, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out, A,
-                       G, ldg);
+    if (rows_bf16)
+        hipLaunchKernelGGL(qk_rows_kernel<true>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
+                           A, G, ldg);
+    else
+        hipLaunchKernelGGL(qk_rows_kernel<false>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
+                           A, G, ldg);
     return launch_status("qk_rows");
+}
+
+// out[n][k] (bf16, row stride K) = W[k][n] (fp32, row stride ld): the [N][K] operand of the bf16 NT GEMM
+__global__ void transpose_cast_bf16_kernel(const float* __restrict__ W, int ld, int K, int N, unsigned short* __restrict__ out) {
+    const long n_el = (long)K * N;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_el; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K), n = (int)(i / K);
+        unsigned u = __float_as_uint(W[(size_t)k * ld + n]);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        out[i] = (unsigned short)(u >> 16);
+    }
+}
+
+int transpose_cast_bf16(const float* W, int ld, int K, int N, unsigned short* out, hipStream_t s) {
+    ProfScope prof("transpose_cast_bf16", s);
+    const long n_el = (long)K * N;
+    hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3((int)((n_el + 255) / 256)), dim3(256), 0, s, W, ld, K, N, out);
+    return launch_status("transpose_cast_bf16");
 }
 
 int local_attention(const LocalAttnP& p, hipStream_t s) {

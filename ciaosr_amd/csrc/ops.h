@@ -75,7 +75,8 @@ int head_indices(const float* coord, const float* cell, long q0, int nq, int chu
                  int* q_idx, int* k_idx, float* rel, hipStream_t s);
 int head_rows(const HeadRowsP& p, hipStream_t s);
 int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
-            int ldg, hipStream_t s);
+            int ldg, bool rows_bf16, hipStream_t s);
+int transpose_cast_bf16(const float* W, int ld, int K, int N, unsigned short* out, hipStream_t s);
 int local_attention(const LocalAttnP& p, hipStream_t s);
 int decode_residual(const DecodeP& p, hipStream_t s);
 
