@@ -21,6 +21,7 @@
 // Swapped operands (weights = A, activations = B): a lane owns one pixel and 4x4 consecutive channels.
 #include <cstdlib>
 
+#include "bf16_util.h"
 #include "ops.h"
 
 namespace ciaosr {
@@ -178,8 +179,7 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
                 const size_t pix = (size_t)y * p.W + x;
                 *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
                 *reinterpret_cast<uint2*>(p.xb_out + pix * p.ldxb + p.col_out + co) =
-                    make_uint2((unsigned)f2bf_d(v.x) | ((unsigned)f2bf_d(v.y) << 16),
-                               (unsigned)f2bf_d(v.z) | ((unsigned)f2bf_d(v.w) << 16));
+                    pack_bf16x4(v.x, v.y, v.z, v.w);
             }
         }
         __syncthreads();
@@ -195,7 +195,7 @@ __global__ void cast_group_bf16_kernel(const float* __restrict__ X, int ldx, uns
         const int c = (int)(i & 15) * 4;
         const float4 v = *reinterpret_cast<const float4*>(X + pix * ldx + col + c);
         *reinterpret_cast<uint2*>(Xb + pix * ldxb + col + c) =
-            make_uint2((unsigned)f2bf_d(v.x) | ((unsigned)f2bf_d(v.y) << 16), (unsigned)f2bf_d(v.z) | ((unsigned)f2bf_d(v.w) << 16));
+            pack_bf16x4(v.x, v.y, v.z, v.w);
     }
 }
 

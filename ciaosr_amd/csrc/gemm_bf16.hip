@@ -11,6 +11,7 @@
 // Swapped MFMA operands (B rows = A operand, A rows = B operand): a lane owns one output row and 4 consecutive
 // columns per accumulator quad, so the epilogue stores 16 B (fp32) / 8 B (bf16) pieces.
 // Out-of-range rows / k-chunks are buffer loads with an out-of-range offset (return 0, no branches).
+#include "bf16_util.h"
 #include "ops.h"
 
 namespace ciaosr {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Gemm16P p) {
                     }
                 } else if (p.c_bf16)
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
-                        make_uint2((unsigned)f2bf_g(v0) | ((unsigned)f2bf_g(v1) << 16), (unsigned)f2bf_g(v2) | ((unsigned)f2bf_g(v3) << 16));
+                        pack_bf16x4(v0, v1, v2, v3);
                 else
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
             }
@@ -165,7 +166,7 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int ld_src,
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
         *reinterpret_cast<uint2*>(dst + r * ld_dst + c) =
-            make_uint2((unsigned)f2bf_g(v.x) | ((unsigned)f2bf_g(v.y) << 16), (unsigned)f2bf_g(v.z) | ((unsigned)f2bf_g(v.w) << 16));
+            pack_bf16x4(v.x, v.y, v.z, v.w);
     }
 }
 
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bf16_kernel(const float* __r
             v.z = c + 2 < L ? expf(x.z - m) / sum : 0.f;
             v.w = c + 3 < L ? expf(x.w - m) / sum : 0.f;
         }
-        po[t] = make_uint2((unsigned)f2bf_g(v.x) | ((unsigned)f2bf_g(v.y) << 16), (unsigned)f2bf_g(v.z) | ((unsigned)f2bf_g(v.w) << 16));
+        po[t] = pack_bf16x4(v.x, v.y, v.z, v.w);
     }
 }
 

@@ -15,6 +15,7 @@
 // (weights are shared by every workgroup and never staged in LDS).  4 waves split the output columns;
 // layers run in place: all waves finish reading X, barrier, write bias+ReLU results, barrier.
 // Two workgroups per CU (69 KB LDS each) overlap one's epilogue/barrier bubbles with the other's MFMAs.
+#include "bf16_util.h"
 #include "index_math.h"
 #include "ops.h"
 
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
             a += x.x * gv[i].x + x.y * gv[i].y + x.z * gv[i].z + x.w * gv[i].w;
         }
         a += cterm;
-        a += __shfl_xor(a, 1, 64);
-        a += __shfl_xor(a, 2, 64);
+        a += quad_xor1(a);
+        a += quad_xor2(a);
         if (part == 0) {
             s_part[row] = a;
             s_part[FBM + row] = 0.f;
@@ -361,10 +362,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
                     z.y = av[mi] * (vv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y));
                     z.z = av[mi] * (vv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z));
                     z.w = av[mi] * (vv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
-                    z.x += __shfl_xor(z.x, 1, 64); z.y += __shfl_xor(z.y, 1, 64);
-                    z.z += __shfl_xor(z.z, 1, 64); z.w += __shfl_xor(z.w, 1, 64);
-                    z.x += __shfl_xor(z.x, 2, 64); z.y += __shfl_xor(z.y, 2, 64);
-                    z.z += __shfl_xor(z.z, 2, 64); z.w += __shfl_xor(z.w, 2, 64);
+                    z.x += quad_xor1(z.x); z.y += quad_xor1(z.y); z.z += quad_xor1(z.z); z.w += quad_xor1(z.w);
+                    z.x += quad_xor2(z.x); z.y += quad_xor2(z.y); z.z += quad_xor2(z.z); z.w += quad_xor2(z.w);
                     if (jsel == g) zsel = z;
                 }
                 const int d0 = 32 * u + 8 * jsel + 4 * lh;
@@ -424,9 +423,9 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
             a2 += x.x * u2.x + x.y * u2.y + x.z * u2.z + x.w * u2.w;
         }
     }
-    a0 += __shfl_xor(a0, 1, 64); a0 += __shfl_xor(a0, 2, 64);
-    a1 += __shfl_xor(a1, 1, 64); a1 += __shfl_xor(a1, 2, 64);
-    a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+    a0 += quad_xor1(a0); a0 += quad_xor2(a0);
+    a1 += quad_xor1(a1); a1 += quad_xor2(a1);
+    a2 += quad_xor1(a2); a2 += quad_xor2(a2);
     const int ql = qbase + row;
     if (part < 3 && ql < p.nq) {
         const long q = p.q0 + ql;

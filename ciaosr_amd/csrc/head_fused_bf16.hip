@@ -8,6 +8,7 @@
 // Same structure as head_fused.hip: swapped MFMA operands (weights = A operand from L2 in pre-packed fragment
 // order [n_tile][k16][lane][8 bf16], activations = B operand from LDS via ds_read_b128), a lane owns one
 // activation row and 4x4 consecutive output channels, hidden layers in place in LDS.
+#include "bf16_util.h"
 #include "index_math.h"
 #include "ops.h"
 
@@ -29,7 +30,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-neare
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ unsigned pack2(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
 
 __device__ __forceinline__ float4 hload4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
@@ -62,27 +63,38 @@ __global__ void pack_fragments_bf16_kernel(const float* __restrict__ W, int ld, 
 template <int NT>
 __device__ __forceinline__ void mma_pass16(const unsigned short* xa, const uint4* __restrict__ wf, int nks, long tile_stride,
                                            f32x16 (&acc)[HMI][NT]) {
-    uint4 fb[NT], fbn[NT];
+    // software pipeline: weight fragments (L2) are requested two k-steps ahead, the activation fragments (LDS) one
+    // k-step ahead, so neither latency sits between two MFMA groups
+    uint4 fb0[NT], fb1[NT], fb2[NT];
+    bf16x8 fa0[HMI], fa1[HMI];
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) fb[ni] = wf[ni * tile_stride];
+    for (int ni = 0; ni < NT; ++ni) {
+        fb0[ni] = wf[ni * tile_stride];
+        fb1[ni] = wf[ni * tile_stride + (nks > 1 ? 64 : 0)];
+    }
+#pragma unroll
+    for (int mi = 0; mi < HMI; ++mi) fa0[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
 #pragma unroll 1
     for (int ks = 0; ks < nks; ++ks) {
+        if (ks + 2 < nks) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fb2[ni] = wf[ni * tile_stride + (long)(ks + 2) * 64];
+        }
         if (ks + 1 < nks) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) fbn[ni] = wf[ni * tile_stride + (long)(ks + 1) * 64];
+            for (int mi = 0; mi < HMI; ++mi)
+                fa1[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
         }
-        bf16x8 fa[HMI];
-#pragma unroll
-        for (int mi = 0; mi < HMI; ++mi)
-            fa[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * ks));
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-            const bf16x8 w = __builtin_bit_cast(bf16x8, fb[ni]);
+            const bf16x8 w = __builtin_bit_cast(bf16x8, fb0[ni]);
 #pragma unroll
-            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fa[mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fa0[mi], acc[mi][ni], 0, 0, 0);
         }
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) fb[ni] = fbn[ni];
+        for (int ni = 0; ni < NT; ++ni) { fb0[ni] = fb1[ni]; fb1[ni] = fb2[ni]; }
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) fa0[mi] = fa1[mi];
     }
 }
 
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
             a += __uint_as_float(xb.x << 16) * gv.x + __uint_as_float(xb.x & 0xFFFF0000u) * gv.y +
                  __uint_as_float(xb.y << 16) * gv.z + __uint_as_float(xb.y & 0xFFFF0000u) * gv.w;
         }
-        a += __shfl_xor(a, 1, 64);
+        a += quad_xor1(a);
         if (part == 0) {
             s_part[row] = a;
             s_part[HBM_ + row] = 0.f;
@@ -322,10 +334,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
                     z.y = av[mi] * (vv[mi].y * (acc[mi][0][4 * g + 1] + bv.y));
                     z.z = av[mi] * (vv[mi].z * (acc[mi][0][4 * g + 2] + bv.z));
                     z.w = av[mi] * (vv[mi].w * (acc[mi][0][4 * g + 3] + bv.w));
-                    z.x += __shfl_xor(z.x, 1, 64); z.y += __shfl_xor(z.y, 1, 64);
-                    z.z += __shfl_xor(z.z, 1, 64); z.w += __shfl_xor(z.w, 1, 64);
-                    z.x += __shfl_xor(z.x, 2, 64); z.y += __shfl_xor(z.y, 2, 64);
-                    z.z += __shfl_xor(z.z, 2, 64); z.w += __shfl_xor(z.w, 2, 64);
+                    z.x += quad_xor1(z.x); z.y += quad_xor1(z.y); z.z += quad_xor1(z.z); z.w += quad_xor1(z.w);
+                    z.x += quad_xor2(z.x); z.y += quad_xor2(z.y); z.z += quad_xor2(z.z); z.w += quad_xor2(z.w);
                     if (jsel == g) zsel[mi] = z;
                 }
             }
@@ -392,9 +402,9 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
             a2 += x0 * u2.x + x1 * u2.y + x2 * u2.z + x3 * u2.w;
         }
     }
-    a0 += __shfl_xor(a0, 1, 64);
-    a1 += __shfl_xor(a1, 1, 64);
-    a2 += __shfl_xor(a2, 1, 64);
+    a0 += quad_xor1(a0);
+    a1 += quad_xor1(a1);
+    a2 += quad_xor1(a2);
     const int ql = qbase + row;
     if (part == 0 && ql < p.nq) {
         const long q = p.q0 + ql;

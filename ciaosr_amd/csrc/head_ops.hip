@@ -8,6 +8,7 @@
 //  decode_residual  last Linear of imnet_q (-> 3) + bilinear/border LR residual       (:107-108,221)
 //
 // One wavefront (64 lanes) per row / query; lanes stride the channel dimension with float4.
+#include "bf16_util.h"
 #include "common.h"
 #include "index_math.h"
 #include "ops.h"
@@ -269,7 +270,6 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
     const int ky = y + o / 3 - 1, kx = x + o % 3 - 1;
     float4* a = reinterpret_cast<float4*>(A + (size_t)rl * D);
     uint2* a16 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(A) + (size_t)rl * D);
-    auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };
     float c = 0.f;
     if (ky < 0 || ky >= H || kx < 0 || kx >= W) {          // this (query pixel, key pixel) pair cannot occur
         for (int t = lane; t < (D >> 2); t += 64) {
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
         for (int t = lane; t < (D >> 2); t += 64) {
             const float4 qv = q[t], kv = k[t], bv = b[t];
             const float4 v = make_float4(qv.x * kv.x, qv.y * kv.y, qv.z * kv.z, qv.w * kv.w);
-            if (B16) a16[t] = make_uint2(bf(v.x) | (bf(v.y) << 16), bf(v.z) | (bf(v.w) << 16));
+            if (B16) a16[t] = pack_bf16x4(v.x, v.y, v.z, v.w);
             else a[t] = v;
             c += v.x * bv.x + v.y * bv.y + v.z * bv.z + v.w * bv.w;
         }
@@ -338,9 +338,7 @@ __global__ void transpose_cast_bf16_kernel(const float* __restrict__ W, int ld, 
     const long n_el = (long)K * N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_el; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i % K), n = (int)(i / K);
-        unsigned u = __float_as_uint(W[(size_t)k * ld + n]);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        out[i] = (unsigned short)(u >> 16);
+        out[i] = to_bf16(W[(size_t)k * ld + n]);
     }
 }
 

@@ -2,6 +2,7 @@
 // row softmax, the gather-form fold of conv_transpose2d, restorer plumbing.
 // All accesses are float4 along the channel (innermost) dimension: one 3x3 / 6x6 tap of a
 // channels-last map is C contiguous floats.
+#include "bf16_util.h"
 #include "common.h"
 #include "index_math.h"
 
@@ -217,8 +218,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict
         if (t >= n4) continue;
         const float4 o = make_float4(v[i].x / sum, v[i].y / sum, v[i].z / sum, v[i].w / sum);
         if (OUT16) {
-            auto bf = [](float f) { unsigned u = __float_as_uint(f); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };
-            reinterpret_cast<uint2*>(P + (size_t)row * ldp)[t] = make_uint2(bf(o.x) | (bf(o.y) << 16), bf(o.z) | (bf(o.w) << 16));
+            reinterpret_cast<uint2*>(P + (size_t)row * ldp)[t] = pack_bf16x4(o.x, o.y, o.z, o.w);
         } else {
             s[t] = o;
         }
@@ -309,9 +309,7 @@ __global__ void csa_gather_vprime_t_bf16_kernel(const float* __restrict__ Pc, in
             else { dy = 0; dx = 0; r = 2; sct = 2; }
             v = Pc[((size_t)(ly - dy + 1) * We + (lx - dx + 1)) * (9 * C) + (size_t)(3 * r + sct) * C + co];
         }
-        unsigned u = __float_as_uint(v);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        VpT[idx] = (unsigned short)(u >> 16);
+        VpT[idx] = to_bf16(v);
     }
 }
 
