@@ -78,6 +78,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'enc_conv3x3': (2 * 2.0 * HW * 9 * C * C, 'flop'),            # sfe2 + gff.1 (dense layers run in scatter form)
         'enc_dense_scatter': (dense, 'flop'),
         'enc_dense_bf16': (dense, 'flop16'),
+        'enc_dense_gather': (dense, 'flop'),
         'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),
         'local_attention': (Q * (4.0 * J * D + 4.0 * J * Dv + 4.0 * Dv + 16) + 2.0 * C * 4 * HW, 'byte'),
         'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),

@@ -41,7 +41,7 @@ class CsAttnWeightsT(C.Structure):
 
 class ConvT(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int),
-                ('frag16', C.c_void_p)]
+                ('frag16', C.c_void_p), ('frag', C.c_void_p)]
 
 
 class RdnWeightsT(C.Structure):

@@ -20,6 +20,11 @@ int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int c
 int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
                      const float* bias, hipStream_t s);
 
+// dense_f32.hip
+int dense_f32_min_tiles();
+int dense_f32_tiles(int H, int W);
+int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, hipStream_t s);
+
 __global__ void image_to_hwc4_kernel(const float* __restrict__ x, float* __restrict__ out, long HW) {
     // [3][H][W] -> [H*W][4] with a zero 4th channel (so the first conv moves float4 taps)
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < HW; i += (long)gridDim.x * blockDim.x)
@@ -90,6 +95,9 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     bool dense16 = bf16 && C == 64 && G == 64 && dense_bf16_tiles(H, W) >= dense_bf16_min_tiles();
     if (bf16)
         for (int i = 0; i < NB * NL && dense16; ++i) dense16 = w->dense[i].frag16 != nullptr;
+    // big maps, fp32: halo-resident gather-form dense layers (dense_f32.hip) instead of the scatter form
+    bool dense32 = !dense16 && C == 64 && G == 64 && dense_f32_tiles(H, W) >= dense_f32_min_tiles();
+    for (int i = 0; i < NB * NL && dense32; ++i) dense32 = w->dense[i].frag != nullptr;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
     RUN(first_conv(x_nchw, H, W, w->sfe1, img4, rows, sfe1, C, s));
@@ -105,6 +113,12 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
                 RUN(dense_layer_bf16(x, cb, Xb, cb, H, W, l, c.frag16, c.bias, s));
+            }
+        } else if (dense32) {
+            for (int l = 0; l < NL; ++l) {
+                const ciaosr_conv_t& c = w->dense[b * NL + l];
+                CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
+                RUN(dense_layer_f32(x, cb, H, W, l, c.frag, c.bias, s));
             }
         } else if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
             // scatter form: input group s (64 channels) feeds every later dense layer in ONE convolution with

@@ -221,6 +221,8 @@ typedef struct ciaosr_conv {
     int cin, cout, ksize;
     const void* frag16;  /* optional: ciaosr_pack_fragments_bf16(weight, ld = k*k*cin, N = cout, K = k*k*cin); used by
                           * ciaosr_rdn_forward_bf16 for the dense layers, NULL otherwise */
+    const float* frag;   /* optional: ciaosr_pack_fragments_f32 of the same matrix; lets ciaosr_rdn_forward_f32 run the
+                          * dense layers of maps with >= 128 tiles of 12x12 pixels through the halo-resident kernel */
 } ciaosr_conv_t;
 
 typedef struct ciaosr_rdn_weights {

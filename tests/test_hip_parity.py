@@ -366,6 +366,29 @@ def test_staged_local_attention_kernel(dev):
 # ------------------------------------------------------------------------------------------------
 # encoder trunks (implicit-GEMM convolutions)
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('hw', [(37, 53), (48, 48)])
+def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw, monkeypatch):
+    """The big-map fp32 dense-layer kernel (dense_f32.hip, gather form, 12x12 tiles, K-sliced waves) forced onto small
+    ragged maps, against the torch-CPU trunk and against the default scatter-form path."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_init_
+    from oracle import ciaosr_oracle as orc
+    model = _restorer('rdn', 4, dev, dict(scale=4))
+    seeded_init_(model, seed=21, gain=1.6)
+    params = {k[len('generator.'):]: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    x = randn((1, 3) + hw, 77) * 0.3
+    want = orc.encoder_features(x, params)
+    gen = model.generator.to(dev)
+    scatter = gen.gen_feature(x.to(dev))[0].cpu()
+    monkeypatch.setenv('CIAOSR_DENSE_F32_MIN_TILES', '1')
+    with hip_ops.profile():
+        got = gen.gen_feature(x.to(dev))[0].cpu()
+    assert 'enc_dense_gather' in hip_ops.profile.results(), 'halo-resident fp32 dense kernel did not run'
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() < 2e-4 * max(scale, 1.0), ((got - want).abs().max().item(), scale)
+    assert (got - scatter).abs().max().item() < 2e-4 * max(scale, 1.0)
+
+
 def _rdn_trunk_bf16_emulation(x, P, nb, nl):
     """torch-CPU RDN trunk with the bf16 mode's rounding points: dense-layer inputs and weights rounded to bf16
     (products are then exact in fp32), fp32 accumulation, everything else fp32."""
