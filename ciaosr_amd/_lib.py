@@ -48,7 +48,8 @@ class RdnWeightsT(C.Structure):
     _fields_ = [('mid_channels', C.c_int), ('growth', C.c_int), ('num_blocks', C.c_int), ('num_layers', C.c_int),
                 ('sfe1', ConvT), ('sfe2', ConvT), ('gff0', ConvT), ('gff1', ConvT),
                 ('dense', C.POINTER(ConvT)), ('lff', C.POINTER(ConvT)),
-                ('scatter_weight', C.POINTER(C.c_void_p)), ('scatter_bias', C.c_void_p)]
+                ('scatter_weight', C.POINTER(C.c_void_p)), ('scatter_bias', C.c_void_p),
+                ('scatter_frag', C.POINTER(C.c_void_p))]
 
 
 class EdsrWeightsT(C.Structure):

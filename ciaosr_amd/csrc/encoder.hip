@@ -20,6 +20,10 @@ int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int c
 int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
                      const float* bias, hipStream_t s);
 
+// dense_scatter_f32.hip
+int dense_scatter_small_max_pixels();
+int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layers, const float* frag, const float* bias_all,
+                        float* acc_buf, hipStream_t s);
 // dense_f32.hip
 int dense_f32_min_tiles();
 int dense_f32_tiles(int H, int W);
@@ -123,9 +127,15 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
         } else if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
             // scatter form: input group s (64 channels) feeds every later dense layer in ONE convolution with
             // N = 64*(NL-s) output channels and K = 576: no split-K slabs, 8 launches instead of 16
-            for (int st = 0; st < NL; ++st)
-                RUN(dense_scatter_step(x, cb, H, W, st, NL, w->scatter_weight[b * NL + st],
-                                       w->scatter_bias + (size_t)b * NL * 64, accb, part, pf, s));
+            const bool small = w->scatter_frag && (long)HW <= dense_scatter_small_max_pixels();
+            for (int st = 0; st < NL; ++st) {
+                if (small && w->scatter_frag[b * NL + st])
+                    RUN(dense_scatter_small(x, cb, H, W, st, NL, w->scatter_frag[b * NL + st], w->scatter_bias + (size_t)b * NL * 64,
+                                            accb, s));
+                else
+                    RUN(dense_scatter_step(x, cb, H, W, st, NL, w->scatter_weight[b * NL + st],
+                                           w->scatter_bias + (size_t)b * NL * 64, accb, part, pf, s));
+            }
         } else {
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];

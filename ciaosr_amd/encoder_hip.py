@@ -75,11 +75,12 @@ class PackedEncoder:
                 lff[b] = _pack_conv(n.rdbs[b].lff, keep)
             st.dense, st.lff = dense, lff
             keep += [dense, lff]
-            st.scatter_weight, st.scatter_bias = None, None
+            st.scatter_weight, st.scatter_bias, st.scatter_frag = None, None, None
             if st.mid_channels == 64 and st.growth == 64:
                 # scatter form of the dense blocks (include/ciaosr_hip.h): stack, for input group s, the weight
                 # slices of every later layer -> one N = 64*(nl-s), K = 576 convolution per group
                 ptrs = (C.c_void_p * (nb * nl))()
+                fptrs = (C.c_void_p * (nb * nl))()
                 for b in range(nb):
                     convs = [n.rdbs[b].layers[l].conv.weight.detach().float() for l in range(nl)]   # [64][64(l+1)][3][3]
                     for s_ in range(nl):
@@ -87,9 +88,16 @@ class PackedEncoder:
                         wst = torch.cat(sl, 0).contiguous()
                         keep.append(wst)
                         ptrs[b * nl + s_] = wst.data_ptr()
+                        # MFMA fragment order for the small-map scatter kernel (dense_scatter_f32.hip)
+                        fr = torch.empty(_lib.load().ciaosr_fragment_floats(wst.shape[0], 576), dtype=torch.float32, device=wst.device)
+                        _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(wst), 576, wst.shape[0], 576, hip_ops.ptr(fr),
+                                  hip_ops.stream_ptr())
+                        keep.append(fr)
+                        fptrs[b * nl + s_] = fr.data_ptr()
                 bias = torch.stack([torch.stack([n.rdbs[b].layers[l].conv.bias.detach().float() for l in range(nl)])
                                     for b in range(nb)]).contiguous()
-                keep += [ptrs, bias]
+                keep += [ptrs, fptrs, bias]
+                st.scatter_frag = C.cast(fptrs, C.POINTER(C.c_void_p))
                 st.scatter_weight = C.cast(ptrs, C.POINTER(C.c_void_p))
                 st.scatter_bias = bias.data_ptr()
         else:
