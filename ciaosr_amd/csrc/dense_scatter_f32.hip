@@ -36,6 +36,13 @@ static_assert(SPATCH <= 32768, "the halo patch must fit the reduction scratch");
 constexpr size_t kScatterLds = 32768;        // max(patch, K-slice reduction scratch 4 x 2 x 4 x 64 x 16 B)
 constexpr unsigned kOobS = 0xFFFFFFF0u;
 
+#ifdef CIAOSR_PROBE      // developer probe (tools/scatter_probe.hip): cycle stamps of workgroup phases
+__device__ unsigned long long g_sprobe[4096 * 8];
+#define SPROBE(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_sprobe[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SPROBE(slot) do { } while (0)
+#endif
+
 struct ScatterP {
     float* x; int ldx;                       // block feature buffer [HW][ldx]: group s read, group s + 1 written
     unsigned x_bytes;
@@ -51,6 +58,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int tile = blockIdx.x / p.n32, nt = blockIdx.x - tile * p.n32;
     const int ty0 = (tile / p.tiles_x) * ST, tx0 = (tile % p.tiles_x) * ST;
+    SPROBE(0);
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
     // (1) weights first: 9 taps x 2 chunks of this wave's K slice, k-chunk j = tap*8 + 2w + c
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
     }
 
     // (2) halo patch of input group `step` -> LDS
+    SPROBE(1);
     i32x4 pv_[SLOADS];
 #pragma unroll
     for (int s = 0; s < SLOADS; ++s) {
@@ -113,6 +122,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
     __syncthreads();
+    SPROBE(2);
 
     // (3) 144 MFMAs per wave, no barrier
 #pragma unroll
@@ -131,6 +141,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
             }
         }
     }
+    SPROBE(3);
     __syncthreads();                                       // every wave is done reading the patch
 
     // (4) K-slice reduction through LDS: red[w][r][q][lane] = accumulator registers 4q..4q+3
@@ -142,6 +153,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
             red[((w * 2 + r) * 4 + q) * 64 + lane] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
     __syncthreads();
 
+    SPROBE(4);
     // (5) epilogue: 512 float4 units (r, q, lane) = pixel 32r + (lane & 31), channels 8q + 4 (lane >> 5) .. + 3
     float4 v[2];
 #pragma unroll
@@ -172,6 +184,13 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
             __builtin_amdgcn_raw_buffer_store_b128(iv, rs_acc, (int)aoff[u], 0, 0);
         }
     }
+    SPROBE(5);
+#ifdef CIAOSR_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_sprobe[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
+        g_sprobe[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
+    }
+#endif
 }
 
 int dense_scatter_small_max_pixels() {
