@@ -272,7 +272,7 @@ def main():
                 roof['other_kernels'] = others
                 # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
                 # WRITE_SIZE, tools/pmc_summary.py); offline evidence, null when the summary is absent
-                tag2fn = {'enc_dense_scatter': 'ciaosr::conv3x3_halo_kernel', 'head_kv_fused': 'ciaosr::head_kv_fused_kernel',
+                tag2fn = {'enc_dense_scatter': 'ciaosr::dense_scatter_small_kernel', 'head_kv_fused': 'ciaosr::head_kv_fused_kernel',
                           'head_decode_fused': 'ciaosr::head_decode_fused_kernel'}
                 pmc_path = os.path.join(REPO, 'profiles', 'r1_c2_pmc_hbm_traffic.json')
                 if args.workload == 'c2' and os.path.exists(pmc_path) and dominant in tag2fn:

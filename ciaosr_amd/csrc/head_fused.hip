@@ -77,17 +77,22 @@ __global__ void pack_fragments_kernel(const float* __restrict__ W, int ld, int N
 template <int NT>
 __device__ __forceinline__ void mma_pass(const float* xa, const float4* __restrict__ wf, int nj, long tile_stride,
                                          f32x16 (&acc)[2][NT]) {
+    // software pipeline: weight fragments (L2) and activation fragments (LDS) of step j + 1 are requested before
+    // the MFMAs of step j, so neither latency sits between two MFMA groups
     float4 fb[NT], fbn[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) fb[ni] = wf[ni * tile_stride];
+    float4 fa0 = *reinterpret_cast<const float4*>(xa);
+    float4 fa1 = *reinterpret_cast<const float4*>(xa + 32 * FLD);
 #pragma unroll 1
     for (int j = 0; j < nj; ++j) {
+        float4 fa0n = fa0, fa1n = fa1;
         if (j + 1 < nj) {
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) fbn[ni] = wf[ni * tile_stride + (long)(j + 1) * 64];
+            fa0n = *reinterpret_cast<const float4*>(xa + 8 * (j + 1));
+            fa1n = *reinterpret_cast<const float4*>(xa + 32 * FLD + 8 * (j + 1));
         }
-        const float4 fa0 = *reinterpret_cast<const float4*>(xa + 8 * j);
-        const float4 fa1 = *reinterpret_cast<const float4*>(xa + 32 * FLD + 8 * j);
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa0.x, acc[0][ni], 0, 0, 0);
@@ -101,6 +106,7 @@ __device__ __forceinline__ void mma_pass(const float* xa, const float4* __restri
         }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) fb[ni] = fbn[ni];
+        fa0 = fa0n; fa1 = fa1n;
     }
 }
 
