@@ -140,9 +140,33 @@ class CiaoSR(BasicRestorer):
                 hip_ops.set_precision(prev)
         return self._restore(lq, coord, cell)
 
+    @torch.no_grad()
+    def clip_test_any_scale(self, img_lq, ht, wt):
+        """Opt-in tiled inference for non-integer / > 4 scales (tile_plan.py): the reference's LR tiling and
+        uniform blending, HR rectangles by pixel-centre membership, tile-local coordinates and cells.
+        Returns [B, ht*wt, 3]."""
+        from . import tile_plan
+        b, c, h, w = img_lq.shape
+        tiles = tile_plan.plan(h, w, ht, wt, self.test_cfg.get('tile'), self.test_cfg.get('tile_overlap', 0) or 0)
+        E = torch.zeros(b, c, ht, wt, dtype=torch.float32, device=img_lq.device)
+        Wt = torch.zeros_like(E)
+        for t in tiles:
+            patch = img_lq[..., t['y0']:t['y0'] + t['th'], t['x0']:t['x0'] + t['tw']].contiguous()
+            coord = t['coord'].to(img_lq.device).unsqueeze(0).expand(b, -1, 2)
+            cell = t['cell'].to(img_lq.device).unsqueeze(0).expand(b, -1, 2)
+            out = self.generator(patch, coord, cell, test_mode=True)
+            for bi in range(b):
+                hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), t['i0'], t['j0'], t['i1'] - t['i0'], t['j1'] - t['j0'])
+        return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
+
     def _restore(self, lq, coord=None, cell=None):
         x = self.normalize(lq)
-        if self.test_cfg.get('tile', None):
+        if self.test_cfg.get('tile', None) and self.test_cfg.get('tile_any_scale', False) and coord is not None:
+            ih, iw = lq.shape[-2:]
+            s = math.sqrt(coord.shape[1] / (ih * iw))                 # the reference's own size rule (ciaosr.py:166-169)
+            pred = self.clip_test_any_scale(x, round(ih * s), round(iw * s))
+            n_q = pred.shape[1]
+        elif self.test_cfg.get('tile', None):
             pred = self.clip_test(x, self.generator)
             n_q = pred.shape[1]
         else:

@@ -710,3 +710,41 @@ def test_tiny_image_whole_path(dev):
     want = orc.forward_test(lq, coord, cell, params)
     got = model.to(dev).restore(lq.to(dev), coord.to(dev), cell.to(dev)).cpu()
     assert (got - want).abs().max() < 2e-4
+
+
+def test_any_scale_tiled_restore_vs_oracle_composition(dev):
+    """Opt-in tiling at a non-integer scale (tile_plan.py): EDSR x3.3 on a 45x51 LR image with 32-pixel
+    tiles against the same plan evaluated tile by tile with the torch-CPU oracle and blended on the CPU; and a one-tile
+    plan against the plain whole-image path (bitwise)."""
+    from ciaosr_amd import tile_plan
+    from ciaosr_amd.coords import make_coord, make_cell
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    from oracle import ciaosr_oracle as orc
+    h, w, ht, wt = 45, 51, 149, 168
+    model = _restorer('edsr', 3.3, dev, dict(tile=32, tile_overlap=8, tile_any_scale=True), blocks=4)
+    seeded_init_(model, seed=5, gain=1.4)
+    params = {k[len('generator.'):]: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    lq, _ = synthetic_pair(h, w, 3)
+    coord, cell = make_coord((ht, wt)).unsqueeze(0), make_cell((ht, wt)).unsqueeze(0)
+    got = model.restore(lq.to(dev), coord.to(dev), cell.to(dev)).cpu()
+    assert got.shape == (1, 3, ht, wt)
+    mean = torch.tensor(model.rgb_mean).view(1, 3, 1, 1)
+    x = lq - mean
+    E, Wt = torch.zeros(1, 3, ht, wt), torch.zeros(1, 3, ht, wt)
+    for t in tile_plan.plan(h, w, ht, wt, 32, 8):
+        patch = x[..., t['y0']:t['y0'] + 32, t['x0']:t['x0'] + 32]
+        out = orc.generator_forward(patch, t['coord'].unsqueeze(0), t['cell'].unsqueeze(0), params)
+        nh, nw = t['i1'] - t['i0'], t['j1'] - t['j0']
+        E[..., t['i0']:t['i1'], t['j0']:t['j1']] += out.view(1, nh, nw, 3).permute(0, 3, 1, 2)
+        Wt[..., t['i0']:t['i1'], t['j0']:t['j1']] += 1
+    want = (E / Wt + mean).clamp(0, 1)
+    assert (got - want).abs().max().item() < 1e-4
+    # one tile (square image, tile >= image) == whole-image path, bitwise
+    lq2, _ = synthetic_pair(40, 40, 3)
+    coord2, cell2 = make_coord((131, 131)).unsqueeze(0).to(dev), make_cell((131, 131)).unsqueeze(0).to(dev)
+    model.test_cfg['tile'] = 192
+    one = model.restore(lq2.to(dev), coord2, cell2).cpu()
+    model.test_cfg.pop('tile'); model.test_cfg.pop('tile_any_scale')
+    whole = model.restore(lq2.to(dev), coord2, cell2).cpu()
+    assert torch.equal(one, whole)

@@ -186,3 +186,34 @@ def test_dataset_pipeline_and_checkpoint_roundtrip(tmp_path):
     m2 = _small_restorer(dict(scale=2))
     load_checkpoint(m2, str(tmp_path / 'ck.pth'), strict=True)
     assert state_dict_sha256(m2) == sha
+
+
+def test_any_scale_tile_plan_properties():
+    """tile_plan.py (opt-in): integer scales reproduce clip_test's rectangles and tile-local grids, a
+    one-tile plan IS the whole-image grid (bitwise), every HR pixel is covered, coordinates stay inside the tile."""
+    import numpy as np
+    from ciaosr_amd import tile_plan
+    from ciaosr_amd.coords import make_coord, make_cell
+    # integer scale: same rectangles as ciaosr.py:233-254 and the same local grids up to fp32 rounding
+    h, w, sf, tile, ov = 50, 70, 4, 32, 8
+    for t in tile_plan.plan(h, w, h * sf, w * sf, tile, ov):
+        assert (t['i0'], t['i1'], t['j0'], t['j1']) == (t['y0'] * sf, (t['y0'] + tile) * sf, t['x0'] * sf, (t['x0'] + tile) * sf)
+        ref = make_coord((tile * sf, tile * sf))
+        assert (t['coord'] - ref).abs().max().item() < 3e-7
+        assert (t['cell'] - make_cell((tile * sf, tile * sf))).abs().max().item() < 1e-9
+    # one tile covering the image: the global grid and cell, bitwise
+    (t,) = tile_plan.plan(24, 24, 79, 79, 192, 32)
+    assert torch.equal(t['coord'], make_coord((79, 79))) and torch.equal(t['cell'], make_cell((79, 79)))
+    # non-integer scale: full coverage, blend weights >= 1 everywhere, local coordinates inside (-1, 1)
+    h, w, ht, wt = 45, 51, 149, 168                     # x3.3
+    cover = np.zeros((ht, wt), np.int32)
+    for t in tile_plan.plan(h, w, ht, wt, 32, 8):
+        cover[t['i0']:t['i1'], t['j0']:t['j1']] += 1
+        assert t['coord'].shape[0] == (t['i1'] - t['i0']) * (t['j1'] - t['j0'])
+        assert t['coord'].abs().max().item() < 1.0
+        # centre rule: the first/last HR row of the tile maps into the tile, its outer neighbours do not
+        pos = lambda i, n_lr, n_hr: (i + 0.5) * n_lr / n_hr
+        assert t['y0'] <= pos(t['i0'], h, ht) < t['y0'] + t['th'] and t['y0'] <= pos(t['i1'] - 1, h, ht) < t['y0'] + t['th']
+        assert t['i0'] == 0 or pos(t['i0'] - 1, h, ht) < t['y0']
+        assert t['i1'] == ht or pos(t['i1'], h, ht) >= t['y0'] + t['th']
+    assert cover.min() >= 1 and cover.max() <= 4
