@@ -52,6 +52,18 @@ class RdnWeightsT(C.Structure):
                 ('scatter_frag', C.POINTER(C.c_void_p))]
 
 
+class SwinBlockT(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('ln1_w', 'ln1_b', 'qkv_w', 'qkv_b', 'bias', 'proj_w', 'proj_b', 'ln2_w', 'ln2_b',
+                                           'fc1_w', 'fc1_b', 'fc2_w', 'fc2_b')] + [('shift', C.c_int), ('mask', C.c_void_p)]
+
+
+class SwinirWeightsT(C.Structure):
+    _fields_ = [('embed_dim', C.c_int), ('num_heads', C.c_int), ('window_size', C.c_int), ('hidden', C.c_int),
+                ('num_groups', C.c_int), ('depth', C.c_int), ('conv_first', ConvT), ('conv_after_body', ConvT),
+                ('pe_norm_w', C.c_void_p), ('pe_norm_b', C.c_void_p), ('norm_w', C.c_void_p), ('norm_b', C.c_void_p),
+                ('blocks', C.POINTER(SwinBlockT)), ('group_conv', C.POINTER(ConvT))]
+
+
 class EdsrWeightsT(C.Structure):
     _fields_ = [('mid_channels', C.c_int), ('num_blocks', C.c_int), ('res_scale', C.c_float),
                 ('conv_first', ConvT), ('conv_after_body', ConvT),
@@ -99,6 +111,8 @@ SIGNATURES = {
     'ciaosr_rdn_forward_bf16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
     'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),
     'ciaosr_edsr_forward_f32': (_I, [_P, _I, _I, C.POINTER(EdsrWeightsT), _P, _P, _S, _P]),
+    'ciaosr_swinir_workspace_bytes': (_S, [_I, _I, C.POINTER(SwinirWeightsT)]),
+    'ciaosr_swinir_forward_f32': (_I, [_P, _I, _I, C.POINTER(SwinirWeightsT), _P, _P, _S, _P]),
     'ciaosr_normalize_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     'ciaosr_denorm_clamp_f32': (_I, [_P, _P, _I, _I, C.POINTER(_F), C.POINTER(_F), _P]),
     'ciaosr_tile_blend_f32': (_I, [_P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),

@@ -77,6 +77,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, int row, int col, 
     }
     v = (v + (p.bias ? p.bias[col] : 0.f)) * p.alpha;
     if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (p.act == CIAOSR_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     if (p.res) v += p.res[(size_t)row * p.ld_res + col];
     p.dst[(size_t)row * p.ld_dst + col] = v;
     if (p.dst2) p.dst2[(size_t)row * p.ld_dst2 + col] = v;
@@ -144,6 +145,7 @@ __device__ __forceinline__ void conv_tile_epilogue(const ConvP& p, f32x16& acc, 
         for (int r = 0; r < 16; ++r) {
             float v = (acc[r] + b) * p.alpha;
             if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == CIAOSR_ACT_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
             v += resv[r];
             acc[r] = v;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rs_d, off(r, p.ld_dst, col), 0, 0);

@@ -1,0 +1,300 @@
+// SwinIR trunk of LocalImplicitSRSWINIR.gen_feature (ciaosr_net.py:475-525 over swinir_net.py: conv_first :710,
+// PatchEmbed norm :553-557, RSTB :420-460 = 6 x SwinTransformerBlock :149-258 + conv + residual, final norm :718,
+// conv_after_body :777) on channels-last token maps.
+//
+// Token map T [Hp*Wp][ld] fp32, ld = C rounded up to 64 (180 -> 192), pad columns kept at zero so that every linear
+// layer and 3x3 convolution runs through the implicit-GEMM convolution of conv_f32.hip with Cin = ld (weights are
+// zero-padded on the host).  Per Swin block: LayerNorm -> qkv (1x1 conv) -> window attention -> proj (+ residual,
+// in place) -> LayerNorm -> fc1 (+ exact GELU) -> fc2 (+ residual, in place): 7 launches instead of PyTorch's ~30.
+//
+// Window attention (swinir_net.py:66-146): one workgroup per (window, head); the cyclic shift (torch.roll :228-231,
+// :247-250) is folded into the token index, the relative-position bias arrives pre-gathered per layer
+// [heads][N][N] and the shifted-window mask [nW][N][N] (calculate_mask :192-213) per map size, both built once on the
+// host.  Everything fp32 (exact-fp32 MFMA for q k^T and P v).
+#include "ops.h"
+
+namespace ciaosr {
+
+int conv2d_hwc(const float* src, int ld_src, int H, int W, int Cin, const float* wgt, int ldw, const float* bias,
+               int Cout, int ksize, float* dst, int ld_dst, float* dst2, int ld_dst2, const float* res, int ld_res,
+               int act, float alpha, float* partial, size_t partial_floats, hipStream_t s, const char* tag);
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// [3][H][W] -> [Hp*Wp][4], bottom/right reflect padding (F.pad(..., 'reflect'), ciaosr_net.py:509-512), zero 4th channel
+__global__ void image_to_hwc4_reflect_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int Hp, int Wp) {
+    const long n = (long)Hp * Wp;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        int y = (int)(i / Wp), xx = (int)(i - (long)y * Wp);
+        if (y >= H) y = 2 * (H - 1) - y;
+        if (xx >= W) xx = 2 * (W - 1) - xx;
+        const long s = (long)y * W + xx, HW = (long)H * W;
+        reinterpret_cast<float4*>(out)[i] = make_float4(x[s], x[HW + s], x[2 * HW + s], 0.f);
+    }
+}
+
+// LayerNorm over the first C of ld columns of each token (eps 1e-5, biased variance: nn.LayerNorm); pad columns -> 0.
+// One wavefront per token, float4 lanes.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ X, int ldx, float* __restrict__ Y, int ldy,
+                                                        const float* __restrict__ g, const float* __restrict__ b, long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* x = reinterpret_cast<const float4*>(X + row * ldx);
+    const int n4 = C >> 2;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < n4) v = x[lane];
+    float4 v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane + 64 < n4) v2 = x[lane + 64];                       // C <= 512
+    const float mean = wsum64((v.x + v.y) + (v.z + v.w) + (v2.x + v2.y) + (v2.z + v2.w)) / (float)C;
+    float sq = 0.f;
+    if (lane < n4) sq += (v.x - mean) * (v.x - mean) + (v.y - mean) * (v.y - mean) + (v.z - mean) * (v.z - mean) + (v.w - mean) * (v.w - mean);
+    if (lane + 64 < n4) sq += (v2.x - mean) * (v2.x - mean) + (v2.y - mean) * (v2.y - mean) + (v2.z - mean) * (v2.z - mean) + (v2.w - mean) * (v2.w - mean);
+    const float rstd = 1.0f / sqrtf(wsum64(sq) / (float)C + 1e-5f);
+    float4* y = reinterpret_cast<float4*>(Y + row * ldy);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (int t = lane; t < (ldy >> 2); t += 64) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < n4) {
+            const float4 xv = t < 64 ? v : v2, gv = g4[t], bv = b4[t];
+            o = make_float4((xv.x - mean) * rstd * gv.x + bv.x, (xv.y - mean) * rstd * gv.y + bv.y,
+                            (xv.z - mean) * rstd * gv.z + bv.z, (xv.w - mean) * rstd * gv.w + bv.w);
+        }
+        y[t] = o;
+    }
+}
+
+// ---- window attention ---------------------------------------------------------------------------------------
+struct WinAttnP {
+    const float* qkv; int ld_qkv;     // [HW][3C]: q | k | v, each [heads][d]  (q already scaled: the scale is folded into the weights)
+    float* out; int ld_out;           // [HW][ld]: column h*d + e
+    const float* bias;                // [heads][N][N] relative-position bias of this layer
+    const float* mask;                // [nW][N][N] or null (unshifted layer)
+    int Hp, Wp, C, heads, d, ws, shift;
+};
+
+constexpr int WMAXN = 64, WMAXD = 32;   // window 8x8, head dim <= 32
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+
+// One workgroup per (window, head), 4 waves.  q, k, v of the window's 64 tokens go to LDS (head dim zero-padded to 32);
+// S = q k^T as four 32x32 MFMA tiles (one per wave, exact-fp32 v_mfma_f32_32x32x2_f32), + bias + mask, row softmax,
+// O = P v as two 32x32 tiles.  N < 64 (smaller windows) runs with zero rows and -inf columns.
+__global__ __launch_bounds__(256) void window_attention_kernel(WinAttnP p) {
+    __shared__ float sq[WMAXN][WMAXD + 2], sk[WMAXN][WMAXD + 2], sv[WMAXN][WMAXD + 2];
+    __shared__ float sp[WMAXN][WMAXN + 1];
+    __shared__ int stok[WMAXN];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.x % p.heads, win = blockIdx.x / p.heads;
+    const int N = p.ws * p.ws, nwx = p.Wp / p.ws;
+    const int wy = win / nwx, wx = win - wy * nwx;
+    if (t < WMAXN) {
+        // window-local (ly, lx) of the ROLLED map -> original token: rolled[y'] = x[(y' + shift) mod Hp]  (roll by -shift)
+        int tok = 0;
+        if (t < N) {
+            const int ly = t / p.ws, lx = t - ly * p.ws;
+            int y = wy * p.ws + ly + p.shift, x = wx * p.ws + lx + p.shift;
+            if (y >= p.Hp) y -= p.Hp;
+            if (x >= p.Wp) x -= p.Wp;
+            tok = y * p.Wp + x;
+        }
+        stok[t] = tok;
+    }
+    __syncthreads();
+    for (int i = t; i < WMAXN * WMAXD; i += 256) {
+        const int n = i >> 5, e = i & 31;
+        float q = 0.f, k = 0.f, v = 0.f;
+        if (n < N && e < p.d) {
+            const float* r = p.qkv + (size_t)stok[n] * p.ld_qkv + head * p.d + e;
+            q = r[0]; k = r[p.C]; v = r[2 * p.C];
+        }
+        sq[n][e] = q; sk[n][e] = k; sv[n][e] = v;
+    }
+    __syncthreads();
+    {   // scores tile (mi, ni) of this wave: D[m][n], lane holds column j = 32 ni + li, rows 8 (r >> 2) + 4 lh + (r & 3)
+        const int mi = w >> 1, ni = w & 1;
+        f32x16w acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < WMAXD / 2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sq[32 * mi + li][2 * ks + lh], sk[32 * ni + li][2 * ks + lh], acc, 0, 0, 0);
+        const int j = 32 * ni + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * mi + 8 * (r >> 2) + 4 * lh + (r & 3);
+            float a = -INFINITY;
+            if (i < N && j < N) {
+                a = acc[r] + p.bias[((size_t)head * N + i) * N + j];
+                if (p.mask) a += p.mask[((size_t)win * N + i) * N + j];
+            }
+            sp[i][j] = a;
+        }
+    }
+    __syncthreads();
+    for (int i = w; i < WMAXN; i += 4) {                  // softmax, one wavefront per row (rows >= N become zeros)
+        const float v = sp[i][lane];
+        const float m = wmax64(v);
+        const float e = (i < N && lane < N) ? expf(v - m) : 0.f;
+        const float sum = wsum64(e);
+        sp[i][lane] = i < N ? e / sum : 0.f;
+    }
+    __syncthreads();
+    if (w < 2) {                                          // O tile mi = w: D[m][e], lane holds channel e = li
+        f32x16w acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+        for (int ks = 0; ks < WMAXN / 2; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sp[32 * w + li][2 * ks + lh], sv[2 * ks + lh][li], acc, 0, 0, 0);
+        if (li < p.d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 32 * w + 8 * (r >> 2) + 4 * lh + (r & 3);
+                if (i < N) p.out[(size_t)stok[i] * p.ld_out + head * p.d + li] = acc[r];
+            }
+        }
+    }
+}
+
+// F [Hp*Wp][ld] -> feat [H][W][C] (crop of the reflect padding, ciaosr_net.py:523, and repack to C columns)
+__global__ void crop_repack_kernel(const float* __restrict__ F, int ld, int Wp, float* __restrict__ out, int H, int W, int C) {
+    const int c4n = C >> 2;
+    const long n = (long)H * W * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const long pix = i / c4n;
+        const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+        reinterpret_cast<float4*>(out)[i] = *reinterpret_cast<const float4*>(F + ((size_t)y * Wp + x) * ld + 4 * c4);
+    }
+}
+
+static int layernorm(const float* X, int ldx, float* Y, int ldy, const float* g, const float* b, long rows, int C, hipStream_t s) {
+    CIAOSR_CHECK_ARG(X && Y && g && b && (C & 3) == 0 && C <= 512 && (ldx & 3) == 0 && (ldy & 3) == 0);
+    ProfScope prof("swin_layernorm", s);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, X, ldx, Y, ldy, g, b, rows, C);
+    return launch_status("layernorm");
+}
+
+static bool cv_ok(const ciaosr_conv_t& c, int cin, int cout, int k) {
+    return c.weight && c.bias && c.cin == cin && c.cout == cout && c.ksize == k;
+}
+
+}  // namespace ciaosr
+
+using namespace ciaosr;
+
+static int swin_ld(int C) { return (int)round_up((size_t)C, 64); }
+
+extern "C" size_t ciaosr_swinir_workspace_bytes(int H, int W, const ciaosr_swinir_weights_t* w) {
+    if (!w || H <= 0 || W <= 0 || w->window_size <= 0) return 0;
+    const int ws = w->window_size;
+    const size_t Hp = round_up((size_t)H, ws), Wp = round_up((size_t)W, ws), HW = Hp * Wp;
+    const int ld = swin_ld(w->embed_dim), ldh = swin_ld(w->hidden);
+    const size_t n = HW * 4 + HW * 36 + 5 * HW * ld /*x0, two token maps, normed, attention*/ + HW * round_up(3 * (size_t)w->embed_dim, 32) +
+                     HW * ldh + 16 * HW * ld /*split-K slabs*/;
+    return n * sizeof(float) + 16 * 256;
+}
+
+extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, const ciaosr_swinir_weights_t* w, float* feat_hwc,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+    CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
+    const int C = w->embed_dim, heads = w->num_heads, ws = w->window_size, hid = w->hidden;
+    CIAOSR_CHECK_ARG(C > 0 && (C & 3) == 0 && heads > 0 && C % heads == 0 && C / heads <= WMAXD && ws > 0 && ws * ws <= WMAXN);
+    CIAOSR_CHECK_ARG(hid > 0 && (hid & 3) == 0 && w->num_groups >= 1 && w->depth >= 1 && w->blocks && w->group_conv);
+    CIAOSR_CHECK_ARG(w->pe_norm_w && w->pe_norm_b && w->norm_w && w->norm_b);
+    const int ld = swin_ld(C), ldh = swin_ld(hid), d = C / heads;
+    // the convolution kernels store whole 32-column tiles: every destination row needs room up to the next multiple of 32
+    const int ldq = (int)round_up((size_t)3 * C, 32);
+    const int Hp = (int)round_up((size_t)H, ws), Wp = (int)round_up((size_t)W, ws);
+    CIAOSR_CHECK_ARG(Hp - H < H && Wp - W < W);                    // reflect padding needs pad < size
+    CIAOSR_CHECK_ARG(cv_ok(w->conv_first, 3, C, 3) && cv_ok(w->conv_after_body, ld, C, 3));
+    if (workspace_bytes < ciaosr_swinir_workspace_bytes(H, W, w)) return CIAOSR_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t HW = (size_t)Hp * Wp;
+    Arena ar(workspace, workspace_bytes);
+    float* img4 = ar.take<float>(HW * 4);
+    float* rows = ar.take<float>(HW * 36);
+    float* x0 = ar.take<float>(HW * ld);
+    float* T[2] = {ar.take<float>(HW * ld), ar.take<float>(HW * ld)};
+    float* Y = ar.take<float>(HW * ld);
+    float* A = ar.take<float>(HW * ld);
+    float* QKV = ar.take<float>(HW * (size_t)ldq);
+    float* Hb = ar.take<float>(HW * ldh);
+    const size_t pf = 16 * HW * ld;
+    float* part = ar.take<float>(pf);
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+    int rc;
+#define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    // zero the padded maps once: the pad columns [C, ld) / [hid, ldh) are never written afterwards
+    if (hipMemsetAsync(x0, 0, (size_t)((char*)QKV - (char*)x0), s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
+    if (hipMemsetAsync(Hb, 0, HW * ldh * sizeof(float), s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
+    {
+        ProfScope prof("image_to_hwc4", s);
+        int grid = (int)((HW + 255) / 256);
+        hipLaunchKernelGGL(image_to_hwc4_reflect_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, s, x_nchw, img4, H, W, Hp, Wp);
+    }
+    RUN(launch_status("image_to_hwc4_reflect"));
+    RUN(patch_rows(img4, 4, Hp, Wp, 4, 3, 1, 1, Hp, Wp, rows, 36, 0, 0.f, s, "enc_patch_first"));
+    RUN(gemm_f32(rows, 36, w->conv_first.weight, 36, false, x0, ld, w->conv_first.bias, (int)HW, C, 36, 1.f, CIAOSR_ACT_NONE, 0.f, s,
+                 "enc_conv_first"));
+    // PatchEmbed: flatten (free in channels-last) + LayerNorm
+    RUN(layernorm(x0, ld, T[0], ld, w->pe_norm_w, w->pe_norm_b, (long)HW, C, s));
+    int cur = 0;
+    for (int g = 0; g < w->num_groups; ++g) {
+        float* t = T[cur];
+        float* tn = T[cur ^ 1];
+        // the RSTB residual needs the group input: work on a copy in the other buffer, keep `t` untouched
+        if (hipMemcpyAsync(tn, t, HW * ld * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
+        for (int l = 0; l < w->depth; ++l) {
+            const ciaosr_swin_block_t& b = w->blocks[g * w->depth + l];
+            CIAOSR_CHECK_ARG(b.ln1_w && b.ln1_b && b.qkv_w && b.qkv_b && b.bias && b.proj_w && b.proj_b && b.ln2_w && b.ln2_b &&
+                             b.fc1_w && b.fc1_b && b.fc2_w && b.fc2_b);
+            const int shift = b.shift;      // fixed at construction from the CONFIGURED input_resolution (:170-173), not the map size
+            CIAOSR_CHECK_ARG(shift == 0 || b.mask);
+            RUN(layernorm(tn, ld, Y, ld, b.ln1_w, b.ln1_b, (long)HW, C, s));
+            RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, b.qkv_w, ld, b.qkv_b, 3 * C, 1, QKV, ldq, nullptr, 0, nullptr, 0, CIAOSR_ACT_NONE, 1.f,
+                           part, pf, s, "swin_qkv"));
+            {
+                WinAttnP ap{QKV, ldq, A, ld, b.bias, shift ? b.mask : nullptr, Hp, Wp, C, heads, d, ws, shift};
+                ProfScope prof("swin_window_attention", s);
+                hipLaunchKernelGGL(window_attention_kernel, dim3((Hp / ws) * (Wp / ws) * heads), dim3(256), 0, s, ap);
+            }
+            RUN(launch_status("window_attention"));
+            RUN(conv2d_hwc(A, ld, Hp, Wp, ld, b.proj_w, ld, b.proj_b, C, 1, tn, ld, nullptr, 0, tn, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
+                           "swin_proj"));
+            RUN(layernorm(tn, ld, Y, ld, b.ln2_w, b.ln2_b, (long)HW, C, s));
+            RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, b.fc1_w, ld, b.fc1_b, hid, 1, Hb, ldh, nullptr, 0, nullptr, 0, CIAOSR_ACT_GELU, 1.f, part, pf,
+                           s, "swin_fc1"));
+            RUN(conv2d_hwc(Hb, ldh, Hp, Wp, ldh, b.fc2_w, ldh, b.fc2_b, C, 1, tn, ld, nullptr, 0, tn, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
+                           "swin_fc2"));
+        }
+        // RSTB tail: conv3x3(residual_group(x)) + x -> the next group's input
+        const ciaosr_conv_t& gc = w->group_conv[g];
+        CIAOSR_CHECK_ARG(cv_ok(gc, ld, C, 3));
+        // in place over the group input: the epilogue reads res[row][col] and writes dst[row][col] from the same lane
+        RUN(conv2d_hwc(tn, ld, Hp, Wp, ld, gc.weight, 9 * ld, gc.bias, C, 3, t, ld, nullptr, 0, t, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
+                       "swin_group_conv"));
+    }
+    RUN(layernorm(T[cur], ld, Y, ld, w->norm_w, w->norm_b, (long)HW, C, s));
+    RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, w->conv_after_body.weight, 9 * ld, w->conv_after_body.bias, C, 3, A, ld, nullptr, 0, x0, ld,
+                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "swin_conv_after_body"));
+    {
+        ProfScope prof("swin_crop", s);
+        const long n = (long)H * W * (C >> 2);
+        int grid = (int)((n + 255) / 256);
+        hipLaunchKernelGGL(crop_repack_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, A, ld, Wp, feat_hwc, H, W, C);
+    }
+    RUN(launch_status("crop_repack"));
+#undef RUN
+    return CIAOSR_OK;
+}

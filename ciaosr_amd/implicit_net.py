@@ -165,7 +165,8 @@ class LocalImplicitSREDSR(LocalImplicitSRNet):
 
 
 class LocalImplicitSRSWINIR(LocalImplicitSRNet):
-    """ciaosr_net.py:411-525: SwinIR trunk (PyTorch-ROCm) + the HIP head.  Leading `window_size` argument."""
+    """ciaosr_net.py:411-525: SwinIR trunk (HIP: csrc/swinir.hip; PyTorch-ROCm kept as `gen_feature_torch` for
+    configurations the HIP trunk does not cover) + the HIP head.  Leading `window_size` argument."""
 
     def __init__(self, window_size, encoder, imnet_q, imnet_k, imnet_v, query_mlp=None, key_mlp=None, value_mlp=None,
                  local_size=2, feat_unfold=True, eval_bsize=None, non_local_attn=True, multi_scale=[2],
@@ -183,7 +184,16 @@ class LocalImplicitSRSWINIR(LocalImplicitSRNet):
         self.patch_unembed = self.encoder.patch_unembed
         self.conv_after_body = self.encoder.conv_after_body
         del self.encoder
+        from .swinir_hip import PackedSwinIR
+        self._encoder_hip = PackedSwinIR(self)
 
     def gen_feature(self, img):
+        enc = self._encoder_hip
+        if img.is_cuda and enc.supported():
+            img = img.contiguous().float()
+            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(img[b])) for b in range(img.shape[0])])]
+        return [self.gen_feature_torch(img)]
+
+    def gen_feature_torch(self, img):
         from .encoders.swinir import swinir_features
-        return [swinir_features(self, img)]
+        return swinir_features(self, img)

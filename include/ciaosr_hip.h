@@ -37,6 +37,7 @@ extern "C" {
 #define CIAOSR_ACT_NONE 0
 #define CIAOSR_ACT_RELU 1
 #define CIAOSR_ACT_PRELU 2
+#define CIAOSR_ACT_GELU 3   /* exact erf form (nn.GELU default); convolution epilogues only */
 
 #define CIAOSR_MAX_LAYERS 8
 
@@ -262,6 +263,38 @@ int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_
 size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w);
 int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w, float* feat_hwc,
                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- SwinIR trunk: LocalImplicitSRSWINIR.gen_feature (net:475-525 over swinir_net.py) --------------------------
+ * Token maps are [Hp*Wp][ld] with ld = embed_dim rounded up to 64 (Hp, Wp = H, W reflect-padded to window multiples,
+ * net:509-512); every Linear / 3x3 convolution weight is given with its input dimension zero-padded to that ld
+ * (hidden rounded up to 64 for fc2), i.e. qkv_w [3C][ld], proj_w [C][ld], fc1_w [hidden][ld], fc2_w [C][ldh],
+ * group_conv / conv_after_body [C][9*ld] tap-major; conv_first as in the RDN trunk ([C][36]). */
+typedef struct ciaosr_swin_block {     /* SwinTransformerBlock (swinir_net.py:149-258) */
+    const float *ln1_w, *ln1_b;        /* norm1 */
+    const float *qkv_w, *qkv_b;        /* attn.qkv with the q rows pre-multiplied by head_dim^-0.5 (swinir_net.py:125) */
+    const float *bias;                 /* relative_position_bias_table gathered by relative_position_index: [heads][N][N] (:129-132) */
+    const float *proj_w, *proj_b;      /* attn.proj */
+    const float *ln2_w, *ln2_b;        /* norm2 */
+    const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;   /* mlp (exact GELU in between) */
+    int shift;                         /* 0 or window_size/2 */
+    const float *mask;                 /* shifted blocks: attention mask [nW][N][N] (0 / -100) for THIS call's padded map size:
+                                        * the block's attn_mask buffer when the size equals its input_resolution, else
+                                        * calculate_mask(x_size) (swinir_net.py:192-213, :233-236); NULL for shift 0 */
+} ciaosr_swin_block_t;
+
+typedef struct ciaosr_swinir_weights {
+    int embed_dim, num_heads, window_size, hidden, num_groups, depth;   /* depth = blocks per RSTB (uniform) */
+    ciaosr_conv_t conv_first, conv_after_body;
+    const float *pe_norm_w, *pe_norm_b;        /* patch_embed.norm */
+    const float *norm_w, *norm_b;              /* final norm */
+    const ciaosr_swin_block_t* blocks;         /* host array [num_groups*depth] */
+    const ciaosr_conv_t* group_conv;           /* host array [num_groups]: layers[g].conv ('1conv') */
+} ciaosr_swinir_weights_t;
+
+size_t ciaosr_swinir_workspace_bytes(int H, int W, const ciaosr_swinir_weights_t* w);
+/* x_nchw [3][H][W] normalised LR image -> feat_hwc [H][W][embed_dim] */
+int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, const ciaosr_swinir_weights_t* w, float* feat_hwc,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- restorer plumbing (rest:142-169, :218-258) --------------------------------------------- */
 /* x = (lq - mean) / std on [3][H][W] */

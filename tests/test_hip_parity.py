@@ -748,3 +748,29 @@ def test_any_scale_tiled_restore_vs_oracle_composition(dev):
     model.test_cfg.pop('tile'); model.test_cfg.pop('tile_any_scale')
     whole = model.restore(lq2.to(dev), coord2, cell2).cpu()
     assert torch.equal(one, whole)
+
+
+@pytest.mark.parametrize('hw', [(48, 48), (45, 51), (8, 20)])
+def test_swinir_trunk_hip_vs_torch(dev, hw):
+    """ciaosr_swinir_forward_f32 (LayerNorm / window attention with folded shift, bias and mask / GELU MLP / 3x3 convs on
+    padded channel maps) against the PyTorch trunk with the same weights: map sizes that need reflect padding, and a map
+    with a single window row (the cyclic shift wraps inside one window there)."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.config import Config
+    from ciaosr_amd import build_model
+    from ciaosr_amd.init_utils import seeded_init_
+    cfg = Config.fromfile(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs', '001_localimplicitsr_swinir_div2k_g1_c64b16_1000k_unfold_lec_mulwkv_res_nonlocal.py'))
+    model = build_model(cfg.model, train_cfg=None, test_cfg=cfg.test_cfg)
+    seeded_init_(model, seed=9, gain=1.3)
+    gen = model.generator.to(dev).eval()
+    assert gen._encoder_hip.supported()
+    x = (randn((1, 3) + hw, 91) * 0.3).to(dev)
+    with torch.no_grad():
+        want = gen.gen_feature_torch(x)
+    with hip_ops.profile():
+        got = gen.gen_feature(x)[0]
+    assert 'swin_window_attention' in hip_ops.profile.results(), 'HIP SwinIR trunk did not run'
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    print(f'swinir trunk {hw}: max|d| {err:.3e} (scale {scale:.3f})')
+    assert err < 2e-4 * max(scale, 1.0), (err, scale)
