@@ -121,8 +121,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help='fp32 (default): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs in the fused head only')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c3tile', 'c3'],
-                    help='c2 (default, BASELINE configs[1]): LR 48x48; c3tile: one 192x192 LR tile; c3: LR 1356x2040 (117 tiles)')
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c3tile', 'c3', 'c3s'],
+                    help='c2 (default, BASELINE configs[1]): LR 48x48; c3tile: one 192x192 LR tile; c3: LR 1356x2040 (117 tiles); '
+                         'c3s: LR 339x510 (6 tiles).  c3 / c3s with --gpus N > 1 shard the tiles of the ONE image over the ranks (C4, strong scaling)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -152,13 +153,14 @@ def main():
     hip_ops.set_precision(args.precision)
 
     scale, lr = 4, 48
-    if args.workload != 'c2':
-        assert world == 1, 'the c3 workloads are single-GPU measurements'
-    test_cfg = dict(scale=scale, tile=192, tile_overlap=32) if world == 1 else dict(scale=scale, tile=lr, tile_overlap=0)
+    if args.workload == 'c3tile':
+        assert world == 1, 'c3tile is a single-tile (single-GPU) measurement'
+    weak = args.workload == 'c2'                      # c2: one 48x48 tile per rank; c3 / c3s: one image, tiles sharded
+    test_cfg = dict(scale=scale, tile=192, tile_overlap=32) if (world == 1 or not weak) else dict(scale=scale, tile=lr, tile_overlap=0)
     model = rdn_ciaosr(test_cfg)
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
-    lr_h, lr_w = {'c2': (lr, lr * world), 'c3tile': (192, 192), 'c3': (1356, 2040)}[args.workload]
+    lr_h, lr_w = {'c2': (lr, lr * world), 'c3tile': (192, 192), 'c3': (1356, 2040), 'c3s': (339, 510)}[args.workload]
     lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
     lq = lq.to(dev)
     out_pixels = (lr_h * scale) * (lr_w * scale)
@@ -169,8 +171,7 @@ def main():
         x = model.normalize(lq)
         pred = clip_test_distributed(model, x, rank, world)
         if rank == 0:
-            return hip_ops.denorm_clamp(pred[0].contiguous(), lr * scale, lr * world * scale, model.rgb_mean,
-                                        model.rgb_std)
+            return hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
         return None
 
     def sync():
@@ -234,7 +235,9 @@ def main():
         roof = None
         if dominant and dominant in prof_dom:
             tile_lr = lr if args.workload == 'c2' else 192
-            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117}[args.workload]
+            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
+            if world > 1 and not weak:
+                n_tiles = (n_tiles + world - 1) // world          # tiles t = 0, R, 2R, ... run on rank 0 (whose kernels are timed)
             Q, HW = (tile_lr * scale) ** 2, tile_lr * tile_lr
             work = kernel_work(dominant, Q, HW)
             if work:
@@ -286,13 +289,16 @@ def main():
             'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak' if weak else 'strong', 'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs in the head (fp32 accumulate); encoder + cs_attn f32',
             'data': 'synthetic',
             'config': {'workload': {'c2': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init weights, fp32',
                                     'c3tile': 'C3 unit: RDN-CiaoSR x4, one 192x192 LR tile -> 768x768, random-init weights, fp32',
-                                    'c3': 'C3: RDN-CiaoSR x4, LR 1356x2040 -> 5424x8160, 117 tiles of 192 (overlap 32), random-init weights, fp32'}[args.workload] + ('' if world == 1 else f'; one {lr}x{lr * world} LR image, '
-                                   f'{world} tiles sharded one per GPU, RCCL all_gather + rank-0 blend'),
+                                    'c3': 'C3: RDN-CiaoSR x4, LR 1356x2040 -> 5424x8160, 117 tiles of 192 (overlap 32), random-init weights, fp32',
+                                    'c3s': 'C3 (DIV2K-val pairing): RDN-CiaoSR x4, LR 339x510 -> 1356x2040, 6 tiles of 192 (overlap 32), random-init weights, fp32'}[args.workload]
+                                   + ('' if world == 1 else (f'; one {lr}x{lr * world} LR image, {world} tiles sharded one per GPU' if weak else
+                                                              f'; tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world})')
+                                      + ', RCCL all_gather + rank-0 blend'),
                        'lr': [lr_h, lr_w], 'scale': scale, 'queries_per_step': out_pixels,
                        'parallelism': f'tile-shard x{world}'},
             'roofline': roof,
@@ -312,7 +318,7 @@ def main():
             finally:
                 hip_ops.set_head_mode(0)
             tile_lr = lr if args.workload == 'c2' else 192
-            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117}[args.workload]
+            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
             hb = {}
             for tag in ('local_attention', 'head_rows'):
                 wk = kernel_work(tag, (tile_lr * scale) ** 2, tile_lr * tile_lr)
