@@ -96,13 +96,17 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
     RUN(pad_reflect(feat_hwc, ld_feat, H, W, C, xp, p.Hp, p.Wp, s));
-    RUN(gemm_f32(xp, C, w->w_assembly, C, false, E, C, w->b_assembly, HWp, C, C, 1.f, CIAOSR_ACT_PRELU,
-                 w->slope_assembly, s, "csa_conv1x1"));
-    RUN(gemm_f32(xp, C, w->w_match1, C, false, M, p.Ch, w->b_match1, HWp, p.Ch, C, 1.f, CIAOSR_ACT_PRELU,
-                 w->slope_match1, s, "csa_conv1x1"));
+    // 1x1 convolutions + PReLU: the no-staging small GEMM on small maps
+    auto conv1x1 = [&](const float* src, const float* wgt, const float* bias, float slope, float* dst, int n_out, int rows) -> int {
+        if (gemm_small_ok(rows, n_out, C, C, C) && rows <= 4096)
+            return gemm_small_f32(src, C, wgt, C, bias, dst, n_out, nullptr, 0, nullptr, 0, rows, n_out, C, CIAOSR_ACT_PRELU, slope, s,
+                                  "csa_conv1x1");
+        return gemm_f32(src, C, wgt, C, false, dst, n_out, bias, rows, n_out, C, 1.f, CIAOSR_ACT_PRELU, slope, s, "csa_conv1x1");
+    };
+    RUN(conv1x1(xp, w->w_assembly, w->b_assembly, w->slope_assembly, E, C, HWp));
+    RUN(conv1x1(xp, w->w_match1, w->b_match1, w->slope_match1, M, p.Ch, HWp));
     RUN(avgpool2(xp, p.Hp, p.Wp, C, x2, s));
-    RUN(gemm_f32(x2, C, w->w_match2, C, false, R, p.Ch, w->b_match2, p.L, p.Ch, C, 1.f, CIAOSR_ACT_PRELU,
-                 w->slope_match2, s, "csa_conv1x1"));
+    RUN(conv1x1(x2, w->w_match2, w->b_match2, w->slope_match2, R, p.Ch, p.L));
     RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
     RUN(patch_rows(R, p.Ch, p.Hp / 2, p.Wp / 2, p.Ch, 3, 1, 1, p.Hp / 2, p.Wp / 2, Kn, 9 * p.Ch, 1, w->escape_nan, s,
                    "csa_patch_k"));

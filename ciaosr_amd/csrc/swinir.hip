@@ -235,6 +235,13 @@ extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, cons
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    // Linear on the token map: the no-staging small GEMM for maps of <= 16384 tokens, the implicit-GEMM 1x1 conv otherwise
+    auto linear = [&](const float* src, int ld_src, int K, const float* wgt, int ldw, const float* bias, int N, float* dst, int ld_dst,
+                      const float* res, int ld_res, int act, const char* tag) -> int {
+        if (gemm_small_ok((int)HW, N, K, ld_src, ldw))
+            return gemm_small_f32(src, ld_src, wgt, ldw, bias, dst, ld_dst, nullptr, 0, res, ld_res, (int)HW, N, K, act, 0.f, s, tag);
+        return conv2d_hwc(src, ld_src, Hp, Wp, K, wgt, ldw, bias, N, 1, dst, ld_dst, nullptr, 0, res, ld_res, act, 1.f, part, pf, s, tag);
+    };
     // zero the padded maps once: the pad columns [C, ld) / [hid, ldh) are never written afterwards
     if (hipMemsetAsync(x0, 0, (size_t)((char*)QKV - (char*)x0), s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
     if (hipMemsetAsync(Hb, 0, HW * ldh * sizeof(float), s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
@@ -262,21 +269,17 @@ extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, cons
             const int shift = b.shift;      // fixed at construction from the CONFIGURED input_resolution (:170-173), not the map size
             CIAOSR_CHECK_ARG(shift == 0 || b.mask);
             RUN(layernorm(tn, ld, Y, ld, b.ln1_w, b.ln1_b, (long)HW, C, s));
-            RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, b.qkv_w, ld, b.qkv_b, 3 * C, 1, QKV, ldq, nullptr, 0, nullptr, 0, CIAOSR_ACT_NONE, 1.f,
-                           part, pf, s, "swin_qkv"));
+            RUN(linear(Y, ld, ld, b.qkv_w, ld, b.qkv_b, 3 * C, QKV, ldq, nullptr, 0, CIAOSR_ACT_NONE, "swin_qkv"));
             {
                 WinAttnP ap{QKV, ldq, A, ld, b.bias, shift ? b.mask : nullptr, Hp, Wp, C, heads, d, ws, shift};
                 ProfScope prof("swin_window_attention", s);
                 hipLaunchKernelGGL(window_attention_kernel, dim3((Hp / ws) * (Wp / ws) * heads), dim3(256), 0, s, ap);
             }
             RUN(launch_status("window_attention"));
-            RUN(conv2d_hwc(A, ld, Hp, Wp, ld, b.proj_w, ld, b.proj_b, C, 1, tn, ld, nullptr, 0, tn, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
-                           "swin_proj"));
+            RUN(linear(A, ld, ld, b.proj_w, ld, b.proj_b, C, tn, ld, tn, ld, CIAOSR_ACT_NONE, "swin_proj"));
             RUN(layernorm(tn, ld, Y, ld, b.ln2_w, b.ln2_b, (long)HW, C, s));
-            RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, b.fc1_w, ld, b.fc1_b, hid, 1, Hb, ldh, nullptr, 0, nullptr, 0, CIAOSR_ACT_GELU, 1.f, part, pf,
-                           s, "swin_fc1"));
-            RUN(conv2d_hwc(Hb, ldh, Hp, Wp, ldh, b.fc2_w, ldh, b.fc2_b, C, 1, tn, ld, nullptr, 0, tn, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
-                           "swin_fc2"));
+            RUN(linear(Y, ld, ld, b.fc1_w, ld, b.fc1_b, hid, Hb, ldh, nullptr, 0, CIAOSR_ACT_GELU, "swin_fc1"));
+            RUN(linear(Hb, ldh, ldh, b.fc2_w, ldh, b.fc2_b, C, tn, ld, tn, ld, CIAOSR_ACT_NONE, "swin_fc2"));
         }
         // RSTB tail: conv3x3(residual_group(x)) + x -> the next group's input
         const ciaosr_conv_t& gc = w->group_conv[g];
