@@ -99,7 +99,7 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     // 1x1 convolutions + PReLU: the no-staging small GEMM on small maps
     auto conv1x1 = [&](const float* src, const float* wgt, const float* bias, float slope, float* dst, int n_out, int rows) -> int {
         if (gemm_small_ok(rows, n_out, C, C, C) && rows <= 4096)
-            return gemm_small_f32(src, C, wgt, C, bias, dst, n_out, nullptr, 0, nullptr, 0, rows, n_out, C, CIAOSR_ACT_PRELU, slope, s,
+            return gemm_small_f32(src, C, wgt, C, bias, dst, n_out, nullptr, 0, nullptr, 0, rows, n_out, C, CIAOSR_ACT_PRELU, slope, 1.f, s,
                                   "csa_conv1x1");
         return gemm_f32(src, C, wgt, C, false, dst, n_out, bias, rows, n_out, C, 1.f, CIAOSR_ACT_PRELU, slope, s, "csa_conv1x1");
     };
@@ -166,8 +166,12 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     RUN(fold(O, 36 * C, p.Hp, p.Wp, C, Y, s));
     // down conv 3x3 stride 2 pad 1 on Y [2Hp][2Wp][C], only for the H x W output pixels kept by the crop
     RUN(patch_rows(Y, C, 2 * p.Hp, 2 * p.Wp, C, 3, 2, 1, H, W, Yp, 9 * C, 0, 0.f, s, "csa_patch_down"));
-    RUN(gemm_f32(Yp, 9 * C, w->w_down, 9 * C, false, out, ld_out, w->b_down, H * W, C, 9 * C, 1.0f / 6.0f,
-                 CIAOSR_ACT_NONE, 0.f, s, "csa_down"));
+    if (gemm_small_ok(H * W, C, 9 * C, 9 * C, 9 * C) && H * W <= 4096)
+        RUN(gemm_small_f32(Yp, 9 * C, w->w_down, 9 * C, w->b_down, out, ld_out, nullptr, 0, nullptr, 0, H * W, C, 9 * C, CIAOSR_ACT_NONE,
+                           0.f, 1.0f / 6.0f, s, "csa_down"));
+    else
+        RUN(gemm_f32(Yp, 9 * C, w->w_down, 9 * C, false, out, ld_out, w->b_down, H * W, C, 9 * C, 1.0f / 6.0f,
+                     CIAOSR_ACT_NONE, 0.f, s, "csa_down"));
 #undef RUN
     return CIAOSR_OK;
 }

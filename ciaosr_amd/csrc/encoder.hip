@@ -151,14 +151,14 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
         // RDB output = x + lff(dense): goes to the global concat and is the next block's input
         if (gemm_small_ok((int)HW, G, cb, cb, cb))
             RUN(gemm_small_f32(x, cb, f.weight, cb, f.bias, Gc + (size_t)b * G, G * NB, b + 1 < NB ? xn : nullptr, cb, x, cb, (int)HW, G,
-                               cb, CIAOSR_ACT_NONE, 0.f, s, "enc_conv1x1"));
+                               cb, CIAOSR_ACT_NONE, 0.f, 1.f, s, "enc_conv1x1"));
         else
             RUN(conv2d_hwc(x, cb, H, W, cb, f.weight, cb, f.bias, G, 1, Gc + (size_t)b * G, G * NB,
                            b + 1 < NB ? xn : nullptr, cb, x, cb, CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
     }
     if (gemm_small_ok((int)HW, C, G * NB, G * NB, G * NB))
         RUN(gemm_small_f32(Gc, G * NB, w->gff0.weight, G * NB, w->gff0.bias, g0, C, nullptr, 0, nullptr, 0, (int)HW, C, G * NB,
-                           CIAOSR_ACT_NONE, 0.f, s, "enc_conv1x1"));
+                           CIAOSR_ACT_NONE, 0.f, 1.f, s, "enc_conv1x1"));
     else
         RUN(conv2d_hwc(Gc, G * NB, H, W, G * NB, w->gff0.weight, G * NB, w->gff0.bias, C, 1, g0, C, nullptr, 0, nullptr, 0,
                        CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));

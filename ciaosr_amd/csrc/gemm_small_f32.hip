@@ -28,7 +28,7 @@ struct GemmSmallP {
     float* C2; int ldc2; unsigned c2_bytes;
     const float* res; int ldres; unsigned res_bytes;
     int M, N, K, tiles_n, act;
-    float slope;
+    float slope, alpha;      // out = act((acc + bias) * alpha) + res
 };
 
 __device__ __forceinline__ float4 gs_load4(__amdgpu_buffer_rsrc_t rs, unsigned off) {
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
             const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
+        v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
         if (p.act == CIAOSR_ACT_RELU) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         } else if (p.act == CIAOSR_ACT_PRELU) {
@@ -161,7 +162,7 @@ bool gemm_small_ok(int M, int N, int K, int lda, int ldw) {
 }
 
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,
-                   const float* res, int ldres, int M, int N, int K, int act, float slope, hipStream_t s, const char* tag) {
+                   const float* res, int ldres, int M, int N, int K, int act, float slope, float alpha, hipStream_t s, const char* tag) {
     CIAOSR_CHECK_ARG(A && W && C && gemm_small_ok(M, N, K, lda, ldw) && (ldc & 3) == 0 && (ldc2 & 3) == 0 && (ldres & 3) == 0);
     CIAOSR_CHECK_ARG(aligned16(A) && aligned16(W) && aligned16(C) && (!C2 || aligned16(C2)) && (!res || aligned16(res)) &&
                      (!bias || aligned16(bias)));
@@ -175,7 +176,7 @@ int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float
     p.C = C; p.ldc = ldc; p.c_bytes = (unsigned)cb;
     p.C2 = C2; p.ldc2 = ldc2; p.c2_bytes = (unsigned)c2b;
     p.res = res; p.ldres = ldres; p.res_bytes = (unsigned)rb;
-    p.M = M; p.N = N; p.K = K; p.tiles_n = ceil_div(N, 32); p.act = act; p.slope = slope;
+    p.M = M; p.N = N; p.K = K; p.tiles_n = ceil_div(N, 32); p.act = act; p.slope = slope; p.alpha = alpha;
     ProfScope prof(tag ? tag : "gemm_small_f32", s);
     if (ceil_div(M, 64) * p.tiles_n < 192)        // too few 64-row workgroups to cover the chip: 32-row tiles
         hipLaunchKernelGGL(gemm_small_f32_kernel<1>, dim3(ceil_div(M, 32) * p.tiles_n), dim3(256), kGemmSmallLds, s, p);

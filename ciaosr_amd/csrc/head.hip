@@ -172,9 +172,9 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     if (gemm_small_ok(p.HW, p.wk0, p.D, p.Dv, w->k.ld[0]) && gemm_small_ok(p.HW, p.wv0, p.Dv, p.Dv, w->v.ld[0]) && p.HW <= 4096) {
         RUN(gemm_small_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], w->k.bias[0], Tk, p.wk0, nullptr, 0, nullptr, 0, p.HW, p.wk0, p.D,
-                           CIAOSR_ACT_NONE, 0.f, s, "head_table"));
+                           CIAOSR_ACT_NONE, 0.f, 1.f, s, "head_table"));
         RUN(gemm_small_f32(U, p.Dv, w->v.weight[0], w->v.ld[0], w->v.bias[0], Tv, p.wv0, nullptr, 0, nullptr, 0, p.HW, p.wv0, p.Dv,
-                           CIAOSR_ACT_NONE, 0.f, s, "head_table"));
+                           CIAOSR_ACT_NONE, 0.f, 1.f, s, "head_table"));
     } else {
         RUN(gemm_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], false, Tk, p.wk0, w->k.bias[0], p.HW, p.wk0, p.D, 1.f,
                      CIAOSR_ACT_NONE, 0.f, s, "head_table"));

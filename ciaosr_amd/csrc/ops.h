@@ -55,7 +55,7 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
 // gemm_small_f32.hip: few-MFLOP problems (no staging, K-sliced waves); gemm_small_ok tells whether a problem qualifies
 bool gemm_small_ok(int M, int N, int K, int lda, int ldw);
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,
-                   const float* res, int ldres, int M, int N, int K, int act, float slope, hipStream_t s, const char* tag);
+                   const float* res, int ldres, int M, int N, int K, int act, float slope, float alpha, hipStream_t s, const char* tag);
 // patch_ops.hip
 int nchw_to_hwc(const float* src, float* dst, int C, int H, int W, int ld, hipStream_t s);
 int hwc_to_nchw(const float* src, int ld, float* dst, int C, int H, int W, hipStream_t s);

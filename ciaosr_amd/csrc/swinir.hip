@@ -239,7 +239,7 @@ extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, cons
     auto linear = [&](const float* src, int ld_src, int K, const float* wgt, int ldw, const float* bias, int N, float* dst, int ld_dst,
                       const float* res, int ld_res, int act, const char* tag) -> int {
         if (gemm_small_ok((int)HW, N, K, ld_src, ldw))
-            return gemm_small_f32(src, ld_src, wgt, ldw, bias, dst, ld_dst, nullptr, 0, res, ld_res, (int)HW, N, K, act, 0.f, s, tag);
+            return gemm_small_f32(src, ld_src, wgt, ldw, bias, dst, ld_dst, nullptr, 0, res, ld_res, (int)HW, N, K, act, 0.f, 1.f, s, tag);
         return conv2d_hwc(src, ld_src, Hp, Wp, K, wgt, ldw, bias, N, 1, dst, ld_dst, nullptr, 0, res, ld_res, act, 1.f, part, pf, s, tag);
     };
     // zero the padded maps once: the pad columns [C, ld) / [hid, ldh) are never written afterwards
