@@ -9,7 +9,7 @@
 //     ahead of their use; no LDS, no barrier in the main loop;
 //   * one fixed-order K-slice reduction through 32 KB of LDS, then a float4 epilogue (bias, ReLU / exact GELU,
 //     residual, optional second destination).
-// Out-of-range rows / columns go through buffer descriptors (loads return 0, stores vanish).  K % 32 == 0.
+// Out-of-range rows / columns / k go through buffer descriptors (loads return 0, stores vanish).  K % 4 == 0.
 #include "ops.h"
 
 namespace ciaosr {
@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, p.w_bytes, 0x00020000);
 
     // this wave's K range: chunks [c0, c0 + cpw) of 8 consecutive k; a lane reads k = 8c + 4lh .. + 3
-    const int cpw = p.K >> 5;                 // K / 8 / 4
+    const int cpw = (((p.K + 7) >> 3) + 3) >> 2;   // ceil(ceil(K / 8) / 4); K % 4 == 0, loads past K read zeros
     const int c0 = w * cpw;
+    const int kl = 8 * c0 + 4 * lh;           // this lane's first k
     unsigned aoff[MT], woff;
 #pragma unroll
     for (int r = 0; r < MT; ++r) {
@@ -62,8 +63,8 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
         const int n = n0 + li;
         woff = n < p.N ? ((unsigned)n * (unsigned)p.ldw + (unsigned)(8 * c0 + 4 * lh)) * 4u : kOobGS;
     }
-    auto ld_a = [&](int r, int c) { return gs_load4(rs_a, aoff[r] == kOobGS ? kOobGS : aoff[r] + (unsigned)c * 32u); };
-    auto ld_w = [&](int c) { return gs_load4(rs_w, woff == kOobGS ? kOobGS : woff + (unsigned)c * 32u); };
+    auto ld_a = [&](int r, int c) { return gs_load4(rs_a, (aoff[r] == kOobGS || kl + 8 * c >= p.K) ? kOobGS : aoff[r] + (unsigned)c * 32u); };
+    auto ld_w = [&](int c) { return gs_load4(rs_w, (woff == kOobGS || kl + 8 * c >= p.K) ? kOobGS : woff + (unsigned)c * 32u); };
 
     f32x16 acc[MT];
 #pragma unroll
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
     }
 }
 
-// true when the problem fits this kernel's envelope (small M, K a multiple of 32, 16-byte aligned rows)
+// true when the problem fits this kernel's envelope (small M, K a multiple of 4, 16-byte aligned rows)
 bool gemm_small_ok(int M, int N, int K, int lda, int ldw) {
-    return M > 0 && M <= 16384 && N > 0 && (N & 3) == 0 && K >= 32 && (K & 31) == 0 && (lda & 3) == 0 && (ldw & 3) == 0;
+    return M > 0 && M <= 16384 && N > 0 && (N & 3) == 0 && K >= 32 && (K & 3) == 0 && (lda & 3) == 0 && (ldw & 3) == 0;
 }
 
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,
