@@ -343,12 +343,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
             zoff[mi] = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 4u : kOobF;
         }
         for (int u = w; u < n_units; u += 4) {
-            f32x16 acc[2][1];
-            zero_acc<1>(acc);
-            mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
-                        FNJ, 0, acc);
-            // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
-            // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
+            // the epilogue's gathers (bias, value rows) do not depend on the MFMA pass: request them first so their L2
+            // latency hides behind the 256 MFMAs of this unit
             float4 bv[4], vv[2][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -358,6 +354,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) vv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : voff[mi] + doff);
             }
+            f32x16 acc[2][1];
+            zero_acc<1>(acc);
+            mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
+                        FNJ, 0, acc);
+            // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
+            // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 float4 zsel = make_float4(0.f, 0.f, 0.f, 0.f);
