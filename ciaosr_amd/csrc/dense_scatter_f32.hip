@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
 
 int dense_scatter_small_max_pixels() {
     const char* e = getenv("CIAOSR_SCATTER_SMALL_MAX");         // read per call (tests / experiments)
-    return e ? atoi(e) : 16384;
+    return e ? atoi(e) : 18432;      // = 128 tiles of 12x12: every larger map has >= 128 tiles and takes dense_f32.hip
 }
 
 int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layers, const float* frag, const float* bias_all,

@@ -239,7 +239,7 @@ typedef struct ciaosr_rdn_weights {
     const float* const* scatter_weight; /* host array [num_blocks*num_layers] of device pointers */
     const float* scatter_bias;          /* device */
     /* optional: ciaosr_pack_fragments_f32(scatter_weight[i], ld = 576, N = 64*(num_layers-s), K = 576) per entry; maps of
-     * <= 16384 pixels then run the steps through the small-map kernel (dense_scatter_f32.hip) */
+     * <= 18432 pixels then run the steps through the small-map kernel (dense_scatter_f32.hip) */
     const float* const* scatter_frag;   /* host array [num_blocks*num_layers] of device pointers, or NULL */
 } ciaosr_rdn_weights_t;
 

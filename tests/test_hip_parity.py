@@ -387,6 +387,11 @@ def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw, monkeypatch):
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() < 2e-4 * max(scale, 1.0), ((got - want).abs().max().item(), scale)
     assert (got - scatter).abs().max().item() < 2e-4 * max(scale, 1.0)
+    # third implementation of the same layers: the generic tap-major convolution in scatter form (conv_f32.hip)
+    monkeypatch.delenv('CIAOSR_DENSE_F32_MIN_TILES')
+    monkeypatch.setenv('CIAOSR_SCATTER_SMALL_MAX', '0')
+    generic = gen.gen_feature(x.to(dev))[0].cpu()
+    assert (generic - want).abs().max().item() < 2e-4 * max(scale, 1.0)
 
 
 def _rdn_trunk_bf16_emulation(x, P, nb, nl):
