@@ -11,6 +11,7 @@
 // :247-250) is folded into the token index, the relative-position bias arrives pre-gathered per layer
 // [heads][N][N] and the shifted-window mask [nW][N][N] (calculate_mask :192-213) per map size, both built once on the
 // host.  Everything fp32 (exact-fp32 MFMA for q k^T and P v).
+#include "bf16_util.h"
 #include "ops.h"
 
 namespace ciaosr {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // ---- window attention ---------------------------------------------------------------------------------------
 struct WinAttnP {
-    const float* qkv; int ld_qkv;     // [HW][3C]: q | k | v, each [heads][d]  (q already scaled: the scale is folded into the weights)
+    const float* qkv; int ld_qkv; unsigned qkv_bytes;   // [HW][3C]: q | k | v, each [heads][d]  (q already scaled: the scale is folded into the weights)
     float* out; int ld_out;           // [HW][ld]: column h*d + e
     const float* bias;                // [heads][N][N] relative-position bias of this layer
     const float* mask;                // [nW][N][N] or null (unshifted layer)
@@ -110,14 +111,32 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnP p) {
         stok[t] = tok;
     }
     __syncthreads();
-    for (int i = t; i < WMAXN * WMAXD; i += 256) {
-        const int n = i >> 5, e = i & 31;
-        float q = 0.f, k = 0.f, v = 0.f;
-        if (n < N && e < p.d) {
-            const float* r = p.qkv + (size_t)stok[n] * p.ld_qkv + head * p.d + e;
-            q = r[0]; k = r[p.C]; v = r[2 * p.C];
+    {   // q, k, v of the window's tokens -> LDS.  All 12 loads of a thread are issued before the first LDS store (a
+        // load-store loop makes hipcc wait for every load in turn: 8 dependent HBM round trips, ~16 us)
+        // (buffer loads with an out-of-range offset for the padding: no branch around a load)
+        const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.qkv), 0, p.qkv_bytes, 0x00020000);
+        typedef int i32x2w __attribute__((ext_vector_type(2)));
+        float2 vq[4], vk[4], vv[4];
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            const int i = t + 256 * sI, n = i >> 4, e = 2 * (i & 15);
+            const unsigned off = (n < N && e < p.d) ? ((unsigned)stok[n] * (unsigned)p.ld_qkv + (unsigned)(head * p.d + e)) * 4u : 0xFFFFFFF0u;
+            const unsigned offk = off == 0xFFFFFFF0u ? off : off + (unsigned)p.C * 4u;
+            const unsigned offv = off == 0xFFFFFFF0u ? off : off + (unsigned)p.C * 8u;
+            const i32x2w a = __builtin_amdgcn_raw_buffer_load_b64(rs_q, (int)off, 0, 0);
+            const i32x2w b = __builtin_amdgcn_raw_buffer_load_b64(rs_q, (int)offk, 0, 0);
+            const i32x2w c = __builtin_amdgcn_raw_buffer_load_b64(rs_q, (int)offv, 0, 0);
+            vq[sI] = make_float2(__int_as_float(a.x), __int_as_float(a.y));
+            vk[sI] = make_float2(__int_as_float(b.x), __int_as_float(b.y));
+            vv[sI] = make_float2(__int_as_float(c.x), __int_as_float(c.y));
         }
-        sq[n][e] = q; sk[n][e] = k; sv[n][e] = v;
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) {
+            const int i = t + 256 * sI, n = i >> 4, e = 2 * (i & 15);
+            sq[n][e] = vq[sI].x; sq[n][e + 1] = vq[sI].y;
+            sk[n][e] = vk[sI].x; sk[n][e + 1] = vk[sI].y;
+            sv[n][e] = vv[sI].x; sv[n][e + 1] = vv[sI].y;
+        }
     }
     __syncthreads();
     {   // scores tile (mi, ni) of this wave: D[m][n], lane holds column j = 32 ni + li, rows 8 (r >> 2) + 4 lh + (r & 3)
@@ -129,24 +148,41 @@ __global__ __launch_bounds__(256) void window_attention_kernel(WinAttnP p) {
         for (int ks = 0; ks < WMAXD / 2; ++ks)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sq[32 * mi + li][2 * ks + lh], sk[32 * ni + li][2 * ks + lh], acc, 0, 0, 0);
         const int j = 32 * ni + li;
+        float bb[16], mm[16];                              // bias and mask of the 16 rows: all requested before use
+        const unsigned nn4 = (unsigned)N * (unsigned)N * 4u;
+        const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias) + (size_t)head * N * N, 0, nn4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_m =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.mask ? p.mask + (size_t)win * N * N : p.bias), 0, p.mask ? nn4 : 0u, 0x00020000);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * mi + 8 * (r >> 2) + 4 * lh + (r & 3);
-            float a = -INFINITY;
-            if (i < N && j < N) {
-                a = acc[r] + p.bias[((size_t)head * N + i) * N + j];
-                if (p.mask) a += p.mask[((size_t)win * N + i) * N + j];
-            }
-            sp[i][j] = a;
+            const unsigned off = (i < N && j < N) ? (unsigned)(i * N + j) * 4u : 0xFFFFFFF0u;
+            bb[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_b, (int)off, 0, 0));
+            mm[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_m, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * mi + 8 * (r >> 2) + 4 * lh + (r & 3);
+            sp[i][j] = (i < N && j < N) ? acc[r] + bb[r] + mm[r] : -INFINITY;
         }
     }
     __syncthreads();
-    for (int i = w; i < WMAXN; i += 4) {                  // softmax, one wavefront per row (rows >= N become zeros)
-        const float v = sp[i][lane];
-        const float m = wmax64(v);
-        const float e = (i < N && lane < N) ? expf(v - m) : 0.f;
-        const float sum = wsum64(e);
-        sp[i][lane] = i < N ? e / sum : 0.f;
+    {   // softmax: 4 adjacent lanes per row (16 columns each), quad reductions through DPP
+        const int i = t >> 2, c0 = (t & 3) * 16;
+        float v[16];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { v[c] = sp[i][c0 + c]; m = fmaxf(m, v[c]); }
+        m = fmaxf(m, quad_xor1(m));
+        m = fmaxf(m, quad_xor2(m));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { v[c] = (i < N && c0 + c < N) ? expf(v[c] - m) : 0.f; sum += v[c]; }
+        sum += quad_xor1(sum);
+        sum += quad_xor2(sum);
+        const float inv = i < N ? 1.0f / sum : 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sp[i][c0 + c] = v[c] * inv;
     }
     __syncthreads();
     if (w < 2) {                                          // O tile mi = w: D[m][e], lane holds channel e = li
@@ -210,6 +246,7 @@ extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, cons
     CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
     const int C = w->embed_dim, heads = w->num_heads, ws = w->window_size, hid = w->hidden;
     CIAOSR_CHECK_ARG(C > 0 && (C & 3) == 0 && heads > 0 && C % heads == 0 && C / heads <= WMAXD && ws > 0 && ws * ws <= WMAXN);
+    CIAOSR_CHECK_ARG(((C / heads) & 1) == 0);                        // 8-byte q/k/v loads in the window-attention kernel
     CIAOSR_CHECK_ARG(hid > 0 && (hid & 3) == 0 && w->num_groups >= 1 && w->depth >= 1 && w->blocks && w->group_conv);
     CIAOSR_CHECK_ARG(w->pe_norm_w && w->pe_norm_b && w->norm_w && w->norm_b);
     const int ld = swin_ld(C), ldh = swin_ld(hid), d = C / heads;
@@ -271,7 +308,7 @@ extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, cons
             RUN(layernorm(tn, ld, Y, ld, b.ln1_w, b.ln1_b, (long)HW, C, s));
             RUN(linear(Y, ld, ld, b.qkv_w, ld, b.qkv_b, 3 * C, QKV, ldq, nullptr, 0, CIAOSR_ACT_NONE, "swin_qkv"));
             {
-                WinAttnP ap{QKV, ldq, A, ld, b.bias, shift ? b.mask : nullptr, Hp, Wp, C, heads, d, ws, shift};
+                WinAttnP ap{QKV, ldq, (unsigned)(HW * (size_t)ldq * 4), A, ld, b.bias, shift ? b.mask : nullptr, Hp, Wp, C, heads, d, ws, shift};
                 ProfScope prof("swin_window_attention", s);
                 hipLaunchKernelGGL(window_attention_kernel, dim3((Hp / ws) * (Wp / ws) * heads), dim3(256), 0, s, ap);
             }

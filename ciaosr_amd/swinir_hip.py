@@ -41,7 +41,8 @@ class PackedSwinIR:
             ws = n.window_size
             ok = isinstance(n.layers[0].conv, torch.nn.Conv2d) and isinstance(n.conv_after_body, torch.nn.Conv2d)
             ok = ok and n.conv_first.in_channels == 3 and c % 4 == 0 and blk.mlp.fc1.out_features % 4 == 0
-            ok = ok and ws * ws <= 64 and c % blk.num_heads == 0 and c // blk.num_heads <= 32 and n.patch_embed.norm is not None
+            ok = ok and ws * ws <= 64 and c % blk.num_heads == 0 and c // blk.num_heads <= 32 and (c // blk.num_heads) % 2 == 0
+            ok = ok and n.patch_embed.norm is not None
             depths = {len(l.residual_group.blocks) for l in n.layers}
             return ok and len(depths) == 1 and all(b.window_size == ws for l in n.layers for b in l.residual_group.blocks)
         except (AttributeError, IndexError):
