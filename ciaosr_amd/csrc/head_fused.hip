@@ -390,17 +390,24 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     const int qbase = blockIdx.x * FBM;
 
     // layer 0: K = Dv streamed through X in chunks of 256 columns
+    const __amdgpu_buffer_rsrc_t rs_zin =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
     f32x16 acc[2][2];
     zero_acc<2>(acc);
     for (int k0 = 0; k0 < p.Dv; k0 += FH) {
         const int kc = min(FH, p.Dv - k0);          // multiple of 8
         if (k0 > 0) __syncthreads();                 // previous chunk fully consumed
-        for (int idx = t; idx < FBM * (FH / 4); idx += 256) {
-            const int r = idx >> 6, c4 = (idx & 63) * 4;
-            const int ql = qbase + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ql < p.nq && c4 < kc) v = *reinterpret_cast<const float4*>(p.Z + (size_t)ql * p.ldz + k0 + c4);
-            *reinterpret_cast<float4*>(X + r * FLD + c4) = v;
+        {   // stage the 64 x 256 chunk of Z: 16 float4 per thread, all requested before the first LDS store, through a
+            // buffer descriptor (a guarded load inside a load -> store loop costs one HBM round trip per iteration)
+            const int c4 = (t & 63) * 4;
+            float4 zv[FBM / 4];
+#pragma unroll
+            for (int i = 0; i < FBM / 4; ++i) {
+                const int ql = qbase + (t >> 6) + 4 * i;
+                zv[i] = bload4(rs_zin, (ql < p.nq && c4 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c4)) * 4u : kOobF);
+            }
+#pragma unroll
+            for (int i = 0; i < FBM / 4; ++i) *reinterpret_cast<float4*>(X + ((t >> 6) + 4 * i) * FLD + c4) = zv[i];
         }
         __syncthreads();
         mma_pass<2>(X + li * FLD + 4 * lh,
