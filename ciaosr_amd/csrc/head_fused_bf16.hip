@@ -362,14 +362,24 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
     for (int k0 = 0; k0 < p.Dv; k0 += HH) {
         const int kc = min(HH, p.Dv - k0);          // multiple of 8; the fragment stream is zero-padded to 16
         if (k0 > 0) __syncthreads();
-        for (int idx = t; idx < HBM_ * (HH / 4); idx += 256) {
-            const int r = idx >> 6, c4 = (idx & 63) * 4;
-            const int ql = qbase + r;
-            const float4 v = hload4(rs_z, (ql < p.nq && c4 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c4)) * 4u : kOobH);
-            uint2 o;
-            o.x = pack2(v.x, v.y);
-            o.y = pack2(v.z, v.w);
-            *reinterpret_cast<uint2*>(X + r * HLD + c4) = o;
+        {   // 128 x 256 chunk of Z -> bf16 in LDS: 32 float4 per thread in batches of 8, every batch fully in flight
+            const int c4 = (t & 63) * 4;
+#pragma unroll
+            for (int b = 0; b < HBM_ / 32; ++b) {
+                float4 zv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int ql = qbase + (t >> 6) + 4 * (8 * b + i);
+                    zv[i] = hload4(rs_z, (ql < p.nq && c4 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c4)) * 4u : kOobH);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    uint2 o;
+                    o.x = pack2(zv[i].x, zv[i].y);
+                    o.y = pack2(zv[i].z, zv[i].w);
+                    *reinterpret_cast<uint2*>(X + ((t >> 6) + 4 * (8 * b + i)) * HLD + c4) = o;
+                }
+            }
         }
         __syncthreads();
         mma_pass16<2>(X + li * HLD + 8 * lh,
