@@ -144,15 +144,23 @@ __device__ __forceinline__ void build_rows16(unsigned short* X, const FusedChain
     float4 tw[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
-    for (int r = t >> 6; r < HBM_; r += 4) {
-        const float4 tv = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[r] * HH)[n4];
-        const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
-        uint2 o;
-        o.x = pack2(fmaxf(tv.x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f),
-                    fmaxf(tv.y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f));
-        o.y = pack2(fmaxf(tv.z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f),
-                    fmaxf(tv.w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f));
-        *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
+    // 32 rows per thread in batches of 8 table gathers, each batch fully in flight before it is used
+#pragma unroll
+    for (int b = 0; b < HBM_ / 32; ++b) {
+        float4 tv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tv[i] = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[(t >> 6) + 4 * (8 * b + i)] * HH)[n4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (t >> 6) + 4 * (8 * b + i);
+            const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
+            uint2 o;
+            o.x = pack2(fmaxf(tv[i].x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f),
+                        fmaxf(tv[i].y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f));
+            o.y = pack2(fmaxf(tv[i].z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f),
+                        fmaxf(tv[i].w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f));
+            *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
+        }
     }
 }
 
