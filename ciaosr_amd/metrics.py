@@ -4,9 +4,7 @@
 in-repo copy mmedited/core/evaluation/metrics.py:181-226 and SURVEY Appendix A.6.
 Y channel = mmcv.bgr2ycbcr(img/255, y_only=True)*255 on BGR uint8 images.
 """
-import math
 import numpy as np
-import torch
 
 
 def tensor2img(tensor, out_type=np.uint8, min_max=(0, 1)):

@@ -13,7 +13,6 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops, metrics
-from .coords import make_coord, make_cell
 from .registry import build_backbone, build_loss
 
 
