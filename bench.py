@@ -121,9 +121,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help='fp32 (default): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs in the fused head only')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c3tile', 'c3', 'c3s'],
+    ap.add_argument('--workload', default='c2', choices=['c2', 'c2q', 'c3tile', 'c3', 'c3s'],
                     help='c2 (default, BASELINE configs[1]): LR 48x48; c3tile: one 192x192 LR tile; c3: LR 1356x2040 (117 tiles); '
-                         'c3s: LR 339x510 (6 tiles).  c3 / c3s with --gpus N > 1 shard the tiles of the ONE image over the ranks (C4, strong scaling)')
+                         'c3s: LR 339x510 (6 tiles); c2q: the ONE 48x48 image of C2 with its query range sharded over the ranks after a '
+                         'broadcast of the encoder features (strong scaling).  c3 / c3s with --gpus N > 1 shard the tiles of the ONE image over the ranks (C4, strong scaling)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -148,7 +149,8 @@ def main():
 
     from ciaosr_amd import hip_ops, _lib
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
-    from ciaosr_amd.tile_shard import clip_test_distributed
+    from ciaosr_amd.tile_shard import clip_test_distributed, predict_query_sharded
+    from ciaosr_amd.coords import make_coord, make_cell
     _lib.load()
     hip_ops.set_precision(args.precision)
 
@@ -160,15 +162,24 @@ def main():
     model = rdn_ciaosr(test_cfg)
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
-    lr_h, lr_w = {'c2': (lr, lr * world), 'c3tile': (192, 192), 'c3': (1356, 2040), 'c3s': (339, 510)}[args.workload]
+    lr_h, lr_w = {'c2': (lr, lr * world), 'c2q': (lr, lr), 'c3tile': (192, 192), 'c3': (1356, 2040), 'c3s': (339, 510)}[args.workload]
     lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
     lq = lq.to(dev)
     out_pixels = (lr_h * scale) * (lr_w * scale)
+
+    if args.workload == 'c2q':
+        q_coord = make_coord((lr_h * scale, lr_w * scale)).unsqueeze(0).to(dev)
+        q_cell = make_cell((lr_h * scale, lr_w * scale)).unsqueeze(0).to(dev)
 
     def step():
         if world == 1:
             return model.restore(lq)
         x = model.normalize(lq)
+        if args.workload == 'c2q':
+            pred = predict_query_sharded(model, x, q_coord, q_cell, rank, world)
+            if rank == 0:
+                return hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
+            return None
         pred = clip_test_distributed(model, x, rank, world)
         if rank == 0:
             return hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
@@ -214,7 +225,15 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.ciaosr_prof_enable(0)
     prof_steps = args.steps
-    if dominant and not live:
+    # the separate pass contains collectives when world > 1: every rank must take it if ANY rank needs it (ranks can
+    # disagree on the dominant kernel, e.g. the query-sharded mode runs the encoder on rank 0 only)
+    need_pass = int(bool(dominant) and not live)
+    if world > 1:
+        flag = torch.tensor([need_pass], device=dev if backend == 'nccl' else 'cpu', dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        need_pass = int(flag.item())
+    if need_pass:
+        live = False
         prof_steps = min(args.steps, 10)
         lib.ciaosr_prof_reset()
         lib.ciaosr_prof_enable(1)
@@ -234,8 +253,8 @@ def main():
         ms = elapsed / args.steps * 1e3
         roof = None
         if dominant and dominant in prof_dom:
-            tile_lr = lr if args.workload == 'c2' else 192
-            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
+            tile_lr = lr if args.workload in ('c2', 'c2q') else 192
+            n_tiles = {'c2': 1, 'c2q': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
             if world > 1 and not weak:
                 n_tiles = (n_tiles + world - 1) // world          # tiles t = 0, R, 2R, ... run on rank 0 (whose kernels are timed)
             Q, HW = (tile_lr * scale) ** 2, tile_lr * tile_lr
@@ -293,14 +312,16 @@ def main():
             'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs in the head (fp32 accumulate); encoder + cs_attn f32',
             'data': 'synthetic',
             'config': {'workload': {'c2': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init weights, fp32',
+                                    'c2q': 'C2 (query-sharded): RDN-CiaoSR (c64b16) x4, ONE LR 48x48 -> 192x192 image, random-init weights, fp32',
                                     'c3tile': 'C3 unit: RDN-CiaoSR x4, one 192x192 LR tile -> 768x768, random-init weights, fp32',
                                     'c3': 'C3: RDN-CiaoSR x4, LR 1356x2040 -> 5424x8160, 117 tiles of 192 (overlap 32), random-init weights, fp32',
                                     'c3s': 'C3 (DIV2K-val pairing): RDN-CiaoSR x4, LR 339x510 -> 1356x2040, 6 tiles of 192 (overlap 32), random-init weights, fp32'}[args.workload]
-                                   + ('' if world == 1 else (f'; one {lr}x{lr * world} LR image, {world} tiles sharded one per GPU' if weak else
+                                   + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs' if args.workload == 'c2q' else
+                                                              f'; one {lr}x{lr * world} LR image, {world} tiles sharded one per GPU' if weak else
                                                               f'; tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world})')
-                                      + ', RCCL all_gather + rank-0 blend'),
+                                      + (', RCCL all_gather of the RGB slices' if args.workload == 'c2q' else ', RCCL all_gather + rank-0 blend')),
                        'lr': [lr_h, lr_w], 'scale': scale, 'queries_per_step': out_pixels,
-                       'parallelism': f'tile-shard x{world}'},
+                       'parallelism': (f'query-shard x{world}' if args.workload == 'c2q' else f'tile-shard x{world}')},
             'roofline': roof,
             'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
                 prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
@@ -317,8 +338,8 @@ def main():
                 st = hip_ops.profile.results()
             finally:
                 hip_ops.set_head_mode(0)
-            tile_lr = lr if args.workload == 'c2' else 192
-            n_tiles = {'c2': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
+            tile_lr = lr if args.workload in ('c2', 'c2q') else 192
+            n_tiles = {'c2': 1, 'c2q': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
             hb = {}
             for tag in ('local_attention', 'head_rows'):
                 wk = kernel_work(tag, (tile_lr * scale) ** 2, tile_lr * tile_lr)
