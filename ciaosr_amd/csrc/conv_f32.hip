@@ -453,8 +453,8 @@ template <int TM, int TN>
 static void launch_tile(const ConvP& p, int tiles, hipStream_t s) {
     constexpr size_t lds = ConvCfg<TM, TN>::lds;
     auto kernel = conv_gemm_kernel<TM, TN>;
-    static bool attr = false;
-    if (!attr) { allow_big_lds(kernel, lds); attr = true; }
+    static const bool attr = (allow_big_lds(kernel, lds), true);      // thread-safe one-time setup (C++11 static init)
+    (void)attr;
     hipLaunchKernelGGL(kernel, dim3(tiles, p.splitk), dim3(512), lds, s, p);
 }
 
@@ -485,8 +485,8 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
         p.partial = partial;
         {
             ProfScope prof(tag, s);
-            static bool attr = false;
-            if (!attr) { allow_big_lds(conv3x3_halo_kernel, kHaloLds); attr = true; }
+            static const bool attr = (allow_big_lds(conv3x3_halo_kernel, kHaloLds), true);      // thread-safe one-time setup (C++11 static init)
+            (void)attr;
             hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, p.splitk), dim3(512), kHaloLds, s, p);
         }
         int rc = launch_status("conv3x3_halo");

@@ -227,8 +227,8 @@ int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int
     p.wf = reinterpret_cast<const uint4*>(frag16); p.nks = 9 * 64 * (l + 1) / 16;
     p.bias = bias;
     p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
-    static bool attr = false;
-    if (!attr) { allow_big_lds(dense_bf16_kernel, kDenseLds); attr = true; }
+    static const bool attr = (allow_big_lds(dense_bf16_kernel, kDenseLds), true);      // thread-safe one-time setup (C++11 static init)
+    (void)attr;
     ProfScope prof("enc_dense_bf16", s);
     hipLaunchKernelGGL(dense_bf16_kernel, dim3(dense_bf16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     return launch_status("dense_bf16");

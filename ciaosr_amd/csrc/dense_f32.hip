@@ -208,8 +208,8 @@ int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, c
     p.wf = reinterpret_cast<const float4*>(frag); p.nj = 9 * 64 * (l + 1) / 8;
     p.bias = bias;
     p.col_out = 64 * (l + 1);
-    static bool attr = false;
-    if (!attr) { allow_big_lds(dense_f32_kernel, kDenseF32Lds); attr = true; }
+    static const bool attr = (allow_big_lds(dense_f32_kernel, kDenseF32Lds), true);      // thread-safe one-time setup (C++11 static init)
+    (void)attr;
     ProfScope prof("enc_dense_gather", s);
     hipLaunchKernelGGL(dense_f32_kernel, dim3(dense_f32_tiles(H, W)), dim3(256), kDenseF32Lds, s, p);
     return launch_status("dense_f32");

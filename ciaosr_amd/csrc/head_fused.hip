@@ -482,8 +482,8 @@ int pack_fragments(const float* W, int ld, int N, int K, float* P, hipStream_t s
 constexpr size_t kFusedLds = (size_t)(FBM * FLD + FBM * 4 + 4 * FBM + FBM) * sizeof(float) + (FBM + 16 + FBM) * sizeof(int);
 
 int head_kv_fused(const FusedKVP& p, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) { allow_big_lds(head_kv_fused_kernel, kFusedLds); attr = true; }
+    static const bool attr = (allow_big_lds(head_kv_fused_kernel, kFusedLds), true);      // thread-safe one-time setup (C++11 static init)
+    (void)attr;
     ProfScope prof("head_kv_fused", s);
     hipLaunchKernelGGL(head_kv_fused_kernel, dim3(ceil_div(p.nq, FBM / 4)), dim3(256), kFusedLds, s, p);
     return launch_status("head_kv_fused");
@@ -491,8 +491,8 @@ int head_kv_fused(const FusedKVP& p, hipStream_t s) {
 
 int head_decode_fused(const FusedQP& p, hipStream_t s) {
     const size_t lds = (size_t)FBM * FLD * sizeof(float);
-    static bool attr = false;
-    if (!attr) { allow_big_lds(head_decode_fused_kernel, lds); attr = true; }
+    static const bool attr = (allow_big_lds(head_decode_fused_kernel, lds), true);      // thread-safe one-time setup (C++11 static init)
+    (void)attr;
     ProfScope prof("head_decode_fused", s);
     hipLaunchKernelGGL(head_decode_fused_kernel, dim3(ceil_div(p.nq, FBM)), dim3(256), lds, s, p);
     return launch_status("head_decode_fused");
