@@ -56,6 +56,16 @@ static bool conv_ok(const ciaosr_conv_t& c, int cin, int cout, int k) {
     return c.weight && c.bias && c.cin == cin && c.cout == cout && c.ksize == k;
 }
 
+// 3x3 trunk convolution: the one-launch small-map kernel when the layer has fragment-packed weights, else the generic path
+static int conv3(const float* src, int ld_src, int H, int W, const ciaosr_conv_t& c, float* dst, int ld_dst, const float* res,
+                 int ld_res, int act, float alpha, float* part, size_t pf, hipStream_t s) {
+    if (c.frag && conv3x3_small_ok(H, W, c.cin, c.cout, ld_src, act))
+        return conv3x3_small(src, ld_src, H, W, c.cin, c.frag, c.bias, c.cout, dst, ld_dst, nullptr, 0, res, ld_res, act, alpha, s,
+                             "enc_conv3x3");
+    return conv2d_hwc(src, ld_src, H, W, c.cin, c.weight, 9 * c.cin, c.bias, c.cout, 3, dst, ld_dst, nullptr, 0, res, ld_res, act,
+                      alpha, part, pf, s, "enc_conv3x3");
+}
+
 }  // namespace ciaosr
 
 using namespace ciaosr;
@@ -106,8 +116,7 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
     RUN(first_conv(x_nchw, H, W, w->sfe1, img4, rows, sfe1, C, s));
     // sfe2 -> block 0 input (columns [0, C) of X[0])
-    RUN(conv2d_hwc(sfe1, C, H, W, C, w->sfe2.weight, 9 * C, w->sfe2.bias, C, 3, X[0], cb, nullptr, 0, nullptr, 0,
-                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
+    RUN(conv3(sfe1, C, H, W, w->sfe2, X[0], cb, nullptr, 0, CIAOSR_ACT_NONE, 1.f, part, pf, s));
     for (int b = 0; b < NB; ++b) {
         float* x = X[b & 1];
         float* xn = X[(b + 1) & 1];
@@ -162,8 +171,7 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     else
         RUN(conv2d_hwc(Gc, G * NB, H, W, G * NB, w->gff0.weight, G * NB, w->gff0.bias, C, 1, g0, C, nullptr, 0, nullptr, 0,
                        CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
-    RUN(conv2d_hwc(g0, C, H, W, C, w->gff1.weight, 9 * C, w->gff1.bias, C, 3, feat_hwc, C, nullptr, 0, sfe1, C,
-                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
+    RUN(conv3(g0, C, H, W, w->gff1, feat_hwc, C, sfe1, C, CIAOSR_ACT_NONE, 1.f, part, pf, s));
 #undef RUN
     return CIAOSR_OK;
 }
@@ -212,14 +220,11 @@ extern "C" int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const 
     for (int i = 0; i < NB; ++i) {
         CIAOSR_CHECK_ARG(conv_ok(w->conv1[i], C, C, 3) && conv_ok(w->conv2[i], C, C, 3));
         // ResidualBlockNoBN: x + conv2(relu(conv1(x))) * res_scale
-        RUN(conv2d_hwc(cur, C, H, W, C, w->conv1[i].weight, 9 * C, w->conv1[i].bias, C, 3, tmp, C, nullptr, 0, nullptr, 0,
-                       CIAOSR_ACT_RELU, 1.f, part, pf, s, "enc_conv3x3"));
-        RUN(conv2d_hwc(tmp, C, H, W, C, w->conv2[i].weight, 9 * C, w->conv2[i].bias, C, 3, pp[i & 1], C, nullptr, 0, cur, C,
-                       CIAOSR_ACT_NONE, w->res_scale, part, pf, s, "enc_conv3x3"));
+        RUN(conv3(cur, C, H, W, w->conv1[i], tmp, C, nullptr, 0, CIAOSR_ACT_RELU, 1.f, part, pf, s));
+        RUN(conv3(tmp, C, H, W, w->conv2[i], pp[i & 1], C, cur, C, CIAOSR_ACT_NONE, w->res_scale, part, pf, s));
         cur = pp[i & 1];
     }
-    RUN(conv2d_hwc(cur, C, H, W, C, w->conv_after_body.weight, 9 * C, w->conv_after_body.bias, C, 3, feat_hwc, C, nullptr, 0,
-                   first, C, CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv3x3"));
+    RUN(conv3(cur, C, H, W, w->conv_after_body, feat_hwc, C, first, C, CIAOSR_ACT_NONE, 1.f, part, pf, s));
 #undef RUN
     return CIAOSR_OK;
 }

@@ -322,12 +322,19 @@ extern "C" int ciaosr_swinir_forward_f32(const float* x_nchw, int H, int W, cons
         const ciaosr_conv_t& gc = w->group_conv[g];
         CIAOSR_CHECK_ARG(cv_ok(gc, ld, C, 3));
         // in place over the group input: the epilogue reads res[row][col] and writes dst[row][col] from the same lane
-        RUN(conv2d_hwc(tn, ld, Hp, Wp, ld, gc.weight, 9 * ld, gc.bias, C, 3, t, ld, nullptr, 0, t, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
-                       "swin_group_conv"));
+        if (gc.frag && conv3x3_small_ok(Hp, Wp, ld, C, ld, CIAOSR_ACT_NONE))
+            RUN(conv3x3_small(tn, ld, Hp, Wp, ld, gc.frag, gc.bias, C, t, ld, nullptr, 0, t, ld, CIAOSR_ACT_NONE, 1.f, s, "swin_group_conv"));
+        else
+            RUN(conv2d_hwc(tn, ld, Hp, Wp, ld, gc.weight, 9 * ld, gc.bias, C, 3, t, ld, nullptr, 0, t, ld, CIAOSR_ACT_NONE, 1.f, part, pf, s,
+                           "swin_group_conv"));
     }
     RUN(layernorm(T[cur], ld, Y, ld, w->norm_w, w->norm_b, (long)HW, C, s));
-    RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, w->conv_after_body.weight, 9 * ld, w->conv_after_body.bias, C, 3, A, ld, nullptr, 0, x0, ld,
-                   CIAOSR_ACT_NONE, 1.f, part, pf, s, "swin_conv_after_body"));
+    if (w->conv_after_body.frag && conv3x3_small_ok(Hp, Wp, ld, C, ld, CIAOSR_ACT_NONE))
+        RUN(conv3x3_small(Y, ld, Hp, Wp, ld, w->conv_after_body.frag, w->conv_after_body.bias, C, A, ld, nullptr, 0, x0, ld, CIAOSR_ACT_NONE,
+                          1.f, s, "swin_conv_after_body"));
+    else
+        RUN(conv2d_hwc(Y, ld, Hp, Wp, ld, w->conv_after_body.weight, 9 * ld, w->conv_after_body.bias, C, 3, A, ld, nullptr, 0, x0, ld,
+                       CIAOSR_ACT_NONE, 1.f, part, pf, s, "swin_conv_after_body"));
     {
         ProfScope prof("swin_crop", s);
         const long n = (long)H * W * (C >> 2);

@@ -9,7 +9,7 @@ import torch
 from . import _lib, hip_ops
 
 
-def _pack_conv(conv, keep, pad_cin_to=None, frag16=False):
+def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False):
     w = conv.weight.detach().float()
     co, ci, kh, kw = w.shape
     w = w.permute(0, 2, 3, 1)
@@ -31,6 +31,13 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False):
         keep.append(f16)
         st.frag16 = f16.data_ptr()
         # exact-fp32 MFMA fragments for the halo-resident fp32 kernel of big maps (dense_f32.hip)
+        f32 = torch.empty(_lib.load().ciaosr_fragment_floats(n_, k_), dtype=torch.float32, device=w.device)
+        _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f32), hip_ops.stream_ptr())
+        keep.append(f32)
+        st.frag = f32.data_ptr()
+    elif frag:
+        # exact-fp32 MFMA fragments only: the one-launch small-map 3x3 kernel (conv_small_f32.hip)
+        n_, k_ = w.shape
         f32 = torch.empty(_lib.load().ciaosr_fragment_floats(n_, k_), dtype=torch.float32, device=w.device)
         _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f32), hip_ops.stream_ptr())
         keep.append(f32)
@@ -64,9 +71,9 @@ class PackedEncoder:
             st.growth = n.rdbs[0].layers[0].conv.out_channels
             st.num_blocks, st.num_layers = nb, nl
             st.sfe1 = _pack_conv(n.sfe1, keep, pad_cin_to=4)
-            st.sfe2 = _pack_conv(n.sfe2, keep)
+            st.sfe2 = _pack_conv(n.sfe2, keep, frag=True)
             st.gff0 = _pack_conv(n.gff[0], keep)
-            st.gff1 = _pack_conv(n.gff[1], keep)
+            st.gff1 = _pack_conv(n.gff[1], keep, frag=True)
             dense = (_lib.ConvT * (nb * nl))()
             lff = (_lib.ConvT * nb)()
             for b in range(nb):
@@ -107,12 +114,12 @@ class PackedEncoder:
             st.num_blocks = nb
             st.res_scale = float(n.body[0].res_scale) if nb else 1.0
             st.conv_first = _pack_conv(n.conv_first, keep, pad_cin_to=4)
-            st.conv_after_body = _pack_conv(n.conv_after_body, keep)
+            st.conv_after_body = _pack_conv(n.conv_after_body, keep, frag=True)
             c1 = (_lib.ConvT * max(nb, 1))()
             c2 = (_lib.ConvT * max(nb, 1))()
             for b in range(nb):
-                c1[b] = _pack_conv(n.body[b].conv1, keep)
-                c2[b] = _pack_conv(n.body[b].conv2, keep)
+                c1[b] = _pack_conv(n.body[b].conv1, keep, frag=True)
+                c2[b] = _pack_conv(n.body[b].conv2, keep, frag=True)
             st.conv1, st.conv2 = c1, c2
             keep += [c1, c2]
         self._st, self._keep, self._key = st, keep, key

@@ -62,7 +62,7 @@ class PackedSwinIR:
         st.embed_dim, st.num_heads, st.window_size, st.hidden = Cc, heads, ws, hid
         st.num_groups, st.depth = len(n.layers), len(n.layers[0].residual_group.blocks)
         st.conv_first = _pack_conv(n.conv_first, keep, pad_cin_to=4)
-        st.conv_after_body = _pack_conv(n.conv_after_body, keep, pad_cin_to=ld)
+        st.conv_after_body = _pack_conv(n.conv_after_body, keep, pad_cin_to=ld, frag=True)
         st.conv_after_body.cin = ld
 
         def dptr(t):
@@ -92,7 +92,7 @@ class PackedSwinIR:
                 sb.fc2_w, sb.fc2_b = dptr(_pad_cols(b.mlp.fc2.weight, ldh)), dptr(b.mlp.fc2.bias)
                 sb.shift = int(b.shift_size)
                 sb.mask = None
-            gconv[g] = _pack_conv(layer.conv, keep, pad_cin_to=ld)
+            gconv[g] = _pack_conv(layer.conv, keep, pad_cin_to=ld, frag=True)
             gconv[g].cin = ld
         st.blocks, st.group_conv = blocks, gconv
         keep += [blocks, gconv]

@@ -223,7 +223,8 @@ typedef struct ciaosr_conv {
     const void* frag16;  /* optional: ciaosr_pack_fragments_bf16(weight, ld = k*k*cin, N = cout, K = k*k*cin); used by
                           * ciaosr_rdn_forward_bf16 for the dense layers, NULL otherwise */
     const float* frag;   /* optional: ciaosr_pack_fragments_f32 of the same matrix; lets ciaosr_rdn_forward_f32 run the
-                          * dense layers of maps with >= 128 tiles of 12x12 pixels through the halo-resident kernel */
+                          * dense layers of maps with >= 128 tiles of 12x12 pixels through the halo-resident kernel, and any
+                          * 3x3 trunk convolution of a map of <= 18432 pixels through the one-launch small-map kernel */
 } ciaosr_conv_t;
 
 typedef struct ciaosr_rdn_weights {
