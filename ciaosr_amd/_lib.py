@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libciaosr_hip.so')
+# CIAOSR_HIP_LIB: developer override (e.g. the cycle-stamp probe build, `make -C ciaosr_amd/csrc probe`)
+LIB_PATH = os.environ.get('CIAOSR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libciaosr_hip.so')
 MAX_LAYERS = 8
 
 ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2

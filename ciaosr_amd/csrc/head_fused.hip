@@ -31,6 +31,13 @@ constexpr int FNJ = FH / 8;    // k-chunks of 8 per 256-wide layer
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobF = 0xFFFFFFF0u;
 
+#ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/head_probe.py): cycle stamps of workgroup phases
+__device__ unsigned long long g_hprobe[4096 * 16];
+#define HPROBE(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_hprobe[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HPROBE(slot) do { } while (0)
+#endif
+
 // Epilogue gathers go through buffer descriptors: a column group past the layer width or a missing query row
 // gets an out-of-range offset and reads zeros; no branch around the load, so all loads of an epilogue are in
 // flight together (per-element conditionals make hipcc wait vmcnt(0) after each one).
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (FBM / 4);          // local query index of row 0
+    HPROBE(0);
 
     // ---- index math: one thread per row (ciaosr_net.py:145-193) ---------------------------------
     int bad = 0;
@@ -222,9 +230,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     if (p.G == nullptr) __syncthreads();
 
     // ================= phi_k =====================================================================
+    HPROBE(1);
     build_rows(X, p.k, s_kpix, s_t4, t);
     __syncthreads();
+    HPROBE(2);
     for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    HPROBE(3);
 
     if (table) {
         // logit = h4 . G[query pixel, key offset] + c  (exact fold of the output layer, head_ops.hip qk_rows):
@@ -321,9 +332,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     // (the barrier inside build_rows' caller below also orders s_attn)
 
     // ================= phi_v =====================================================================
+    HPROBE(4);
     build_rows(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
     __syncthreads();
+    HPROBE(5);
     for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    HPROBE(6);
     {
         const int n_units = (p.v.n_out + 31) >> 5;
         const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
@@ -379,6 +393,13 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
             }
         }
     }
+    HPROBE(7);
+#ifdef CIAOSR_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_hprobe[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
+        g_hprobe[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -508,3 +529,9 @@ extern "C" int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, f
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
     return pack_fragments(W, ld, N, K, out, (hipStream_t)stream);
 }
+
+#ifdef CIAOSR_PROBE
+extern "C" int ciaosr_debug_probe_read(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::g_hprobe), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif

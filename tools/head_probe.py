@@ -1,0 +1,41 @@
+"""Developer probe: per-phase cycle stamps of head_kv_fused_kernel at C2 (needs `make -C ciaosr_amd/csrc probe`).
+   CIAOSR_HIP_LIB=ciaosr_amd/csrc/libciaosr_hip_probe.so python tools/head_probe.py"""
+import ctypes as C
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from bench import rdn_ciaosr
+from ciaosr_amd import _lib
+from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+
+dev = torch.device('cuda')
+model = rdn_ciaosr(dict(scale=4, tile=192, tile_overlap=32))
+seeded_init_(model, 0)
+model = model.to(dev)
+lq, _ = synthetic_pair(48, 48, 4)
+lq = lq.to(dev)
+for _ in range(3):
+    model.restore(lq)
+torch.cuda.synchronize()
+lib = _lib.load()
+n = 2304
+buf = (C.c_ulonglong * (4096 * 16))()
+lib.ciaosr_debug_probe_read.restype = C.c_int
+assert lib.ciaosr_debug_probe_read(buf, 4096 * 16) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16)[:n].astype(np.int64)
+names = ['index math', 'build rows k', 'k hidden x3', 'logit + softmax', 'build rows v', 'v hidden x3', 'v out + epilogue']
+d = a[:, 1:8] - a[:, 0:7]
+tot = a[:, 7] - a[:, 0]
+print(f'{n} workgroups; lifetime avg {tot.mean():.0f} ticks (min {tot.min()}, max {tot.max()})')
+for i, nm in enumerate(names):
+    print(f'  {nm:20s} {d[:, i].mean():9.0f} ticks avg  ({100 * d[:, i].mean() / tot.mean():5.1f} %)')
+mfma = 64 * (3 * 512 + 3 * 512 + 5 * 256)           # MFMA issue cycles of one wave: 6 hidden layers + its 5 v-out units
+print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; two workgroups share a CU)')
+# concurrency on a CU: how many workgroups ran on each CU and their span
+key = (a[:, 9] & 0xF) << 32 | (a[:, 8] & 0xFF00)
+for k in np.unique(key)[:3]:
+    rows = a[key == k]
+    rows = rows[np.argsort(rows[:, 0])]
+    t0 = rows[0, 0]
+    print(f'  CU {k:x}: {len(rows)} workgroups, span {rows[:, 7].max() - t0} ticks; starts {list((rows[:, 0] - t0)[:10])}')
