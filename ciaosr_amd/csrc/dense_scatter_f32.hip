@@ -30,8 +30,6 @@ constexpr int ST = 8;                        // output tile edge (pixels): 64 pi
 constexpr int SP = ST + 2;                   // patch edge with the 1-pixel halo
 constexpr int SPS = 272;                     // bytes per patch pixel: 64 fp32 + 16 B pad (conflict-free ds_read_b128)
 constexpr int SPATCH = SP * SP * SPS;        // 27 200 B
-constexpr int SCHUNKS = SP * SP * 16;        // 16-byte chunks of the patch
-constexpr int SLOADS = (SCHUNKS + 255) / 256;   // 7
 static_assert(SPATCH <= 32768, "the halo patch must fit the reduction scratch");
 constexpr size_t kScatterLds = 32768;        // max(patch, K-slice reduction scratch 4 x 2 x 4 x 64 x 16 B)
 constexpr unsigned kOobS = 0xFFFFFFF0u;
@@ -53,11 +51,14 @@ struct ScatterP {
     const float* bias;                       // [L][64]
 };
 
+template <int MT>      // 32-pixel MFMA row tiles per workgroup: 2 (8x8 pixels) or 1 (8 wide x 4 high)
 __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
+    constexpr int TY = 4 * MT, PY = TY + 2;             // tile / patch height
+    constexpr int NCH = PY * SP * 16, NLD = (NCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldss[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int tile = blockIdx.x / p.n32, nt = blockIdx.x - tile * p.n32;
-    const int ty0 = (tile / p.tiles_x) * ST, tx0 = (tile % p.tiles_x) * ST;
+    const int ty0 = (tile / p.tiles_x) * TY, tx0 = (tile % p.tiles_x) * ST;
     SPROBE(0);
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
@@ -72,10 +73,10 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
     // (1b) the running sums this workgroup will add to (independent of the MFMA work: requested now, used in the epilogue)
     const int layer = p.step + (nt >> 1), half = nt & 1;
     const __amdgpu_buffer_rsrc_t rs_acc = __builtin_amdgcn_make_buffer_rsrc(p.acc, 0, p.acc_bytes, 0x00020000);
-    float4 prev[2];
-    unsigned aoff[2], xoff[2];
+    float4 prev[MT];
+    unsigned aoff[MT], xoff[MT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < MT; ++u) {
         const int unit = t + 256 * u;
         const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
         const int idx = 32 * r + (ul & 31);
@@ -91,34 +92,34 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
 
     // (2) halo patch of input group `step` -> LDS
     SPROBE(1);
-    i32x4 pv_[SLOADS];
+    i32x4 pv_[NLD];
 #pragma unroll
-    for (int s = 0; s < SLOADS; ++s) {
+    for (int s = 0; s < NLD; ++s) {
         const int c = t + 256 * s;
         const int px = c >> 4, part = c & 15;
         const int py = px / SP, pxx = px - py * SP;
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
-        const bool ok = c < SCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool ok = c < NCH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         pv_[s] = __builtin_amdgcn_raw_buffer_load_b128(
             rs, ok ? (int)((unsigned)(gy * p.W + gx) * (unsigned)p.ldx * 4u + (unsigned)(64 * p.step) * 4u + (unsigned)part * 16u) : (int)kOobS, 0, 0);
     }
 #pragma unroll
-    for (int s = 0; s < SLOADS; ++s) {
+    for (int s = 0; s < NLD; ++s) {
         const int c = t + 256 * s;
-        if (c < SCHUNKS) *reinterpret_cast<i32x4*>(ldss + (c >> 4) * SPS + (c & 15) * 16) = pv_[s];
+        if (c < NCH) *reinterpret_cast<i32x4*>(ldss + (c >> 4) * SPS + (c & 15) * 16) = pv_[s];
     }
 
     constexpr int kTapMin = (-1 * SP - 1) * SPS;
-    int poff[2];
+    int poff[MT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MT; ++r) {
         const int idx = 32 * r + li;
         const int y = idx >> 3, x = idx & 7;
         poff[r] = ((y + 1) * SP + (x + 1)) * SPS + (16 * w + 4 * lh) * 4 + kTapMin;
     }
-    f32x16 acc[2];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MT; ++r)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
     __syncthreads();
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
         for (int c = 0; c < 2; ++c) {
             const float4 a = wv[tap][c];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < MT; ++r) {
                 const float4 b = *reinterpret_cast<const float4*>(ldss + poff[r] + toff + c * 32);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[r], 0, 0, 0);
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[r], 0, 0, 0);
@@ -147,28 +148,28 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
     // (4) K-slice reduction through LDS: red[w][r][q][lane] = accumulator registers 4q..4q+3
     float4* red = reinterpret_cast<float4*>(ldss);
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MT; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            red[((w * 2 + r) * 4 + q) * 64 + lane] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+            red[((w * MT + r) * 4 + q) * 64 + lane] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
     __syncthreads();
 
     SPROBE(4);
     // (5) epilogue: 512 float4 units (r, q, lane) = pixel 32r + (lane & 31), channels 8q + 4 (lane >> 5) .. + 3
-    float4 v[2];
+    float4 v[MT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < MT; ++u) {
         const int unit = t + 256 * u;
         const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
-        v[u] = red[((0 * 2 + r) * 4 + q) * 64 + ul];
+        v[u] = red[((0 * MT + r) * 4 + q) * 64 + ul];
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const float4 o = red[((ww * 2 + r) * 4 + q) * 64 + ul];
+            const float4 o = red[((ww * MT + r) * 4 + q) * 64 + ul];
             v[u].x += o.x; v[u].y += o.y; v[u].z += o.z; v[u].w += o.w;
         }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < MT; ++u) {
         const int unit = t + 256 * u;
         const int ul = unit & 63, q = (unit >> 6) & 3;
         const int col = 32 * half + 8 * q + 4 * (ul >> 5);
@@ -211,9 +212,17 @@ int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layer
     p.wf = reinterpret_cast<const float4*>(frag);
     p.acc = acc_buf; p.ld_acc = 64 * num_layers; p.acc_bytes = (unsigned)ab;
     p.bias = bias_all;
-    const int tiles = ceil_div(H, ST) * p.tiles_x;
+    // 8x8-pixel workgroups, or 8x4 when that takes fewer rounds of 256 CUs (workgroups of a CU run their MFMA phases back to
+    // back: a step costs ceil(WGs / 256) phases; half-size phases quantise finer at twice the weight stream per MAC)
+    static const int force_mt = [] { const char* e = getenv("CIAOSR_SCATTER_MT"); return e ? atoi(e) : 0; }();
+    const int wg2 = ceil_div(H, 8) * p.tiles_x * p.n32, wg1 = ceil_div(H, 4) * p.tiles_x * p.n32;
+    const int cost2 = 2 * ceil_div(wg2, 256), cost1 = ceil_div(wg1, 256);       // in half-phase units
+    const bool use1 = force_mt ? force_mt == 1 : cost1 < cost2;
     ProfScope prof("enc_dense_scatter", s);
-    hipLaunchKernelGGL(dense_scatter_small_kernel, dim3(tiles * p.n32), dim3(256), kScatterLds, s, p);
+    if (use1)
+        hipLaunchKernelGGL(dense_scatter_small_kernel<1>, dim3(wg1), dim3(256), kScatterLds, s, p);
+    else
+        hipLaunchKernelGGL(dense_scatter_small_kernel<2>, dim3(wg2), dim3(256), kScatterLds, s, p);
     return launch_status("dense_scatter_small");
 }
 
