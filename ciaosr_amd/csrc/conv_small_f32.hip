@@ -20,8 +20,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CT = 8, CP = CT + 2, CPS = 272;
 constexpr int CPATCH = CP * CP * CPS;        // 27 200 B
-constexpr int CCHUNKS = CP * CP * 16;
-constexpr int CLOADS = (CCHUNKS + 255) / 256;   // 7
 constexpr size_t kConvSmallLds = 32768;
 static_assert(CPATCH <= 32768, "the halo patch must fit the reduction scratch");
 constexpr unsigned kOobC = 0xFFFFFFF0u;
@@ -37,34 +35,37 @@ struct ConvSmallP {
     int act; float alpha;
 };
 
+template <int MT>      // 32-pixel MFMA row tiles per workgroup: 2 (8x8 pixels) or 1 (8 wide x 4 high)
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
+    constexpr int TY = 4 * MT, PY = TY + 2;
+    constexpr int NCH = PY * CP * 16, NLD = (NCH + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsc[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int tile = blockIdx.x / p.n32, nt = blockIdx.x - tile * p.n32;
-    const int ty0 = (tile / p.tiles_x) * CT, tx0 = (tile % p.tiles_x) * CT;
+    const int ty0 = (tile / p.tiles_x) * TY, tx0 = (tile % p.tiles_x) * CT;
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.src), 0, p.src_bytes, 0x00020000);
 
-    unsigned goff[CLOADS];
+    unsigned goff[NLD];
 #pragma unroll
-    for (int s = 0; s < CLOADS; ++s) {
+    for (int s = 0; s < NLD; ++s) {
         const int c = t + 256 * s;
         const int px = c >> 4, part = c & 15;
         const int py = px / CP, pxx = px - py * CP;
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
-        const bool ok = c < CCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool ok = c < NCH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         goff[s] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)p.ld_src + (unsigned)part * 4u) * 4u : kOobC;
     }
-    i32x4 P[CLOADS];
+    i32x4 P[NLD];
     auto load_patch = [&](int g) {
 #pragma unroll
-        for (int s = 0; s < CLOADS; ++s)
+        for (int s = 0; s < NLD; ++s)
             P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobC ? (int)kOobC : (int)(goff[s] + (unsigned)g * 256u), 0, 0);
     };
     auto store_patch = [&]() {
 #pragma unroll
-        for (int s = 0; s < CLOADS; ++s) {
+        for (int s = 0; s < NLD; ++s) {
             const int c = t + 256 * s;
-            if (c < CCHUNKS) *reinterpret_cast<i32x4*>(ldsc + (c >> 4) * CPS + (c & 15) * 16) = P[s];
+            if (c < NCH) *reinterpret_cast<i32x4*>(ldsc + (c >> 4) * CPS + (c & 15) * 16) = P[s];
         }
     };
     const float4* wl = p.wf + (size_t)nt * p.nj * 64 + lane;
@@ -78,15 +79,15 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
     };
 
     constexpr int kTapMin = (-1 * CP - 1) * CPS;
-    int poff[2];
+    int poff[MT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MT; ++r) {
         const int idx = 32 * r + li;
         poff[r] = (((idx >> 3) + 1) * CP + ((idx & 7) + 1)) * CPS + (16 * w + 4 * lh) * 4 + kTapMin;
     }
-    f32x16 acc[2];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MT; ++r)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
             for (int c = 0; c < 2; ++c) {
                 const float4 a = wc[tap][c];
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
+                for (int r = 0; r < MT; ++r) {
                     const float4 b = *reinterpret_cast<const float4*>(ldsc + poff[r] + toff + c * 32);
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[r], 0, 0, 0);
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[r], 0, 0, 0);
@@ -122,10 +123,10 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
 
     float4* red = reinterpret_cast<float4*>(ldsc);
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < MT; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            red[((w * 2 + r) * 4 + q) * 64 + lane] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+            red[((w * MT + r) * 4 + q) * 64 + lane] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
     __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(p.dst, 0, p.dst_bytes, 0x00020000);
@@ -133,13 +134,13 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
     const __amdgpu_buffer_rsrc_t rs_r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.src), 0, p.res ? p.res_bytes : 0u, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < MT; ++u) {
         const int unit = t + 256 * u;
         const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
-        float4 v = red[((0 * 2 + r) * 4 + q) * 64 + ul];
+        float4 v = red[((0 * MT + r) * 4 + q) * 64 + ul];
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const float4 o = red[((ww * 2 + r) * 4 + q) * 64 + ul];
+            const float4 o = red[((ww * MT + r) * 4 + q) * 64 + ul];
             v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
         const int idx = 32 * r + (ul & 31);
@@ -184,8 +185,13 @@ int conv3x3_small(const float* src, int ld_src, int H, int W, int Cin, const flo
     p.dst2 = dst2; p.ld_dst2 = ld_dst2; p.dst2_bytes = dst2 ? (unsigned)(((M - 1) * ld_dst2 + Cout) * 4) : 0u;
     p.res = res; p.ld_res = ld_res; p.res_bytes = res ? (unsigned)(((M - 1) * ld_res + Cout) * 4) : 0u;
     p.act = act; p.alpha = alpha;
+    // 8x8-pixel workgroups, or 8x4 when that takes fewer rounds of 256 CUs (see dense_scatter_f32.hip)
+    const int wg2 = ceil_div(H, 8) * p.tiles_x * p.n32, wg1 = ceil_div(H, 4) * p.tiles_x * p.n32;
     ProfScope prof(tag ? tag : "conv3x3_small", s);
-    hipLaunchKernelGGL(conv3x3_small_kernel, dim3(ceil_div(H, CT) * p.tiles_x * p.n32), dim3(256), kConvSmallLds, s, p);
+    if (ceil_div(wg1, 256) < 2 * ceil_div(wg2, 256))
+        hipLaunchKernelGGL(conv3x3_small_kernel<1>, dim3(wg1), dim3(256), kConvSmallLds, s, p);
+    else
+        hipLaunchKernelGGL(conv3x3_small_kernel<2>, dim3(wg2), dim3(256), kConvSmallLds, s, p);
     return launch_status("conv3x3_small");
 }
 
