@@ -403,45 +403,133 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---- row-tile-count templated copies of the helpers above, used by the decode kernel (32- or 64-query workgroups) ----
+template <int MT, int NT>
+__device__ __forceinline__ void mma_pass_mt(const float* xa, const float4* __restrict__ wf, int nj, long tile_stride,
+                                         f32x16 (&acc)[MT][NT]) {
+    // software pipeline: weight fragments (L2) and activation fragments (LDS) of step j + 1 are requested before
+    // the MFMAs of step j, so neither latency sits between two MFMA groups
+    float4 fb[NT], fbn[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) fb[ni] = wf[ni * tile_stride];
+    float4 fa[MT], fan[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) fa[mi] = *reinterpret_cast<const float4*>(xa + mi * 32 * FLD);
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fan[mi] = fa[mi];
+        if (j + 1 < nj) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fbn[ni] = wf[ni * tile_stride + (long)(j + 1) * 64];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) fan[mi] = *reinterpret_cast<const float4*>(xa + mi * 32 * FLD + 8 * (j + 1));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa[mi].x, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa[mi].y, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa[mi].z, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa[mi].w, acc[mi][ni], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) fb[ni] = fbn[ni];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fa[mi] = fan[mi];
+    }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc_mt(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+}
+
+template <int MT>
+__device__ __forceinline__ void store_relu_tile_mt(float* X, const f32x16 (&acc)[MT][2], const float* __restrict__ bias,
+                                                int w, int li, int lh) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                float4 o;
+                o.x = fmaxf(acc[mi][ni][4 * g] + b.x, 0.f);
+                o.y = fmaxf(acc[mi][ni][4 * g + 1] + b.y, 0.f);
+                o.z = fmaxf(acc[mi][ni][4 * g + 2] + b.z, 0.f);
+                o.w = fmaxf(acc[mi][ni][4 * g + 3] + b.w, 0.f);
+                *reinterpret_cast<float4*>(X + (32 * mi + li) * FLD + col) = o;
+            }
+        }
+}
+
+template <int MT>
+__device__ __forceinline__ void hidden_layer_mt(float* X, const void* __restrict__ frag, const float* __restrict__ bias,
+                                             int w, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[MT][2];
+    zero_acc_mt<MT, 2>(acc);
+    mma_pass_mt<MT, 2>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(frag) + (size_t)(2 * w) * FNJ * 64 + lane, FNJ,
+                (long)FNJ * 64, acc);
+    __syncthreads();   // every wave has finished reading X
+    store_relu_tile_mt<MT>(X, acc, bias, w, li, lh);
+    __syncthreads();
+}
+
+
+template <int MT>      // 32-query MFMA tiles per workgroup: 2 (64 queries) or 1 (the tail launch)
 __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
+    constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;   // [64][260]
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int qbase = blockIdx.x * FBM;
+    const int qbase = blockIdx.x * BM;
 
     // layer 0: K = Dv streamed through X in chunks of 256 columns
     const __amdgpu_buffer_rsrc_t rs_zin =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
-    f32x16 acc[2][2];
-    zero_acc<2>(acc);
+    f32x16 acc[MT][2];
+    zero_acc_mt<MT, 2>(acc);
     for (int k0 = 0; k0 < p.Dv; k0 += FH) {
         const int kc = min(FH, p.Dv - k0);          // multiple of 8
         if (k0 > 0) __syncthreads();                 // previous chunk fully consumed
         {   // stage the 64 x 256 chunk of Z: 16 float4 per thread, all requested before the first LDS store, through a
             // buffer descriptor (a guarded load inside a load -> store loop costs one HBM round trip per iteration)
             const int c4 = (t & 63) * 4;
-            float4 zv[FBM / 4];
+            float4 zv[BM / 4];
 #pragma unroll
-            for (int i = 0; i < FBM / 4; ++i) {
+            for (int i = 0; i < BM / 4; ++i) {
                 const int ql = qbase + (t >> 6) + 4 * i;
                 zv[i] = bload4(rs_zin, (ql < p.nq && c4 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c4)) * 4u : kOobF);
             }
 #pragma unroll
-            for (int i = 0; i < FBM / 4; ++i) *reinterpret_cast<float4*>(X + ((t >> 6) + 4 * i) * FLD + c4) = zv[i];
+            for (int i = 0; i < BM / 4; ++i) *reinterpret_cast<float4*>(X + ((t >> 6) + 4 * i) * FLD + c4) = zv[i];
         }
         __syncthreads();
-        mma_pass<2>(X + li * FLD + 4 * lh,
+        mma_pass_mt<MT, 2>(X + li * FLD + 4 * lh,
                     reinterpret_cast<const float4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 3)) * 64 + lane,
                     kc >> 3, (long)p.nj_in * 64, acc);
     }
     __syncthreads();
-    store_relu_tile(X, acc, p.bias_in, w, li, lh);
+    store_relu_tile_mt<MT>(X, acc, p.bias_in, w, li, lh);
     __syncthreads();
-    for (int l = 0; l < p.n_hidden; ++l) hidden_layer(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.n_hidden; ++l) hidden_layer_mt<MT>(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
 
     // last Linear (256 -> 3): 4 threads per row, 64 columns each
-    const int row = t >> 2, part = t & 3;
+    const bool rv = (t >> 2) < BM;                        // 32-query variant: the upper half of the threads idles
+    const int row = rv ? (t >> 2) : 0, part = t & 3;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     {
         const float* xr = X + row * FLD + 64 * part;
@@ -463,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     a1 += quad_xor1(a1); a1 += quad_xor2(a1);
     a2 += quad_xor1(a2); a2 += quad_xor2(a2);
     const int ql = qbase + row;
-    if (part < 3 && ql < p.nq) {
+    if (part < 3 && rv && ql < p.nq) {
         const long q = p.q0 + ql;
         float v = (part == 0 ? a0 : part == 1 ? a1 : a2) + p.b_last[part];
         if (p.x_lr) {
@@ -511,11 +599,17 @@ int head_kv_fused(const FusedKVP& p, hipStream_t s) {
 }
 
 int head_decode_fused(const FusedQP& p, hipStream_t s) {
-    const size_t lds = (size_t)FBM * FLD * sizeof(float);
-    static const bool attr = (allow_big_lds(head_decode_fused_kernel, lds), true);      // thread-safe one-time setup (C++11 static init)
+    static const bool attr = (allow_big_lds(head_decode_fused_kernel<2>, (size_t)64 * FLD * sizeof(float)),
+                              allow_big_lds(head_decode_fused_kernel<1>, (size_t)32 * FLD * sizeof(float)), true);
     (void)attr;
+    // 64-query workgroups, or 32-query ones when they take fewer rounds of 256 CUs (a CU runs the MFMA phases of its
+    // workgroups back to back: C2 has 576 = 2.25 per CU -> 3 phases, against 5 half-phases for 1152 workgroups)
+    const int wg2 = ceil_div(p.nq, 64), wg1 = ceil_div(p.nq, 32);
     ProfScope prof("head_decode_fused", s);
-    hipLaunchKernelGGL(head_decode_fused_kernel, dim3(ceil_div(p.nq, FBM)), dim3(256), lds, s, p);
+    if (ceil_div(wg1, 256) < 2 * ceil_div(wg2, 256))
+        hipLaunchKernelGGL(head_decode_fused_kernel<1>, dim3(wg1), dim3(256), (size_t)32 * FLD * sizeof(float), s, p);
+    else
+        hipLaunchKernelGGL(head_decode_fused_kernel<2>, dim3(wg2), dim3(256), (size_t)64 * FLD * sizeof(float), s, p);
     return launch_status("head_decode_fused");
 }
 
