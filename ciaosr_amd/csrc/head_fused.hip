@@ -15,6 +15,8 @@
 // (weights are shared by every workgroup and never staged in LDS).  4 waves split the output columns;
 // layers run in place: all waves finish reading X, barrier, write bias+ReLU results, barrier.
 // Two workgroups per CU (69 KB LDS each) overlap one's epilogue/barrier bubbles with the other's MFMAs.
+#include <cstdlib>
+
 #include "bf16_util.h"
 #include "index_math.h"
 #include "ops.h"
@@ -488,6 +490,243 @@ __device__ __forceinline__ void hidden_layer_mt(float* X, const void* __restrict
 }
 
 
+template <int MT>
+__device__ __forceinline__ void build_rows_mt(float* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
+    // 64 rows x 64 float4: thread handles float4 column (t & 63) of rows (t >> 6) + 4*s
+    const int n4 = t & 63;
+    float4 tw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
+    for (int r = t >> 6; r < 32 * MT; r += 4) {
+        const float4 tv = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[r] * FH)[n4];
+        const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
+        float4 o;
+        o.x = fmaxf(tv.x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f);
+        o.y = fmaxf(tv.y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f);
+        o.z = fmaxf(tv.z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f);
+        o.w = fmaxf(tv.w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f);
+        *reinterpret_cast<float4*>(X + r * FLD + 4 * n4) = o;
+    }
+}
+
+
+// Row-tile-count templated copy of head_kv_fused_kernel, instantiated for 32-row workgroups (8 queries): four of them fit a
+// CU, so a launch with few workgroups per CU (C1, C2, C5: <= 16 per CU, odd counts leave one running alone at 44 % pipe use)
+// overlaps its non-MFMA phases better; big launches keep the 64-row kernel, which streams half the weights per row.
+template <int MT>
+__global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p) {
+    constexpr int BM = 32 * MT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                   // [64][260]
+    float* s_t4 = X + BM * FLD;                       // [64][4]  rel_y rel_x scale_y scale_x
+    float* s_part = s_t4 + BM * 4;                    // [4][64]  per-wave partial logits
+    float* s_attn = s_part + 4 * BM;                  // [64]
+    int* s_kpix = reinterpret_cast<int*>(s_attn + BM);  // [64]
+    int* s_qpix = s_kpix + BM;                        // [16]
+    int* s_goff = s_qpix + BM / 4;                    // [64]  logit-table row of each (query, sample) row
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * (BM / 4);          // local query index of row 0
+
+    // ---- index math: one thread per row (ciaosr_net.py:145-193) ---------------------------------
+    int bad = 0;
+    if (t < BM) {
+        const int ql = qbase + (t >> 2), j = t & 3;
+        int kpix = 0, goff = -1;
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ql < p.nq) {
+            const long q = p.q0 + ql;
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            const long c0 = p.chunk > 0 ? (q / p.chunk) * p.chunk : 0;
+            const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, 2);
+            kpix = s.ky * p.W + s.kx;
+            t4[0] = s.rel_y; t4[1] = s.rel_x;
+            t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
+            t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
+            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+            const bool qin = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (j == 0) s_qpix[t >> 2] = qin ? iy * p.W + ix : -1;
+            if (qin) {
+                const int oy = s.ky - iy, ox = s.kx - ix;      // key pixel relative to the query pixel
+                if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) goff = (iy * p.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
+                else bad = 1;                                   // exotic cell: not a 3x3 neighbour -> MFMA path
+            }
+        } else if (j == 0) {
+            s_qpix[t >> 2] = -1;
+        }
+        s_kpix[t] = kpix;
+        s_goff[t] = goff;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
+    }
+    const bool table = p.G != nullptr && !__syncthreads_or(bad);   // (also the barrier after the index phase)
+    if (p.G == nullptr) __syncthreads();
+
+    // ================= phi_k =====================================================================
+    build_rows_mt<MT>(X, p.k, s_kpix, s_t4, t);
+    __syncthreads();
+    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer_mt<MT>(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+
+    if (table) {
+        // logit = h4 . G[query pixel, key offset] + c  (exact fold of the output layer, head_ops.hip qk_rows):
+        // 4 threads per row, float4-interleaved over the 256 hidden units
+        const bool rv = (t >> 2) < BM;                    // 32-row variant: the upper half of the threads idles
+        const int row = rv ? (t >> 2) : 0, part = t & 3;
+        const int go = rv ? s_goff[row] : -1;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+        const unsigned gbase = go >= 0 ? (unsigned)go * (unsigned)p.ldg * 4u : kOobF;
+        float4 gv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gv[i] = bload4(rs_g, gbase == kOobF ? kOobF : gbase + (unsigned)(16 * i + 4 * part) * 4u);
+        const float cterm = (go >= 0 && part == 0) ? p.G[(size_t)go * p.ldg + 256] : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float4 x = *reinterpret_cast<const float4*>(X + row * FLD + 16 * i + 4 * part);
+            a += x.x * gv[i].x + x.y * gv[i].y + x.z * gv[i].z + x.w * gv[i].w;
+        }
+        a += cterm;
+        a += quad_xor1(a);
+        a += quad_xor2(a);
+        if (part == 0 && rv) {
+            s_part[row] = a;
+            s_part[BM + row] = 0.f;
+            s_part[2 * BM + row] = 0.f;
+            s_part[3 * BM + row] = 0.f;
+        }
+    } else
+    // output layer fused with the logit dot product: wave w takes 32-column units w, w+4, ...
+    {
+        float part[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) part[mi] = 0.f;
+        const int n_units = (p.k.n_out + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bk =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.k.bias_out), 0, (unsigned)p.k.n_out * 4u, 0x00020000);
+        unsigned koff[MT], qoff[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = 32 * mi + li;
+            koff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
+            const int qp = s_qpix[m >> 2];
+            qoff[mi] = qp >= 0 ? (unsigned)qp * (unsigned)p.ldu * 4u : kOobF;     // missing query row reads zeros
+        }
+        for (int u = w; u < n_units; u += 4) {
+            f32x16 acc[MT][1];
+            zero_acc_mt<MT, 1>(acc);
+            mma_pass_mt<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
+                        FNJ, 0, acc);
+            // logit += sum_d q[d] * (key[d] * (w_k[d] + b[d]))   (ciaosr_net.py:203,214)
+            float4 bv[4], kv[MT][4], qv[MT][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.k.n_out ? (unsigned)d0 * 4u : kOobF;
+                bv[g] = bload4(rs_bk, doff);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    kv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : koff[mi] + doff);
+                    qv[mi][g] = bload4(rs_u, (doff == kOobF || qoff[mi] == kOobF) ? kOobF : qoff[mi] + doff);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+                    part[mi] += qv[mi][g].x * (kv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x)) +
+                                qv[mi][g].y * (kv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y)) +
+                                qv[mi][g].z * (kv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z)) +
+                                qv[mi][g].w * (kv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
+        }
+        // the two half-waves hold different channels of the same rows
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            part[mi] += __shfl_xor(part[mi], 32, 64);
+            if (lh == 0) s_part[w * BM + 32 * mi + li] = part[mi];
+        }
+    }
+    __syncthreads();
+    // softmax over the 4 key samples of each query (ciaosr_net.py:214-215)
+    if (t < BM / 4) {
+        float lg[4], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 4 * t + j;
+            lg[j] = (s_part[row] + s_part[BM + row] + s_part[2 * BM + row] + s_part[3 * BM + row]) / p.softmax_scale;
+            m = fmaxf(m, lg[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lg[j] = expf(lg[j] - m); den += lg[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_attn[4 * t + j] = lg[j] / den;
+    }
+    // (the barrier inside build_rows' caller below also orders s_attn)
+
+    // ================= phi_v =====================================================================
+    build_rows_mt<MT>(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
+    __syncthreads();
+    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer_mt<MT>(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    {
+        const int n_units = (p.v.n_out + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bv =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v.bias_out), 0, (unsigned)p.v.n_out * 4u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_z =
+            __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
+        unsigned voff[MT], zoff[MT];
+        float av[MT];
+        const int jsel = li & 3;     // this lane's key sample; also the channel group it stores
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int m = 32 * mi + li;
+            voff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
+            av[mi] = s_attn[m];
+            const int ql = qbase + (m >> 2);
+            zoff[mi] = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 4u : kOobF;
+        }
+        for (int u = w; u < n_units; u += 4) {
+            // the epilogue's gathers (bias, value rows) do not depend on the MFMA pass: request them first so their L2
+            // latency hides behind the 256 MFMAs of this unit
+            float4 bv[4], vv[MT][4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.v.n_out ? (unsigned)d0 * 4u : kOobF;
+                bv[g] = bload4(rs_bv, doff);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) vv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : voff[mi] + doff);
+            }
+            f32x16 acc[MT][1];
+            zero_acc_mt<MT, 1>(acc);
+            mma_pass_mt<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
+                        FNJ, 0, acc);
+            // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
+            // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                float4 zsel = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 z;
+                    z.x = av[mi] * (vv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x));
+                    z.y = av[mi] * (vv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y));
+                    z.z = av[mi] * (vv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z));
+                    z.w = av[mi] * (vv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
+                    z.x += quad_xor1(z.x); z.y += quad_xor1(z.y); z.z += quad_xor1(z.z); z.w += quad_xor1(z.w);
+                    z.x += quad_xor2(z.x); z.y += quad_xor2(z.y); z.z += quad_xor2(z.z); z.w += quad_xor2(z.w);
+                    if (jsel == g) zsel = z;
+                }
+                const int d0 = 32 * u + 8 * jsel + 4 * lh;
+                bstore4(rs_z, (zoff[mi] == kOobF || d0 >= p.v.n_out) ? kOobF : zoff[mi] + (unsigned)d0 * 4u, zsel);
+            }
+        }
+    }
+}
+
+
 template <int MT>      // 32-query MFMA tiles per workgroup: 2 (64 queries) or 1 (the tail launch)
 __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     constexpr int BM = 32 * MT;
@@ -590,11 +829,18 @@ int pack_fragments(const float* W, int ld, int N, int K, float* P, hipStream_t s
 
 constexpr size_t kFusedLds = (size_t)(FBM * FLD + FBM * 4 + 4 * FBM + FBM) * sizeof(float) + (FBM + 16 + FBM) * sizeof(int);
 
+constexpr size_t kFusedLdsSmall = (size_t)(32 * FLD + 32 * 4 + 4 * 32 + 32) * sizeof(float) + (32 + 8 + 32) * sizeof(int);
+
 int head_kv_fused(const FusedKVP& p, hipStream_t s) {
-    static const bool attr = (allow_big_lds(head_kv_fused_kernel, kFusedLds), true);      // thread-safe one-time setup (C++11 static init)
+    static const bool attr = (allow_big_lds(head_kv_fused_kernel, kFusedLds), allow_big_lds(head_kv_fused_small_kernel<1>, kFusedLdsSmall), true);
     (void)attr;
+    static const int small_max = [] { const char* e = getenv("CIAOSR_KV_SMALL_MAX_PER_CU"); return e ? atoi(e) : 16; }();
+    const int wg64 = ceil_div(p.nq, FBM / 4);
     ProfScope prof("head_kv_fused", s);
-    hipLaunchKernelGGL(head_kv_fused_kernel, dim3(ceil_div(p.nq, FBM / 4)), dim3(256), kFusedLds, s, p);
+    if (wg64 <= small_max * 256)       // few workgroups per CU: 32-row workgroups (see head_kv_fused_small_kernel)
+        hipLaunchKernelGGL(head_kv_fused_small_kernel<1>, dim3(ceil_div(p.nq, 8)), dim3(256), kFusedLdsSmall, s, p);
+    else
+        hipLaunchKernelGGL(head_kv_fused_kernel, dim3(wg64), dim3(256), kFusedLds, s, p);
     return launch_status("head_kv_fused");
 }
 
