@@ -1,6 +1,6 @@
 // Fused head kernels (hidden width 256, local_size 2): activations never leave the CU.
 //
-//  head_kv_fused   one workgroup = 64 rows = 16 queries x 4 key samples.
+//  head_kv_fused   one workgroup = 32 rows = 8 queries x 4 key samples (64 rows selectable).
 //                  index math -> layer-0 rows from the hoisted tables -> phi_k hidden layers
 //                  in LDS -> phi_k output layer fused with  logit = sum_d q[d] key[d] w_k[d]  -> softmax
 //                  over the 4 samples -> phi_v hidden layers -> phi_v output layer fused with
@@ -8,13 +8,13 @@
 //  head_decode_fused   64 queries per workgroup: phi_q on Z (layer 0 streamed through LDS), last
 //                  Linear (-> 3) and the bilinear/border residual on the VALU      (ciaosr_net.py:107-108,220-222)
 //
-// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  A operand = the 64 x 256 activation tile in LDS (row stride
+// MFMA: v_mfma_f32_32x32x2_f32 (exact fp32).  A operand = the 32 (64) x 256 activation tile in LDS (row stride
 // 260 floats: conflict-free ds_read_b128, one float4 feeds 4 MFMAs through the consistent k permutation
 // k = 8j + 4h + e); B operand = weights pre-packed on the device into per-wave fragment order
 // [n_tile][j][lane][4] so that a wave's fragment is one coalesced 1 KiB load straight from L2 into VGPRs
 // (weights are shared by every workgroup and never staged in LDS).  4 waves split the output columns;
 // layers run in place: all waves finish reading X, barrier, write bias+ReLU results, barrier.
-// Two workgroups per CU (69 KB LDS each) overlap one's epilogue/barrier bubbles with the other's MFMAs.
+// Four 32-row workgroups per CU (34.5 KB of LDS each) overlap each other's epilogue/barrier bubbles with MFMAs.
 #include <cstdlib>
 
 #include "bf16_util.h"
@@ -25,7 +25,6 @@ namespace ciaosr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int FBM = 64;        // rows per workgroup
 constexpr int FH = 256;        // hidden width
 constexpr int FLD = FH + 4;    // LDS row stride (floats)
 constexpr int FNJ = FH / 8;    // k-chunks of 8 per 256-wide layer
@@ -83,331 +82,9 @@ __global__ void pack_fragments_kernel(const float* __restrict__ W, int ld, int N
 // columns.  Epilogues are therefore per-row: one key/value row pointer per lane, float4 loads along the
 // channel axis, ds_write_b128 / float4 stores, and the reduction over channels is in-register.
 // xa: &X[lane row][4h] of this lane; wf: this wave's first n-tile fragment stream (+lane), tile stride in float4
-template <int NT>
-__device__ __forceinline__ void mma_pass(const float* xa, const float4* __restrict__ wf, int nj, long tile_stride,
-                                         f32x16 (&acc)[2][NT]) {
-    // software pipeline: weight fragments (L2) and activation fragments (LDS) of step j + 1 are requested before
-    // the MFMAs of step j, so neither latency sits between two MFMA groups
-    float4 fb[NT], fbn[NT];
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni) fb[ni] = wf[ni * tile_stride];
-    float4 fa0 = *reinterpret_cast<const float4*>(xa);
-    float4 fa1 = *reinterpret_cast<const float4*>(xa + 32 * FLD);
-#pragma unroll 1
-    for (int j = 0; j < nj; ++j) {
-        float4 fa0n = fa0, fa1n = fa1;
-        if (j + 1 < nj) {
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) fbn[ni] = wf[ni * tile_stride + (long)(j + 1) * 64];
-            fa0n = *reinterpret_cast<const float4*>(xa + 8 * (j + 1));
-            fa1n = *reinterpret_cast<const float4*>(xa + 32 * FLD + 8 * (j + 1));
-        }
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa0.x, acc[0][ni], 0, 0, 0);
-            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].x, fa1.x, acc[1][ni], 0, 0, 0);
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa0.y, acc[0][ni], 0, 0, 0);
-            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].y, fa1.y, acc[1][ni], 0, 0, 0);
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa0.z, acc[0][ni], 0, 0, 0);
-            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].z, fa1.z, acc[1][ni], 0, 0, 0);
-            acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa0.w, acc[0][ni], 0, 0, 0);
-            acc[1][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[ni].w, fa1.w, acc[1][ni], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) fb[ni] = fbn[ni];
-        fa0 = fa0n; fa1 = fa1n;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NT]) {
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-}
-
-// X[m][n] <- relu(acc + bias[n]) for the wave's 64 columns: 4 consecutive columns per register group
-__device__ __forceinline__ void store_relu_tile(float* X, const f32x16 (&acc)[2][2], const float* __restrict__ bias,
-                                                int w, int li, int lh) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
-            const float4 b = *reinterpret_cast<const float4*>(bias + col);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                float4 o;
-                o.x = fmaxf(acc[mi][ni][4 * g] + b.x, 0.f);
-                o.y = fmaxf(acc[mi][ni][4 * g + 1] + b.y, 0.f);
-                o.z = fmaxf(acc[mi][ni][4 * g + 2] + b.z, 0.f);
-                o.w = fmaxf(acc[mi][ni][4 * g + 3] + b.w, 0.f);
-                *reinterpret_cast<float4*>(X + (32 * mi + li) * FLD + col) = o;
-            }
-        }
-}
-
-// hidden layer in place: X <- relu(X . W^T + b); wave w owns columns [64w, 64w+64)
-__device__ __forceinline__ void hidden_layer(float* X, const void* __restrict__ frag, const float* __restrict__ bias,
-                                             int w, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[2][2];
-    zero_acc<2>(acc);
-    mma_pass<2>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(frag) + (size_t)(2 * w) * FNJ * 64 + lane, FNJ,
-                (long)FNJ * 64, acc);
-    __syncthreads();   // every wave has finished reading X
-    store_relu_tile(X, acc, bias, w, li, lh);
-    __syncthreads();
-}
-
-// layer-0 rows of one chain into X (64 rows x 256)
-__device__ __forceinline__ void build_rows(float* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
-    // 64 rows x 64 float4: thread handles float4 column (t & 63) of rows (t >> 6) + 4*s
-    const int n4 = t & 63;
-    float4 tw[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
-    for (int r = t >> 6; r < FBM; r += 4) {
-        const float4 tv = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[r] * FH)[n4];
-        const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
-        float4 o;
-        o.x = fmaxf(tv.x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f);
-        o.y = fmaxf(tv.y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f);
-        o.z = fmaxf(tv.z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f);
-        o.w = fmaxf(tv.w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f);
-        *reinterpret_cast<float4*>(X + r * FLD + 4 * n4) = o;
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* X = smem;                                   // [64][260]
-    float* s_t4 = X + FBM * FLD;                       // [64][4]  rel_y rel_x scale_y scale_x
-    float* s_part = s_t4 + FBM * 4;                    // [4][64]  per-wave partial logits
-    float* s_attn = s_part + 4 * FBM;                  // [64]
-    int* s_kpix = reinterpret_cast<int*>(s_attn + FBM);  // [64]
-    int* s_qpix = s_kpix + FBM;                        // [16]
-    int* s_goff = s_qpix + FBM / 4;                    // [64]  logit-table row of each (query, sample) row
-
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qbase = blockIdx.x * (FBM / 4);          // local query index of row 0
-    HPROBE(0);
-
-    // ---- index math: one thread per row (ciaosr_net.py:145-193) ---------------------------------
-    int bad = 0;
-    if (t < FBM) {
-        const int ql = qbase + (t >> 2), j = t & 3;
-        int kpix = 0, goff = -1;
-        float t4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ql < p.nq) {
-            const long q = p.q0 + ql;
-            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
-            const long c0 = p.chunk > 0 ? (q / p.chunk) * p.chunk : 0;
-            const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, 2);
-            kpix = s.ky * p.W + s.kx;
-            t4[0] = s.rel_y; t4[1] = s.rel_x;
-            t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
-            t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
-            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
-            const bool qin = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            if (j == 0) s_qpix[t >> 2] = qin ? iy * p.W + ix : -1;
-            if (qin) {
-                const int oy = s.ky - iy, ox = s.kx - ix;      // key pixel relative to the query pixel
-                if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) goff = (iy * p.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
-                else bad = 1;                                   // exotic cell: not a 3x3 neighbour -> MFMA path
-            }
-        } else if (j == 0) {
-            s_qpix[t >> 2] = -1;
-        }
-        s_kpix[t] = kpix;
-        s_goff[t] = goff;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
-    }
-    const bool table = p.G != nullptr && !__syncthreads_or(bad);   // (also the barrier after the index phase)
-    if (p.G == nullptr) __syncthreads();
-
-    // ================= phi_k =====================================================================
-    HPROBE(1);
-    build_rows(X, p.k, s_kpix, s_t4, t);
-    __syncthreads();
-    HPROBE(2);
-    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
-    HPROBE(3);
-
-    if (table) {
-        // logit = h4 . G[query pixel, key offset] + c  (exact fold of the output layer, head_ops.hip qk_rows):
-        // 4 threads per row, float4-interleaved over the 256 hidden units
-        const int row = t >> 2, part = t & 3;
-        const int go = s_goff[row];
-        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
-        const unsigned gbase = go >= 0 ? (unsigned)go * (unsigned)p.ldg * 4u : kOobF;
-        float4 gv[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) gv[i] = bload4(rs_g, gbase == kOobF ? kOobF : gbase + (unsigned)(16 * i + 4 * part) * 4u);
-        const float cterm = (go >= 0 && part == 0) ? p.G[(size_t)go * p.ldg + 256] : 0.f;
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const float4 x = *reinterpret_cast<const float4*>(X + row * FLD + 16 * i + 4 * part);
-            a += x.x * gv[i].x + x.y * gv[i].y + x.z * gv[i].z + x.w * gv[i].w;
-        }
-        a += cterm;
-        a += quad_xor1(a);
-        a += quad_xor2(a);
-        if (part == 0) {
-            s_part[row] = a;
-            s_part[FBM + row] = 0.f;
-            s_part[2 * FBM + row] = 0.f;
-            s_part[3 * FBM + row] = 0.f;
-        }
-    } else
-    // output layer fused with the logit dot product: wave w takes 32-column units w, w+4, ...
-    {
-        float part[2] = {0.f, 0.f};
-        const int n_units = (p.k.n_out + 31) >> 5;
-        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_bk =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.k.bias_out), 0, (unsigned)p.k.n_out * 4u, 0x00020000);
-        unsigned koff[2], qoff[2];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int m = 32 * mi + li;
-            koff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
-            const int qp = s_qpix[m >> 2];
-            qoff[mi] = qp >= 0 ? (unsigned)qp * (unsigned)p.ldu * 4u : kOobF;     // missing query row reads zeros
-        }
-        for (int u = w; u < n_units; u += 4) {
-            f32x16 acc[2][1];
-            zero_acc<1>(acc);
-            mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
-                        FNJ, 0, acc);
-            // logit += sum_d q[d] * (key[d] * (w_k[d] + b[d]))   (ciaosr_net.py:203,214)
-            float4 bv[4], kv[2][4], qv[2][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * u + 8 * g + 4 * lh;
-                const unsigned doff = d0 < p.k.n_out ? (unsigned)d0 * 4u : kOobF;
-                bv[g] = bload4(rs_bk, doff);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    kv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : koff[mi] + doff);
-                    qv[mi][g] = bload4(rs_u, (doff == kOobF || qoff[mi] == kOobF) ? kOobF : qoff[mi] + doff);
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    part[mi] += qv[mi][g].x * (kv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x)) +
-                                qv[mi][g].y * (kv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y)) +
-                                qv[mi][g].z * (kv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z)) +
-                                qv[mi][g].w * (kv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
-        }
-        // the two half-waves hold different channels of the same rows
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            part[mi] += __shfl_xor(part[mi], 32, 64);
-            if (lh == 0) s_part[w * FBM + 32 * mi + li] = part[mi];
-        }
-    }
-    __syncthreads();
-    // softmax over the 4 key samples of each query (ciaosr_net.py:214-215)
-    if (t < FBM / 4) {
-        float lg[4], m = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = 4 * t + j;
-            lg[j] = (s_part[row] + s_part[FBM + row] + s_part[2 * FBM + row] + s_part[3 * FBM + row]) / p.softmax_scale;
-            m = fmaxf(m, lg[j]);
-        }
-        float den = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { lg[j] = expf(lg[j] - m); den += lg[j]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s_attn[4 * t + j] = lg[j] / den;
-    }
-    // (the barrier inside build_rows' caller below also orders s_attn)
-
-    // ================= phi_v =====================================================================
-    HPROBE(4);
-    build_rows(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
-    __syncthreads();
-    HPROBE(5);
-    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
-    HPROBE(6);
-    {
-        const int n_units = (p.v.n_out + 31) >> 5;
-        const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_bv =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v.bias_out), 0, (unsigned)p.v.n_out * 4u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_z =
-            __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
-        unsigned voff[2], zoff[2];
-        float av[2];
-        const int jsel = li & 3;     // this lane's key sample; also the channel group it stores
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int m = 32 * mi + li;
-            voff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
-            av[mi] = s_attn[m];
-            const int ql = qbase + (m >> 2);
-            zoff[mi] = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 4u : kOobF;
-        }
-        for (int u = w; u < n_units; u += 4) {
-            // the epilogue's gathers (bias, value rows) do not depend on the MFMA pass: request them first so their L2
-            // latency hides behind the 256 MFMAs of this unit
-            float4 bv[4], vv[2][4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * u + 8 * g + 4 * lh;
-                const unsigned doff = d0 < p.v.n_out ? (unsigned)d0 * 4u : kOobF;
-                bv[g] = bload4(rs_bv, doff);
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) vv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : voff[mi] + doff);
-            }
-            f32x16 acc[2][1];
-            zero_acc<1>(acc);
-            mma_pass<1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
-                        FNJ, 0, acc);
-            // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
-            // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                float4 zsel = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float4 z;
-                    z.x = av[mi] * (vv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x));
-                    z.y = av[mi] * (vv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y));
-                    z.z = av[mi] * (vv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z));
-                    z.w = av[mi] * (vv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
-                    z.x += quad_xor1(z.x); z.y += quad_xor1(z.y); z.z += quad_xor1(z.z); z.w += quad_xor1(z.w);
-                    z.x += quad_xor2(z.x); z.y += quad_xor2(z.y); z.z += quad_xor2(z.z); z.w += quad_xor2(z.w);
-                    if (jsel == g) zsel = z;
-                }
-                const int d0 = 32 * u + 8 * jsel + 4 * lh;
-                bstore4(rs_z, (zoff[mi] == kOobF || d0 >= p.v.n_out) ? kOobF : zoff[mi] + (unsigned)d0 * 4u, zsel);
-            }
-        }
-    }
-    HPROBE(7);
-#ifdef CIAOSR_PROBE
-    if (threadIdx.x == 0 && blockIdx.x < 4096) {
-        g_hprobe[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
-        g_hprobe[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// ---- row-tile-count templated copies of the helpers above, used by the decode kernel (32- or 64-query workgroups) ----
+// (templated on the number MT of 32-row MFMA tiles of a workgroup: 1 = 32 rows, 2 = 64 rows)
 template <int MT, int NT>
-__device__ __forceinline__ void mma_pass_mt(const float* xa, const float4* __restrict__ wf, int nj, long tile_stride,
+__device__ __forceinline__ void mma_pass(const float* xa, const float4* __restrict__ wf, int nj, long tile_stride,
                                          f32x16 (&acc)[MT][NT]) {
     // software pipeline: weight fragments (L2) and activation fragments (LDS) of step j + 1 are requested before
     // the MFMAs of step j, so neither latency sits between two MFMA groups
@@ -446,7 +123,7 @@ __device__ __forceinline__ void mma_pass_mt(const float* xa, const float4* __res
 }
 
 template <int MT, int NT>
-__device__ __forceinline__ void zero_acc_mt(f32x16 (&acc)[MT][NT]) {
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -456,7 +133,7 @@ __device__ __forceinline__ void zero_acc_mt(f32x16 (&acc)[MT][NT]) {
 }
 
 template <int MT>
-__device__ __forceinline__ void store_relu_tile_mt(float* X, const f32x16 (&acc)[MT][2], const float* __restrict__ bias,
+__device__ __forceinline__ void store_relu_tile(float* X, const f32x16 (&acc)[MT][2], const float* __restrict__ bias,
                                                 int w, int li, int lh) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -477,21 +154,21 @@ __device__ __forceinline__ void store_relu_tile_mt(float* X, const f32x16 (&acc)
 }
 
 template <int MT>
-__device__ __forceinline__ void hidden_layer_mt(float* X, const void* __restrict__ frag, const float* __restrict__ bias,
+__device__ __forceinline__ void hidden_layer(float* X, const void* __restrict__ frag, const float* __restrict__ bias,
                                              int w, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[MT][2];
-    zero_acc_mt<MT, 2>(acc);
-    mma_pass_mt<MT, 2>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(frag) + (size_t)(2 * w) * FNJ * 64 + lane, FNJ,
+    zero_acc<MT, 2>(acc);
+    mma_pass<MT, 2>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(frag) + (size_t)(2 * w) * FNJ * 64 + lane, FNJ,
                 (long)FNJ * 64, acc);
     __syncthreads();   // every wave has finished reading X
-    store_relu_tile_mt<MT>(X, acc, bias, w, li, lh);
+    store_relu_tile<MT>(X, acc, bias, w, li, lh);
     __syncthreads();
 }
 
 
 template <int MT>
-__device__ __forceinline__ void build_rows_mt(float* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
+__device__ __forceinline__ void build_rows(float* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
     // 64 rows x 64 float4: thread handles float4 column (t & 63) of rows (t >> 6) + 4*s
     const int n4 = t & 63;
     float4 tw[4];
@@ -510,11 +187,11 @@ __device__ __forceinline__ void build_rows_mt(float* X, const FusedChain& c, con
 }
 
 
-// Row-tile-count templated copy of head_kv_fused_kernel, instantiated for 32-row workgroups (8 queries): four of them fit a
-// CU, so a launch with few workgroups per CU (C1, C2, C5: <= 16 per CU, odd counts leave one running alone at 44 % pipe use)
-// overlaps its non-MFMA phases better; big launches keep the 64-row kernel, which streams half the weights per row.
-template <int MT>
-__global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p) {
+// 32-row workgroups (MT = 1, 8 queries) are the default: four fit a CU (34.5 KB of LDS each) and overlap each other's
+// non-MFMA phases -- measured 1.46 -> 1.41 ms at C2, 1.96 -> 1.68 ms at C5 (C = 180) and 22.5 -> 21.8 ms at the 192 tile against
+// 64-row workgroups (two per CU), although every weight fragment then serves half as many rows.
+template <int MT>      // 32-row MFMA tiles per workgroup: 1 (32 rows = 8 queries) or 2 (64 rows)
+__global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;                                   // [64][260]
@@ -528,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p)
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (BM / 4);          // local query index of row 0
+    HPROBE(0);
 
     // ---- index math: one thread per row (ciaosr_net.py:145-193) ---------------------------------
     int bad = 0;
@@ -564,9 +242,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p)
     if (p.G == nullptr) __syncthreads();
 
     // ================= phi_k =====================================================================
-    build_rows_mt<MT>(X, p.k, s_kpix, s_t4, t);
+    HPROBE(1);
+    build_rows<MT>(X, p.k, s_kpix, s_t4, t);
     __syncthreads();
-    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer_mt<MT>(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    HPROBE(2);
+    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer<MT>(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    HPROBE(3);
 
     if (table) {
         // logit = h4 . G[query pixel, key offset] + c  (exact fold of the output layer, head_ops.hip qk_rows):
@@ -615,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p)
         }
         for (int u = w; u < n_units; u += 4) {
             f32x16 acc[MT][1];
-            zero_acc_mt<MT, 1>(acc);
-            mma_pass_mt<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
+            zero_acc<MT, 1>(acc);
+            mma_pass<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
                         FNJ, 0, acc);
             // logit += sum_d q[d] * (key[d] * (w_k[d] + b[d]))   (ciaosr_net.py:203,214)
             float4 bv[4], kv[MT][4], qv[MT][4];
@@ -666,9 +347,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p)
     // (the barrier inside build_rows' caller below also orders s_attn)
 
     // ================= phi_v =====================================================================
-    build_rows_mt<MT>(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
+    HPROBE(4);
+    build_rows<MT>(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
     __syncthreads();
-    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer_mt<MT>(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    HPROBE(5);
+    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer<MT>(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    HPROBE(6);
     {
         const int n_units = (p.v.n_out + 31) >> 5;
         const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
@@ -700,8 +384,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p)
                 for (int mi = 0; mi < MT; ++mi) vv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : voff[mi] + doff);
             }
             f32x16 acc[MT][1];
-            zero_acc_mt<MT, 1>(acc);
-            mma_pass_mt<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
+            zero_acc<MT, 1>(acc);
+            mma_pass<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
                         FNJ, 0, acc);
             // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
             // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
@@ -724,9 +408,16 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_small_kernel(FusedKVP p)
             }
         }
     }
+    HPROBE(7);
+#ifdef CIAOSR_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_hprobe[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
+        g_hprobe[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
+    }
+#endif
 }
 
-
+// ---------------------------------------------------------------------------------------------
 template <int MT>      // 32-query MFMA tiles per workgroup: 2 (64 queries) or 1 (the tail launch)
 __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     constexpr int BM = 32 * MT;
@@ -740,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     const __amdgpu_buffer_rsrc_t rs_zin =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
     f32x16 acc[MT][2];
-    zero_acc_mt<MT, 2>(acc);
+    zero_acc<MT, 2>(acc);
     for (int k0 = 0; k0 < p.Dv; k0 += FH) {
         const int kc = min(FH, p.Dv - k0);          // multiple of 8
         if (k0 > 0) __syncthreads();                 // previous chunk fully consumed
@@ -757,14 +448,14 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
             for (int i = 0; i < BM / 4; ++i) *reinterpret_cast<float4*>(X + ((t >> 6) + 4 * i) * FLD + c4) = zv[i];
         }
         __syncthreads();
-        mma_pass_mt<MT, 2>(X + li * FLD + 4 * lh,
+        mma_pass<MT, 2>(X + li * FLD + 4 * lh,
                     reinterpret_cast<const float4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 3)) * 64 + lane,
                     kc >> 3, (long)p.nj_in * 64, acc);
     }
     __syncthreads();
-    store_relu_tile_mt<MT>(X, acc, p.bias_in, w, li, lh);
+    store_relu_tile<MT>(X, acc, p.bias_in, w, li, lh);
     __syncthreads();
-    for (int l = 0; l < p.n_hidden; ++l) hidden_layer_mt<MT>(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.n_hidden; ++l) hidden_layer<MT>(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
 
     // last Linear (256 -> 3): 4 threads per row, 64 columns each
     const bool rv = (t >> 2) < BM;                        // 32-query variant: the upper half of the threads idles
@@ -827,20 +518,20 @@ int pack_fragments(const float* W, int ld, int N, int K, float* P, hipStream_t s
     return launch_status("pack_fragments");
 }
 
-constexpr size_t kFusedLds = (size_t)(FBM * FLD + FBM * 4 + 4 * FBM + FBM) * sizeof(float) + (FBM + 16 + FBM) * sizeof(int);
-
-constexpr size_t kFusedLdsSmall = (size_t)(32 * FLD + 32 * 4 + 4 * 32 + 32) * sizeof(float) + (32 + 8 + 32) * sizeof(int);
+template <int MT>
+constexpr size_t fused_kv_lds() {
+    return (size_t)(32 * MT * FLD + 32 * MT * 4 + 4 * 32 * MT + 32 * MT) * sizeof(float) + (32 * MT + 8 * MT + 32 * MT) * sizeof(int);
+}
 
 int head_kv_fused(const FusedKVP& p, hipStream_t s) {
-    static const bool attr = (allow_big_lds(head_kv_fused_kernel, kFusedLds), allow_big_lds(head_kv_fused_small_kernel<1>, kFusedLdsSmall), true);
+    static const bool attr = (allow_big_lds(head_kv_fused_kernel<1>, fused_kv_lds<1>()), allow_big_lds(head_kv_fused_kernel<2>, fused_kv_lds<2>()), true);
     (void)attr;
-    static const int small_max = [] { const char* e = getenv("CIAOSR_KV_SMALL_MAX_PER_CU"); return e ? atoi(e) : 16; }();
-    const int wg64 = ceil_div(p.nq, FBM / 4);
+    static const int rows = [] { const char* e = getenv("CIAOSR_KV_ROWS"); return e ? atoi(e) : 32; }();   // 64: experiments
     ProfScope prof("head_kv_fused", s);
-    if (wg64 <= small_max * 256)       // few workgroups per CU: 32-row workgroups (see head_kv_fused_small_kernel)
-        hipLaunchKernelGGL(head_kv_fused_small_kernel<1>, dim3(ceil_div(p.nq, 8)), dim3(256), kFusedLdsSmall, s, p);
+    if (rows == 64)
+        hipLaunchKernelGGL(head_kv_fused_kernel<2>, dim3(ceil_div(p.nq, 16)), dim3(256), fused_kv_lds<2>(), s, p);
     else
-        hipLaunchKernelGGL(head_kv_fused_kernel, dim3(wg64), dim3(256), kFusedLds, s, p);
+        hipLaunchKernelGGL(head_kv_fused_kernel<1>, dim3(ceil_div(p.nq, 8)), dim3(256), fused_kv_lds<1>(), s, p);
     return launch_status("head_kv_fused");
 }
 

@@ -19,7 +19,7 @@ for _ in range(3):
     model.restore(lq)
 torch.cuda.synchronize()
 lib = _lib.load()
-n = 2304
+n = 4096
 buf = (C.c_ulonglong * (4096 * 16))()
 lib.ciaosr_debug_probe_read.restype = C.c_int
 assert lib.ciaosr_debug_probe_read(buf, 4096 * 16) == 0
@@ -30,8 +30,8 @@ tot = a[:, 7] - a[:, 0]
 print(f'{n} workgroups; lifetime avg {tot.mean():.0f} ticks (min {tot.min()}, max {tot.max()})')
 for i, nm in enumerate(names):
     print(f'  {nm:20s} {d[:, i].mean():9.0f} ticks avg  ({100 * d[:, i].mean() / tot.mean():5.1f} %)')
-mfma = 64 * (3 * 512 + 3 * 512 + 5 * 256)           # MFMA issue cycles of one wave: 6 hidden layers + its 5 v-out units
-print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; two workgroups share a CU)')
+mfma = 64 * (3 * 256 + 3 * 256 + 5 * 128)           # MFMA issue cycles of one wave (32-row workgroup): 6 hidden layers + its 5 v-out units
+print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; four workgroups share a CU)')
 # concurrency on a CU: how many workgroups ran on each CU and their span
 key = (a[:, 9] & 0xF) << 32 | (a[:, 8] & 0xFF00)
 for k in np.unique(key)[:3]:
