@@ -539,14 +539,14 @@ int head_decode_fused(const FusedQP& p, hipStream_t s) {
     static const bool attr = (allow_big_lds(head_decode_fused_kernel<2>, (size_t)64 * FLD * sizeof(float)),
                               allow_big_lds(head_decode_fused_kernel<1>, (size_t)32 * FLD * sizeof(float)), true);
     (void)attr;
-    // 64-query workgroups, or 32-query ones when they take fewer rounds of 256 CUs (a CU runs the MFMA phases of its
-    // workgroups back to back: C2 has 576 = 2.25 per CU -> 3 phases, against 5 half-phases for 1152 workgroups)
-    const int wg2 = ceil_div(p.nq, 64), wg1 = ceil_div(p.nq, 32);
+    // 32-query workgroups by default (four per CU; measured better than 64-query ones at C2 and at the 192 tile: 0.36 -> 0.29 ms,
+    // 3.93 -> 3.83 ms), like the phi_k/phi_v kernel
+    static const int rows = [] { const char* e = getenv("CIAOSR_DECODE_ROWS"); return e ? atoi(e) : 32; }();   // 64: experiments
     ProfScope prof("head_decode_fused", s);
-    if (ceil_div(wg1, 256) < 2 * ceil_div(wg2, 256))
-        hipLaunchKernelGGL(head_decode_fused_kernel<1>, dim3(wg1), dim3(256), (size_t)32 * FLD * sizeof(float), s, p);
+    if (rows == 64)
+        hipLaunchKernelGGL(head_decode_fused_kernel<2>, dim3(ceil_div(p.nq, 64)), dim3(256), (size_t)64 * FLD * sizeof(float), s, p);
     else
-        hipLaunchKernelGGL(head_decode_fused_kernel<2>, dim3(wg2), dim3(256), (size_t)64 * FLD * sizeof(float), s, p);
+        hipLaunchKernelGGL(head_decode_fused_kernel<1>, dim3(ceil_div(p.nq, 32)), dim3(256), (size_t)32 * FLD * sizeof(float), s, p);
     return launch_status("head_decode_fused");
 }
 
