@@ -298,7 +298,12 @@ def main():
                           'head_decode_fused': 'ciaosr::head_decode_fused_kernel'}
                 pmc_path = os.path.join(REPO, 'profiles', 'r1_c2_pmc_hbm_traffic.json')
                 if args.workload == 'c2' and os.path.exists(pmc_path) and dominant in tag2fn:
-                    pmc = json.load(open(pmc_path)).get(tag2fn[dominant])
+                    # the tag may be served by several instantiations of one kernel template: launch-weighted mean
+                    hits = [v for k, v in json.load(open(pmc_path)).items() if tag2fn[dominant] in k]
+                    pmc = None
+                    if hits:
+                        n_l = sum(h['launches'] for h in hits)
+                        pmc = dict(hbm_bytes_per_launch=round(sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n_l, 1)))
                     if pmc:
                         roof['traffic'] = pmc['hbm_bytes_per_launch']
                         roof['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1_c2_pmc_hbm_traffic.json'
@@ -309,7 +314,7 @@ def main():
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
             'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak' if weak else 'strong', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs in the head (fp32 accumulate); encoder + cs_attn f32',
+            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs (fp32 accumulate) in the head, the big-map dense layers and cs_attn contractions; small maps keep the f32 trunk',
             'data': 'synthetic',
             'config': {'workload': {'c2': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init weights, fp32',
                                     'c2q': 'C2 (query-sharded): RDN-CiaoSR (c64b16) x4, ONE LR 48x48 -> 192x192 image, random-init weights, fp32',
