@@ -779,3 +779,32 @@ def test_swinir_trunk_hip_vs_torch(dev, hw):
     err = (got - want).abs().max().item()
     print(f'swinir trunk {hw}: max|d| {err:.3e} (scale {scale:.3f})')
     assert err < 2e-4 * max(scale, 1.0), (err, scale)
+
+
+def test_bench_line_contract(dev):
+    """`python bench.py` prints ONE JSON line with the driver's contract fields, the roofline object of the dominant kernel
+    and the CPU baseline (bounded sample, same workload)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '5', '--warmup', '2'], capture_output=True,
+                         text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 5 and d['warmup'] == 2 and d['unit'] == 'Mpix/s' and d['higher_is_better'] is True
+    assert d['vs_baseline'] is None and d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    assert abs(d['value'] - 192 * 192 / 1e6 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('mfma', 'hbm') and 0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert r['staged_path_hbm_kernels']['local_attention']['frac'] >= 0.40          # north star: >= 40 % of the HBM roofline on K4
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] == 'port' and c['value'] > 0 and d['value'] / c['value'] >= 50     # north star: >= 50x the CPU path
