@@ -3,19 +3,21 @@
 
   python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-Workload (BASELINE.json configs[1], "C2"): RDN-CiaoSR (c64b16) x4, one 48x48 LR image -> 192x192,
-random-init weights (seeded, default-init scale), fp32 arithmetic, synthetic DIV2K-shaped input
-resident in HBM.  A step = CiaoSR.forward_test body: normalise -> clip_test (1 tile) -> RDN encoder
--> cs_attn -> head -> de-normalise/clamp, device to device.
-N > 1 (weak scaling): one LR image of 48 x 48N pixels = N tiles of the same 48x48 unit
-(tile_overlap 0), tile t on rank t, outputs gathered to rank 0 over RCCL and blended in the
-reference order; value = final HR pixels of the whole image / max-over-ranks time.
+Workload (default, every N): BASELINE.json's metric config "RDN-CiaoSR x4 on 2K LR input, tiled inference" (C3; C4 for
+N > 1): RDN-CiaoSR (c64b16) x4, ONE synthetic DIV2K-shaped LR image of 1356x2040 -> 5424x8160, `clip_test` tiling
+(tile 192, overlap 32 -> 117 tiles), random-init weights (seeded, default-init scale), fp32 arithmetic (the
+reference's), input resident in HBM.  A step = the CiaoSR.forward_test body on that image: normalise -> per tile
+[RDN trunk -> cs_attn -> head] -> overlap blend -> de-normalise/clamp, device to device.
+N > 1 (C4, STRONG scaling): the 117 tiles of the same image are sharded over the ranks (tile t -> rank t % N), output
+tiles travel to rank 0 over RCCL while later tiles compute, rank 0 blends in the reference order (bitwise equal to the
+1-GPU image: asserted before timing); value = HR pixels of the image / max-over-ranks time.
 
 The JSON line also carries
   roofline     algorithmic FLOPs (or bytes) of the dominant kernel per launch / its average launch
-               duration measured with HIP events inside the timed region, against the gfx950 peak
-  cpu_baseline the CPU oracle (op-for-op port of the reference, per-chunk cs_attn recompute included)
-               timed on this host's cores on the same workload (rank 0, N = 1 only).
+               duration measured with HIP events on the launch stream inside the timed region, against the gfx950 peak
+  cpu_baseline the CPU oracle (op-for-op port of the reference, per-chunk cs_attn recompute included) timed on this
+               host's cores on a bounded sample of one tile and extrapolated (rank 0, N = 1 only)
+  extras       C2 (48x48 LR) and one-tile bf16-mode timings, and the staged K4 local-attention kernel against HBM peak.
 """
 import argparse
 import json
@@ -86,20 +88,23 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     return table.get(tag)
 
 
-def cpu_baseline(scale=4):
-    """Oracle (port of the reference, configured like it) on this host's CPU cores, same workload."""
+def _cores():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return max(1, min(avail, 16))                    # small ops: more threads only add contention
+
+
+def cpu_baseline_c2(scale=4):
+    """Oracle (port of the reference, configured like it) on this host's CPU cores: the whole C2 image."""
     from oracle import ciaosr_oracle as orc          # checker / baseline only
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32))
     seeded_init_(model, seed=0, gain=1.0)
     params = {k[len('generator.'):]: v.detach() for k, v in model.state_dict().items()}
     lq, _ = synthetic_pair(48, 48, scale)
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 16))                   # small ops: more threads only add contention
-    torch.set_num_threads(cores)
+    torch.set_num_threads(_cores())
     times = []
     for i in range(4):                              # 1 warm-up + 3 timed, ~3 s each on 8 cores
         t0 = time.perf_counter()
@@ -108,23 +113,91 @@ def cpu_baseline(scale=4):
         if sum(times) > 45:
             break
     t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
-    return dict(value=out.shape[-1] * out.shape[-2] / 1e6 / t, unit='Mpix/s', cores=torch.get_num_threads(),
+    return dict(value=round(out.shape[-1] * out.shape[-2] / 1e6 / t, 5), unit='Mpix/s', cores=torch.get_num_threads(),
                 kind='port', sample=f'same workload (1 LR 48x48 -> 192x192 image), median of {len(times) - 1} '
                 f'runs after 1 warm-up, {t * 1e3:.0f} ms/img, torch CPU fp32, reference-style per-chunk cs_attn')
+
+
+def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
+    """SURVEY 8(d) CPU-baseline procedure for the tiled 2K workload: the oracle (op-for-op port of the reference) is
+    timed on a BOUNDED part of ONE 192x192 tile -- the RDN trunk once, plus ONE eval_bsize chunk of query_rgb exactly
+    as the reference runs it (materialised unfold + cs_attn recomputed inside the chunk, ciaosr_net.py:241-246 -> :135),
+    plus the same chunk with the non-local map handed in (isolates cs_attn) -- and EXTRAPOLATED to the tile
+    (ceil(Q / eval_bsize) chunks) and to the n_tiles of the image.  About 10-25 s of CPU work."""
+    from oracle import ciaosr_oracle as orc          # checker / baseline only
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    model = rdn_ciaosr(dict(scale=scale, tile=tile, tile_overlap=32))
+    seeded_init_(model, seed=0, gain=1.0)
+    params = {k[len('generator.'):]: v.detach() for k, v in model.state_dict().items()}
+    lq, _ = synthetic_pair(tile, tile, scale)
+    x = lq - torch.tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1)
+    torch.set_num_threads(_cores())
+    Q = (tile * scale) ** 2
+    coord = orc.make_coord((tile * scale, tile * scale)).unsqueeze(0)[:, :eval_bsize].contiguous()
+    cell = orc.make_cell((tile * scale, tile * scale)).unsqueeze(0)[:, :eval_bsize].contiguous()
+    with torch.no_grad():
+        orc.encoder_features(x[..., :48, :48], params)                     # warm-up of the thread pool / allocator
+        t0 = time.perf_counter()
+        feat = orc.encoder_features(x, params)
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        orc.query_rgb(feat, coord, cell, params)                           # one chunk as the reference runs it
+        t_chunk = time.perf_counter() - t0
+        nl = torch.zeros_like(feat)                                        # timing only: values do not matter
+        t0 = time.perf_counter()
+        orc.query_rgb(feat, coord, cell, params, nonlocal_map=nl)          # same chunk without the cs_attn recompute
+        t_head = time.perf_counter() - t0
+    t_csa = max(t_chunk - t_head, 0.0)
+    n_chunks = -(-Q // eval_bsize)
+    last = (Q - (n_chunks - 1) * eval_bsize) / eval_bsize
+    tile_ref = t_enc + (n_chunks - 1) * t_chunk + (t_csa + last * t_head)
+    tile_hoist = t_enc + t_csa + (Q / eval_bsize) * t_head
+    return dict(value=round(out_pixels / 1e6 / (n_tiles * tile_ref), 6), unit='Mpix/s', cores=torch.get_num_threads(),
+                kind='port',
+                sample=f'EXTRAPOLATED from a bounded sample of one {tile}x{tile} LR tile: RDN trunk {t_enc:.2f} s + one eval_bsize={eval_bsize} '
+                       f'chunk of query_rgb incl. its cs_attn recompute {t_chunk:.2f} s (cs_attn {t_csa:.2f} s, head {t_head:.2f} s) '
+                       f'-> x{n_chunks} chunks = {tile_ref:.1f} s/tile -> x{n_tiles} tiles = {n_tiles * tile_ref / 3600:.2f} h/img; '
+                       f'torch CPU fp32, {torch.get_num_threads()} threads',
+                seconds_per_tile=round(tile_ref, 2),
+                cs_attn_hoisted=dict(value=round(out_pixels / 1e6 / (n_tiles * tile_hoist), 6), unit='Mpix/s',
+                                     seconds_per_tile=round(tile_hoist, 2),
+                                     note='same port with cs_attn computed once per tile instead of once per chunk'))
+
+
+WORKLOADS = {
+    # name: (LR h, LR w, tiles, description)
+    'c3': (1356, 2040, 117, 'C3: RDN-CiaoSR (c64b16) x4, LR 1356x2040 -> 5424x8160 (DIV2K-shaped 2K LR), tiled inference: 117 tiles of '
+                            '192x192 (overlap 32), random-init weights'),
+    'c3s': (339, 510, 6, 'C3 (DIV2K-val pairing): RDN-CiaoSR x4, LR 339x510 -> 1356x2040, 6 tiles of 192 (overlap 32), random-init weights'),
+    'c3tile': (192, 192, 1, 'C3 unit: RDN-CiaoSR x4, one 192x192 LR tile -> 768x768, random-init weights'),
+    'c2': (48, 48, 1, 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192, random-init weights'),
+    'c2q': (48, 48, 1, 'C2 (query-sharded): RDN-CiaoSR (c64b16) x4, ONE LR 48x48 -> 192x192 image, random-init weights'),
+}
+
+
+def time_steps(fn, n, dev):
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / n * 1e3
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                    help='fp32 (default): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs in the fused head only')
-    ap.add_argument('--workload', default='c2', choices=['c2', 'c2q', 'c3tile', 'c3', 'c3s'],
-                    help='c2 (default, BASELINE configs[1]): LR 48x48; c3tile: one 192x192 LR tile; c3: LR 1356x2040 (117 tiles); '
-                         'c3s: LR 339x510 (6 tiles); c2q: the ONE 48x48 image of C2 with its query range sharded over the ranks after a '
-                         'broadcast of the encoder features (strong scaling).  c3 / c3s with --gpus N > 1 shard the tiles of the ONE image over the ranks (C4, strong scaling)')
+                    help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs, fp32 accumulation')
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
+                    help='c3 (default; the config BASELINE.json\'s metric is quoted on): LR 1356x2040, 117 tiles; c3s: LR 339x510 (6 tiles); '
+                         'c3tile: one 192x192 LR tile; c2: LR 48x48 (BASELINE configs[1]); c2q: C2 with its query range sharded over the ranks '
+                         'after a broadcast of the encoder features.  --gpus N > 1 (C4): the tiles of the ONE image are sharded over the ranks '
+                         '(tile t -> rank t % N), strong scaling')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -133,6 +206,8 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
     assert world == args.gpus, f'WORLD_SIZE {world} != --gpus {args.gpus}'
+    if world > 1 and args.workload in ('c2', 'c3tile'):
+        raise SystemExit(f'--workload {args.workload} is a single-tile, single-GPU measurement (use c3 / c3s for tile sharding, c2q for query sharding)')
     n_dev = torch.cuda.device_count()
     backend = os.environ.get('CIAOSR_DIST_BACKEND', 'nccl')   # 'gloo': rehearse the N-rank path on one GPU
     if backend == 'nccl' and world > n_dev:
@@ -140,29 +215,31 @@ def main():
     local_dev = local_rank % max(n_dev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
+    rccl_ranks = 1
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # ranks as the communicator itself counts them: an all-reduce of ones over RCCL
+        ones = torch.ones(1, device=dev if backend == 'nccl' else 'cpu', dtype=torch.int32)
+        dist.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == world == dist.get_world_size()
 
     from ciaosr_amd import hip_ops, _lib
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.tile_shard import clip_test_distributed, predict_query_sharded
     from ciaosr_amd.coords import make_coord, make_cell
     _lib.load()
-    hip_ops.set_precision(args.precision)
+    opt = hip_ops.Options(args.precision)
 
-    scale, lr = 4, 48
-    if args.workload == 'c3tile':
-        assert world == 1, 'c3tile is a single-tile (single-GPU) measurement'
-    weak = args.workload == 'c2'                      # c2: one 48x48 tile per rank; c3 / c3s: one image, tiles sharded
-    test_cfg = dict(scale=scale, tile=192, tile_overlap=32) if (world == 1 or not weak) else dict(scale=scale, tile=lr, tile_overlap=0)
-    model = rdn_ciaosr(test_cfg)
+    scale = 4
+    lr_h, lr_w, n_tiles_img, wl_desc = WORKLOADS[args.workload]
+    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32))
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
-    lr_h, lr_w = {'c2': (lr, lr * world), 'c2q': (lr, lr), 'c3tile': (192, 192), 'c3': (1356, 2040), 'c3s': (339, 510)}[args.workload]
     lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
     lq = lq.to(dev)
     out_pixels = (lr_h * scale) * (lr_w * scale)
@@ -173,14 +250,12 @@ def main():
 
     def step():
         if world == 1:
-            return model.restore(lq)
+            return model.restore(lq, options=opt)
         x = model.normalize(lq)
         if args.workload == 'c2q':
-            pred = predict_query_sharded(model, x, q_coord, q_cell, rank, world)
-            if rank == 0:
-                return hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
-            return None
-        pred = clip_test_distributed(model, x, rank, world)
+            pred = predict_query_sharded(model, x, q_coord, q_cell, rank, world, options=opt)
+        else:
+            pred = clip_test_distributed(model, x, rank, world, options=opt)
         if rank == 0:
             return hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
         return None
@@ -196,11 +271,12 @@ def main():
         # single-process clip_test of the same image on this GPU
         out = step()
         if rank == 0:
-            ref = model.restore(lq)[0]
+            ref = model.restore(lq, options=opt)[0]
             assert torch.equal(out, ref), f'tile-sharded output differs from 1-GPU output by {(out - ref).abs().max().item()}'
+            del ref
+        del out
 
-
-    # warm-up; the last warm-up step is fully profiled to find the dominant kernel
+    # warm-up; the last warm-up step is fully profiled (per-kernel HIP events) to find the dominant kernel
     for _ in range(max(args.warmup - 1, 0)):
         step()
     with hip_ops.profile():
@@ -208,12 +284,13 @@ def main():
         torch.cuda.synchronize(dev)
     prof_all = hip_ops.profile.results()
     dominant = max(prof_all, key=lambda k: prof_all[k]['total_ms']) if prof_all else None
+    step_ms_est = sum(v['total_ms'] for v in prof_all.values()) or 1.0
 
-    # timed region.  The dominant kernel carries HIP-event pairs inside it only when it is launched a few times
-    # per step: a pair costs ~4 us on the GPU timeline, and the 128 convolution launches of a 48x48 RDN pass
-    # would inflate a 5 ms step by ~1 ms.  Otherwise its duration is measured in a separate pass right after.
+    # timed region.  The dominant kernel carries HIP-event pairs inside it only when that is free: a pair costs ~4 us on
+    # the GPU timeline, so it is bracketed live when its launches add < 0.3 % to the step (C3: ~1000 launches of 2.4 ms),
+    # otherwise (C2: 128 dense-block launches of ~10 us) its duration is measured in a separate pass right after.
     lib = _lib.load()
-    live = bool(dominant) and prof_all[dominant]['launches'] <= 8
+    live = bool(dominant) and prof_all[dominant]['launches'] * 0.004 < 0.003 * step_ms_est
     lib.ciaosr_prof_filter(dominant.encode() if dominant else None)
     lib.ciaosr_prof_reset()
     lib.ciaosr_prof_enable(1 if live else 0)
@@ -251,17 +328,18 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        tile_lr = 48 if args.workload in ('c2', 'c2q') else 192
+        n_tiles = n_tiles_img
+        if world > 1 and args.workload != 'c2q':
+            n_tiles = (n_tiles + world - 1) // world          # tiles t = 0, R, 2R, ... run on rank 0 (whose kernels are timed)
+        Q, HW = (tile_lr * scale) ** 2, tile_lr * tile_lr
         roof = None
         if dominant and dominant in prof_dom:
-            tile_lr = lr if args.workload in ('c2', 'c2q') else 192
-            n_tiles = {'c2': 1, 'c2q': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
-            if world > 1 and not weak:
-                n_tiles = (n_tiles + world - 1) // world          # tiles t = 0, R, 2R, ... run on rank 0 (whose kernels are timed)
-            Q, HW = (tile_lr * scale) ** 2, tile_lr * tile_lr
             work = kernel_work(dominant, Q, HW)
             if work:
                 work = (work[0] * n_tiles, work[1])
             avg_ms = prof_dom[dominant]['avg_ms']
+            launches_per_step = prof_dom[dominant]['launches'] / prof_steps
             step_ms = prof_dom[dominant]['total_ms'] / prof_steps      # all launches of the tag in one step
             if work:
                 amount, kind = work
@@ -270,12 +348,14 @@ def main():
                     ach = amount / (step_ms * 1e-3) / 1e12
                     roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
                                 frac=round(ach / peak, 4), traffic=None)
+                    roof['algorithmic_flop_per_launch'] = round(amount / launches_per_step)
                 else:
                     ach = amount / (step_ms * 1e-3) / 1e9
                     roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                 frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-                roof.update(kernel=dominant, timing='HIP events inside the timed region' if live else
-                            f'HIP events in a separate pass of {prof_steps} steps (too many launches per step to bracket live)',
+                    roof['algorithmic_bytes_per_launch'] = round(amount / launches_per_step)
+                roof.update(kernel=dominant, timing='HIP events on the launch stream inside the timed region' if live else
+                            f'HIP events in a separate pass of {prof_steps} steps (too many short launches per step to bracket live)',
                             avg_launch_ms=round(avg_ms, 5),
                             launches=prof_dom[dominant]['launches'],
                             share_of_step=round(prof_all[dominant]['total_ms'] /
@@ -292,69 +372,77 @@ def main():
                     others[tag] = dict(bound='hbm' if knd == 'byte' else 'mfma', ms_per_step=round(pr['total_ms'], 4),
                                        frac=round(rate / pk, 4))
                 roof['other_kernels'] = others
-                # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction +
-                # WRITE_SIZE, tools/pmc_summary.py); offline evidence, null when the summary is absent
-                tag2fn = {'enc_dense_scatter': 'ciaosr::dense_scatter_small_kernel', 'head_kv_fused': 'ciaosr::head_kv_fused_kernel',
-                          'head_decode_fused': 'ciaosr::head_decode_fused_kernel'}
-                pmc_path = os.path.join(REPO, 'profiles', 'r1_c2_pmc_hbm_traffic.json')
-                if args.workload == 'c2' and os.path.exists(pmc_path) and dominant in tag2fn:
-                    # the tag may be served by several instantiations of one kernel template: launch-weighted mean
+                # HBM bytes per launch: OFFLINE evidence from the committed rocprofv3 --pmc passes of this round (separate
+                # passes, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_summary.py); null when the summary is absent
+                tag2fn = {'enc_dense_scatter': 'dense_scatter_small_kernel', 'enc_rdb_fused': 'rdb_fused_kernel',
+                          'head_kv_fused': 'head_kv_fused_kernel', 'head_fused': 'head_fused_kernel',
+                          'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_bf16_kernel'}
+                unit = 'c2' if tile_lr == 48 else 'c3tile'
+                pmc_path = os.path.join(REPO, 'profiles', f'r2_{unit}_pmc_hbm_traffic.json')
+                if args.precision == 'fp32' and os.path.exists(pmc_path) and dominant in tag2fn:
                     hits = [v for k, v in json.load(open(pmc_path)).items() if tag2fn[dominant] in k]
-                    pmc = None
                     if hits:
                         n_l = sum(h['launches'] for h in hits)
-                        pmc = dict(hbm_bytes_per_launch=round(sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n_l, 1)))
-                    if pmc:
-                        roof['traffic'] = pmc['hbm_bytes_per_launch']
-                        roof['traffic_note'] = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE, profiles/r1_c2_pmc_hbm_traffic.json'
-                        if dominant == 'enc_dense_scatter':   # input group + stacked weights + read-modify-write of the running sums (mean N = 288)
-                            roof['algorithmic_bytes_per_launch'] = round(HW * 4.0 * (64 + 9 * 64 * 288 / HW + 2 * 288))
+                        roof['traffic'] = round(sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n_l, 1))
+                        roof['traffic_source'] = (f'offline: bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE of the same kernel on '
+                                                  f'one {tile_lr}x{tile_lr} tile, profiles/{os.path.basename(pmc_path)} (not re-collected by this run)')
         line = {
             'metric': 'HR Mpix/s (RDN-CiaoSR x4, LocalImplicitSR forward_test)',
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
-            'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak' if weak else 'strong', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs (fp32 accumulate) in the head, the big-map dense layers and cs_attn contractions; small maps keep the f32 trunk',
+            'unit': 'Mpix/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 4), 'higher_is_better': True,
+            'scaling': 'weak' if world == 1 else 'strong', 'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions',
             'data': 'synthetic',
-            'config': {'workload': {'c2': 'C2: RDN-CiaoSR (c64b16) x4, LR 48x48 -> 192x192 per GPU, random-init weights, fp32',
-                                    'c2q': 'C2 (query-sharded): RDN-CiaoSR (c64b16) x4, ONE LR 48x48 -> 192x192 image, random-init weights, fp32',
-                                    'c3tile': 'C3 unit: RDN-CiaoSR x4, one 192x192 LR tile -> 768x768, random-init weights, fp32',
-                                    'c3': 'C3: RDN-CiaoSR x4, LR 1356x2040 -> 5424x8160, 117 tiles of 192 (overlap 32), random-init weights, fp32',
-                                    'c3s': 'C3 (DIV2K-val pairing): RDN-CiaoSR x4, LR 339x510 -> 1356x2040, 6 tiles of 192 (overlap 32), random-init weights, fp32'}[args.workload]
-                                   + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs' if args.workload == 'c2q' else
-                                                              f'; one {lr}x{lr * world} LR image, {world} tiles sharded one per GPU' if weak else
-                                                              f'; tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world})')
-                                      + (', RCCL all_gather of the RGB slices' if args.workload == 'c2q' else ', RCCL all_gather + rank-0 blend')),
-                       'lr': [lr_h, lr_w], 'scale': scale, 'queries_per_step': out_pixels,
+            'config': {'workload': wl_desc + (', fp32' if args.precision == 'fp32' else ', bf16 mode')
+                       + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs, '
+                                                 'RCCL gather of the RGB slices' if args.workload == 'c2q' else
+                                                 f' (C4); tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world}), RCCL gather of '
+                                                 'the output tiles to rank 0 overlapped with compute, rank-0 blend in the reference order')),
+                       'lr': [lr_h, lr_w], 'scale': scale, 'tiles': n_tiles_img, 'queries_per_step': out_pixels,
                        'parallelism': (f'query-shard x{world}' if args.workload == 'c2q' else f'tile-shard x{world}')},
             'roofline': roof,
             'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
                 prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
         }
-        if world == 1 and args.precision == 'fp32' and roof is not None:
-            # the HBM-bound kernels of the staged route (north star: >= 40 % of the HBM roofline on the local-attention
-            # kernel K4), measured on the same workload right after the timed region: one staged step, HIP events
-            try:
-                hip_ops.set_head_mode(1)
-                step()
-                with hip_ops.profile():
-                    step()
-                    torch.cuda.synchronize(dev)
-                st = hip_ops.profile.results()
-            finally:
-                hip_ops.set_head_mode(0)
-            tile_lr = lr if args.workload in ('c2', 'c2q') else 192
-            n_tiles = {'c2': 1, 'c2q': 1, 'c3tile': 1, 'c3': 117, 'c3s': 6}[args.workload]
+        if world == 1 and not args.no_extras and roof is not None:
+            extras = {}
+            # (1) the HBM-bound kernels of the staged route (north star: >= 40 % of the HBM roofline on the local-attention
+            # kernel K4) on ONE tile of this workload right after the timed region: one staged pass, HIP events
+            from ciaosr_amd._lib import HEAD_STAGED
+            tl = synthetic_pair(tile_lr, tile_lr, scale)[0].to(dev)
+            staged = hip_ops.Options('fp32', head_route=HEAD_STAGED)
+            model.restore(tl, options=staged)
+            with hip_ops.profile():
+                model.restore(tl, options=staged)
+                torch.cuda.synchronize(dev)
+            st = hip_ops.profile.results()
             hb = {}
             for tag in ('local_attention', 'head_rows'):
-                wk = kernel_work(tag, (tile_lr * scale) ** 2, tile_lr * tile_lr)
+                wk = kernel_work(tag, Q, HW)
                 if tag in st and wk:
-                    gbs = wk[0] * n_tiles / (st[tag]['total_ms'] * 1e-3) / 1e9
+                    gbs = wk[0] / (st[tag]['total_ms'] * 1e-3) / 1e9
                     hb[tag] = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                   frac=round(gbs / PEAK_HBM_GBS, 4), ms_per_step=round(st[tag]['total_ms'], 4))
+                                   frac=round(gbs / PEAK_HBM_GBS, 4), ms_per_tile=round(st[tag]['total_ms'], 4))
             roof['staged_path_hbm_kernels'] = hb
-        if world == 1 and not args.no_cpu_baseline and args.workload == 'c2':
-            line['cpu_baseline'] = cpu_baseline(scale)
+            # (2) the other precision / the other single-tile config, for the record (not the headline)
+            if args.workload in ('c3', 'c3s', 'c3tile'):
+                o16 = hip_ops.Options('bf16')
+                model.restore(tl, options=o16)
+                extras['c3_tile_bf16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=o16), 3, dev), 3)
+                extras['c3_tile_fp32_ms'] = round(time_steps(lambda: model.restore(tl), 3, dev), 3)
+                c2 = synthetic_pair(48, 48, scale)[0].to(dev)
+                for _ in range(3):
+                    model.restore(c2)
+                t_c2 = time_steps(lambda: model.restore(c2), 20, dev)
+                extras['c2_fp32_ms'] = round(t_c2, 4)
+                extras['c2_fp32_mpix_s'] = round(192 * 192 / 1e6 / (t_c2 * 1e-3), 3)
+            line['extras'] = extras
+        if world == 1 and not args.no_cpu_baseline:
+            if args.workload in ('c2', 'c2q'):
+                line['cpu_baseline'] = cpu_baseline_c2(scale)
+            else:
+                line['cpu_baseline'] = cpu_baseline_c3(n_tiles_img, out_pixels, scale)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

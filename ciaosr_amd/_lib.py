@@ -40,6 +40,15 @@ class CsAttnWeightsT(C.Structure):
                 ('escape_nan', C.c_float), ('softmax_scale', C.c_float)]
 
 
+class OptionsT(C.Structure):
+    """ciaosr_options_t: per-call route options (include/ciaosr_hip.h)."""
+    _fields_ = [('head_route', C.c_int), ('csa_composed_min', C.c_int), ('dense_min_tiles', C.c_int),
+                ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('reserved', C.c_int * 2)]
+
+
+HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_SPLIT_DECODE = 1, 2, 4
+
+
 class ConvT(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int),
                 ('frag16', C.c_void_p), ('frag', C.c_void_p)]
@@ -72,11 +81,14 @@ class EdsrWeightsT(C.Structure):
 
 
 _P, _I, _F, _S = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_O = C.POINTER(OptionsT)
 
-# name -> (restype, argtypes); kept in sync with include/ciaosr_hip.h (tests/test_abi.py checks both ways)
+# name -> (restype, argtypes); kept in sync with include/ciaosr_hip.h (tests/test_host_logic.py parses the header's
+# prototypes and compares names, arity and argument classes; struct sizes are compared with ciaosr_sizeof())
 SIGNATURES = {
     'ciaosr_version': (_I, []),
     'ciaosr_error_string': (C.c_char_p, [_I]),
+    'ciaosr_sizeof': (_S, [C.c_char_p]),
     'ciaosr_prof_enable': (_I, [_I]),
     'ciaosr_prof_filter': (_I, [C.c_char_p]),
     'ciaosr_prof_reset': (_I, []),
@@ -88,12 +100,11 @@ SIGNATURES = {
     'ciaosr_gemm_f32': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ciaosr_patch_rows_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P]),
     'ciaosr_cs_attn_workspace_bytes': (_S, [_I, _I, _I]),
-    'ciaosr_cs_attn_f32': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _P, _S, _P]),
-    'ciaosr_cs_attn_bf16': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _P, _S, _P]),
+    'ciaosr_cs_attn_f32': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _O, _P, _S, _P]),
+    'ciaosr_cs_attn_bf16': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _O, _P, _S, _P]),
     'ciaosr_make_coord_cell_f32': (_I, [_P, _P, _I, _I, _P]),
     'ciaosr_fragment_floats': (_S, [_I, _I]),
     'ciaosr_pack_fragments_f32': (_I, [_P, _I, _I, _I, _P, _P]),
-    'ciaosr_set_head_mode': (_I, [_I]),
     'ciaosr_fragment_bf16_bytes': (_S, [_I, _I]),
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -104,12 +115,12 @@ SIGNATURES = {
     'ciaosr_decode_residual_f32': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'ciaosr_head_workspace_bytes': (_S, [_I, _I, C.POINTER(HeadWeightsT), _I]),
     'ciaosr_head_forward_f32': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
-                                     _I, _I, _P, _P, _S, _P]),
+                                     _I, _I, _P, _O, _P, _S, _P]),
     'ciaosr_head_forward_bf16': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
-                                      _I, _I, _P, _P, _S, _P]),
+                                      _I, _I, _P, _O, _P, _S, _P]),
     'ciaosr_rdn_workspace_bytes': (_S, [_I, _I, C.POINTER(RdnWeightsT)]),
-    'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
-    'ciaosr_rdn_forward_bf16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _P, _S, _P]),
+    'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
+    'ciaosr_rdn_forward_bf16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
     'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),
     'ciaosr_edsr_forward_f32': (_I, [_P, _I, _I, C.POINTER(EdsrWeightsT), _P, _P, _S, _P]),
     'ciaosr_swinir_workspace_bytes': (_S, [_I, _I, C.POINTER(SwinirWeightsT)]),
@@ -119,6 +130,12 @@ SIGNATURES = {
     'ciaosr_tile_blend_f32': (_I, [_P, _P, _I, _I, _P, _I, _I, _I, _I, _P]),
     'ciaosr_tile_finalize_f32': (_I, [_P, _P, _P, _I, _I, _P]),
 }
+
+# ctypes mirror of every ABI struct, by the header's typedef name (layout checked against ciaosr_sizeof at load time)
+STRUCTS = {'ciaosr_options_t': OptionsT, 'ciaosr_csattn_weights_t': CsAttnWeightsT, 'ciaosr_mlp_t': MlpT,
+           'ciaosr_head_weights_t': HeadWeightsT, 'ciaosr_conv_t': ConvT, 'ciaosr_rdn_weights_t': RdnWeightsT,
+           'ciaosr_edsr_weights_t': EdsrWeightsT, 'ciaosr_swin_block_t': SwinBlockT,
+           'ciaosr_swinir_weights_t': SwinirWeightsT}
 
 _lib = None
 
@@ -138,6 +155,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, st in STRUCTS.items():
+        want = lib.ciaosr_sizeof(name.encode())
+        if want != C.sizeof(st):
+            raise CiaoSRHipError(f'ABI drift: sizeof({name}) is {want} in {LIB_PATH} but {C.sizeof(st)} in the ctypes mirror')
     _lib = lib
     return lib
 

@@ -1,6 +1,7 @@
 // Shared host-side helpers for libciaosr_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 
@@ -26,17 +27,34 @@ struct ProfScope {
     ~ProfScope();
 };
 
-// > 64 KiB of dynamic LDS needs the attribute once per kernel.
+// > 64 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  The attribute belongs to the
+// (kernel, device) pair, so the one-time setup is tracked per device: `done` is a zero-initialised flag array owned by the
+// call site (one per kernel).  Racing first calls both set the same value, which is harmless.  Returns false if HIP refuses.
+constexpr int kMaxDevices = 32;
+struct LdsAttrOnce { std::atomic<unsigned char> done[kMaxDevices]; };
 template <typename K>
-static inline void allow_big_lds(K kernel, size_t bytes) {
-    if (bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+static inline bool allow_big_lds(LdsAttrOnce& once, K kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return true;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
+    if (once.done[dev].load(std::memory_order_acquire)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
+        hipSuccess)
+        return false;
+    once.done[dev].store(1, std::memory_order_release);
+    return true;
 }
 
 int launch_status(const char* what);
 
 }  // namespace ciaosr
+
+// one-time (per device) > 64 KiB LDS opt-in for `kernel`; returns CIAOSR_ERR_LAUNCH from the enclosing function on failure
+#define CIAOSR_BIG_LDS(kernel, bytes)                                                              \
+    do {                                                                                           \
+        static ::ciaosr::LdsAttrOnce once_;                                                        \
+        if (!::ciaosr::allow_big_lds(once_, kernel, bytes)) return CIAOSR_ERR_LAUNCH;              \
+    } while (0)
 
 #define CIAOSR_CHECK_ARG(cond)                                                         \
     do {                                                                               \

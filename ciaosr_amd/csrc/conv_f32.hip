@@ -27,7 +27,6 @@
 //
 // Replaces the encoder trunk convolutions the reference runs through torch conv2d:
 // RDN / EDSR `gen_feature` (ciaosr_net.py:321-342, :393-408).
-#include <cstdlib>
 
 #include "ops.h"
 
@@ -444,27 +443,20 @@ __global__ void conv_reduce_kernel(ConvP p) {
 }
 
 // ---- launch policy ------------------------------------------------------------------------------
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 template <int TM, int TN>
-static void launch_tile(const ConvP& p, int tiles, hipStream_t s) {
+static int launch_tile(const ConvP& p, int tiles, hipStream_t s) {
     constexpr size_t lds = ConvCfg<TM, TN>::lds;
     auto kernel = conv_gemm_kernel<TM, TN>;
-    static const bool attr = (allow_big_lds(kernel, lds), true);      // thread-safe one-time setup (C++11 static init)
-    (void)attr;
+    CIAOSR_BIG_LDS(kernel, lds);
     hipLaunchKernelGGL(kernel, dim3(tiles, p.splitk), dim3(512), lds, s, p);
+    return CIAOSR_OK;
 }
 
 // picks the tile shape and the K split, launches the GEMM (+ the slab reduce); p.* geometry already filled
 static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStream_t s, const char* tag) {
-    static const int force_tile = env_int("CIAOSR_CONV_TILE", 0);     // 32 or 64: tuning / experiments
-    static const int target_wg = env_int("CIAOSR_CONV_TARGET_WG", 512);
-    static const int use_halo = env_int("CIAOSR_CONV_HALO", 1);
+    constexpr int target_wg = 512;
     const long halo_tiles = (long)ceil_div(p.H, HT) * ceil_div(p.W, HT) * ceil_div(p.Cout, 32);
-    if (use_halo && p.taps == 9 && (p.Cin & 63) == 0 && halo_tiles <= 4096) {
+    if (p.taps == 9 && (p.Cin & 63) == 0 && halo_tiles <= 4096) {
         // small 3x3 layers: halo-resident A tile, 8x8 pixels x 32 output channels per workgroup (the per-workgroup
         // fixed costs -- halo fill, K-slice reduction, read-modify-write epilogue: ~55 % of its cycles by the
         // in-kernel probe -- make the plain 64x64 tap kernel the faster one on big images, where tiles abound)
@@ -485,8 +477,7 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
         p.partial = partial;
         {
             ProfScope prof(tag, s);
-            static const bool attr = (allow_big_lds(conv3x3_halo_kernel, kHaloLds), true);      // thread-safe one-time setup (C++11 static init)
-            (void)attr;
+            CIAOSR_BIG_LDS(conv3x3_halo_kernel, kHaloLds);
             hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(tiles, p.splitk), dim3(512), kHaloLds, s, p);
         }
         int rc = launch_status("conv3x3_halo");
@@ -504,10 +495,9 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
     const long out32 = (long)ceil_div(p.M, 32) * ceil_div(p.Cout, 32);
     // small output (a 48x48 layer): 32x32 tiles spread it over every CU; large output: 64x64 tiles halve the
     // operand traffic per MAC
-    int tm = (out32 <= 4096) ? 32 : 64;        // (128x64, one workgroup per CU, measured 7 % slower than 64x64 at the 192 tile)
-    if (force_tile == 32 || force_tile == 64 || force_tile == 128) tm = force_tile;
+    const int tm = (out32 <= 4096) ? 32 : 64;        // (128x64, one workgroup per CU, measured 7 % slower than 64x64 at the 192 tile)
     if (p.dense_step >= 0 && (p.Cout & 63)) return CIAOSR_ERR_BAD_ARG;
-    const int tn = tm == 128 ? 64 : tm;        // 128x64: 8 MFMA tiles, one per wave, no K-slicing
+    const int tn = tm;
     p.tiles_n = ceil_div(p.Cout, tn);
     const int tiles = ceil_div(p.M, tm) * p.tiles_n;
     int splitk = 1;
@@ -524,9 +514,8 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
     p.partial = partial;
     {
         ProfScope prof(tag, s);
-        if (tm == 32) launch_tile<32, 32>(p, tiles, s);
-        else if (tm == 64) launch_tile<64, 64>(p, tiles, s);
-        else launch_tile<128, 64>(p, tiles, s);
+        const int rc_attr = tm == 32 ? launch_tile<32, 32>(p, tiles, s) : launch_tile<64, 64>(p, tiles, s);
+        if (rc_attr != CIAOSR_OK) return rc_attr;
     }
     int rc = launch_status("conv_gemm");
     if (rc != CIAOSR_OK) return rc;

@@ -14,8 +14,6 @@
 //
 // The score matrix is materialised in HBM (1.36 GB at the 192x192 tile: < 1 % of 288 GB and two
 // passes at HBM speed, against 1.76 TFLOP of MFMA work).
-#include <cstdlib>
-
 #include "ops.h"
 
 namespace ciaosr {
@@ -66,7 +64,7 @@ extern "C" size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C) {
 }
 
 static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w, float* out, int ld_out,
-                   void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
+                   const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
     CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
     const int C = w->channels;
     CIAOSR_CHECK_ARG(C >= 4 && (C & 3) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
@@ -110,11 +108,13 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
     RUN(patch_rows(R, p.Ch, p.Hp / 2, p.Wp / 2, p.Ch, 3, 1, 1, p.Hp / 2, p.Wp / 2, Kn, 9 * p.Ch, 1, w->escape_nan, s,
                    "csa_patch_k"));
-    static const int b3_min_16 = [] { const char* e = getenv("CIAOSR_CSA_COMPOSED_MIN"); return e ? atoi(e) : 4096; }();
+    // composed fold+down tail from this many (padded) LR pixels on: per-call option, default 4096
+    const int composed_min = opt && opt->csa_composed_min ? opt->csa_composed_min : 4096;
+    const bool composed = w->w_down_masked && composed_min > 0 && HWp >= composed_min;
     // bf16 mode (big maps, composed tail): Q.K^T and P.V' on the bf16 MFMA (gemm_bf16.hip); logits and softmax in fp32,
     // probabilities rounded to bf16; 1x1 convolutions, the partial down-convolutions and the final gather stay fp32
     const size_t qk16_bytes = ((size_t)HWp + p.L) * 9 * p.Ch * 2 + 512;
-    if (bf16 && w->w_down_masked && HWp >= b3_min_16 && (9 * p.Ch) % 8 == 0 && (p.Lld & 3) == 0 &&
+    if (bf16 && composed && (9 * p.Ch) % 8 == 0 && (p.Lld & 3) == 0 &&
         qk16_bytes <= p.n_Y * sizeof(float) && (size_t)25 * C * p.Lld8 * 2 <= p.n_V * sizeof(float)) {
         const int Hh = p.Hp / 2, Wh = p.Wp / 2, Kq = 9 * p.Ch;
         unsigned short* Qb = reinterpret_cast<unsigned short*>(Y);
@@ -137,8 +137,7 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
                  CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
     RUN(softmax_rows(S, HWp, p.L, p.Lld, s));
-    static const int b3_min = [] { const char* e = getenv("CIAOSR_CSA_COMPOSED_MIN"); return e ? atoi(e) : 4096; }();
-    if (w->w_down_masked && HWp >= b3_min) {
+    if (composed) {
         // composed fold + down (patch_ops.hip): attn.V with N = 16C instead of 36C, no 2x map, no separate down conv
         const int Hh = p.Hp / 2, Wh = p.Wp / 2;
         float* Otop = Ov;
@@ -177,11 +176,13 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
 }
 
 extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
-                                  float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream) {
-    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, workspace, workspace_bytes, stream, false);
+                                  float* out, int ld_out, const ciaosr_options_t* opt, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, false);
 }
 
 extern "C" int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
-                                   float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream) {
-    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, workspace, workspace_bytes, stream, true);
+                                   float* out, int ld_out, const ciaosr_options_t* opt, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, true);
 }

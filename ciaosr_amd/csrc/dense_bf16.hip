@@ -19,7 +19,6 @@
 //     LDS traffic is ~75 B/clk/CU at the full MFMA rate, under the 128 B/clk limit;
 //   * the K-slices are summed through LDS once per layer (fixed order: deterministic) in the epilogue.
 // Swapped operands (weights = A, activations = B): a lane owns one pixel and 4x4 consecutive channels.
-#include <cstdlib>
 
 #include "bf16_util.h"
 #include "ops.h"
@@ -199,11 +198,6 @@ __global__ void cast_group_bf16_kernel(const float* __restrict__ X, int ldx, uns
     }
 }
 
-int dense_bf16_min_tiles() {
-    const char* e = getenv("CIAOSR_DENSE_BF16_MIN_TILES");     // read per call: tests lower it for small maps
-    return e ? atoi(e) : 128;
-}
-
 int dense_bf16_tiles(int H, int W) { return ceil_div(H, DT) * ceil_div(W, DT); }
 
 int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s) {
@@ -227,8 +221,7 @@ int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int
     p.wf = reinterpret_cast<const uint4*>(frag16); p.nks = 9 * 64 * (l + 1) / 16;
     p.bias = bias;
     p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
-    static const bool attr = (allow_big_lds(dense_bf16_kernel, kDenseLds), true);      // thread-safe one-time setup (C++11 static init)
-    (void)attr;
+    CIAOSR_BIG_LDS(dense_bf16_kernel, kDenseLds);
     ProfScope prof("enc_dense_bf16", s);
     hipLaunchKernelGGL(dense_bf16_kernel, dim3(dense_bf16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     return launch_status("dense_bf16");

@@ -14,7 +14,6 @@
 //   * per group a workgroup ingests 50 KB of patch + 147 KB of weights against 46k cycles of MFMA work (4.3 B/clk/CU);
 //   * the K-slices are summed through LDS once per layer, in a fixed order (deterministic).
 // Same MACs as the reference convolution, fp32 products and sums; only the summation order differs from conv_f32.hip.
-#include <cstdlib>
 
 #include "ops.h"
 
@@ -189,11 +188,6 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
     }
 }
 
-int dense_f32_min_tiles() {
-    const char* e = getenv("CIAOSR_DENSE_F32_MIN_TILES");       // read per call: tests lower it for small maps
-    return e ? atoi(e) : 128;
-}
-
 int dense_f32_tiles(int H, int W) { return ceil_div(H, FT) * ceil_div(W, FT); }
 
 // dense layer l of a block: input groups 0..l of X, output group l+1
@@ -208,8 +202,7 @@ int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, c
     p.wf = reinterpret_cast<const float4*>(frag); p.nj = 9 * 64 * (l + 1) / 8;
     p.bias = bias;
     p.col_out = 64 * (l + 1);
-    static const bool attr = (allow_big_lds(dense_f32_kernel, kDenseF32Lds), true);      // thread-safe one-time setup (C++11 static init)
-    (void)attr;
+    CIAOSR_BIG_LDS(dense_f32_kernel, kDenseF32Lds);
     ProfScope prof("enc_dense_gather", s);
     hipLaunchKernelGGL(dense_f32_kernel, dim3(dense_f32_tiles(H, W)), dim3(256), kDenseF32Lds, s, p);
     return launch_status("dense_f32");

@@ -17,7 +17,6 @@
 //   * 4 waves (K-sliced) instead of 8 and 32 KB of LDS: several workgroups share a CU and overlap each other's
 //     prologue / reduction / epilogue with MFMA work.
 // Fixed-order K-slice reduction through LDS: deterministic.  Out-of-image accesses go through buffer descriptors.
-#include <cstdlib>
 
 #include "ops.h"
 
@@ -194,11 +193,6 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
 #endif
 }
 
-int dense_scatter_small_max_pixels() {
-    const char* e = getenv("CIAOSR_SCATTER_SMALL_MAX");         // read per call (tests / experiments)
-    return e ? atoi(e) : 18432;      // = 128 tiles of 12x12: every larger map has >= 128 tiles and takes dense_f32.hip
-}
-
 int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layers, const float* frag, const float* bias_all,
                         float* acc_buf, hipStream_t s) {
     CIAOSR_CHECK_ARG(X && frag && bias_all && acc_buf && (ldx & 3) == 0 && step >= 0 && step < num_layers);
@@ -214,10 +208,9 @@ int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layer
     p.bias = bias_all;
     // 8x8-pixel workgroups, or 8x4 when that takes fewer rounds of 256 CUs (workgroups of a CU run their MFMA phases back to
     // back: a step costs ceil(WGs / 256) phases; half-size phases quantise finer at twice the weight stream per MAC)
-    static const int force_mt = [] { const char* e = getenv("CIAOSR_SCATTER_MT"); return e ? atoi(e) : 0; }();
     const int wg2 = ceil_div(H, 8) * p.tiles_x * p.n32, wg1 = ceil_div(H, 4) * p.tiles_x * p.n32;
     const int cost2 = 2 * ceil_div(wg2, 256), cost1 = ceil_div(wg1, 256);       // in half-phase units
-    const bool use1 = force_mt ? force_mt == 1 : cost1 < cost2;
+    const bool use1 = cost1 < cost2;
     ProfScope prof("enc_dense_scatter", s);
     if (use1)
         hipLaunchKernelGGL(dense_scatter_small_kernel<1>, dim3(wg1), dim3(256), kScatterLds, s, p);

@@ -14,18 +14,15 @@ int dense_scatter_step(float* X, int ldx, int H, int W, int step, int num_layers
                        float* acc_buf, float* partial, size_t partial_floats, hipStream_t s);
 
 // dense_bf16.hip
-int dense_bf16_min_tiles();
 int dense_bf16_tiles(int H, int W);
 int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);
 int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
                      const float* bias, hipStream_t s);
 
 // dense_scatter_f32.hip
-int dense_scatter_small_max_pixels();
 int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layers, const float* frag, const float* bias_all,
                         float* acc_buf, hipStream_t s);
 // dense_f32.hip
-int dense_f32_min_tiles();
 int dense_f32_tiles(int H, int W);
 int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, hipStream_t s);
 
@@ -80,8 +77,12 @@ extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weig
     return n * sizeof(float) + 16 * 256;
 }
 
-static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc, void* workspace,
-                       size_t workspace_bytes, void* stream_, bool bf16) {
+static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                       const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
+    // route thresholds (per-call options; defaults: halo-resident dense layers from 128 tiles of 12x12 pixels on, small-map
+    // kernels up to 18432 pixels = 128 such tiles)
+    const int min_tiles = opt && opt->dense_min_tiles ? opt->dense_min_tiles : 128;
+    const int small_max = opt && opt->scatter_small_max ? opt->scatter_small_max : 18432;
     CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
     const int C = w->mid_channels, G = w->growth, NB = w->num_blocks, NL = w->num_layers;
     CIAOSR_CHECK_ARG(C % 32 == 0 && G % 32 == 0 && NB >= 1 && NL >= 1 && w->dense && w->lff);
@@ -106,11 +107,11 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
     // bf16 mode: the dense layers (97 % of the trunk's MACs) run on the bf16 MFMA when the map is big enough to give
     // every CU a tile (dense_bf16.hip); first/last convolutions, LFF/GFF 1x1 and all residual sums stay fp32
-    bool dense16 = bf16 && C == 64 && G == 64 && dense_bf16_tiles(H, W) >= dense_bf16_min_tiles();
+    bool dense16 = bf16 && C == 64 && G == 64 && min_tiles > 0 && dense_bf16_tiles(H, W) >= min_tiles;
     if (bf16)
         for (int i = 0; i < NB * NL && dense16; ++i) dense16 = w->dense[i].frag16 != nullptr;
     // big maps, fp32: halo-resident gather-form dense layers (dense_f32.hip) instead of the scatter form
-    bool dense32 = !dense16 && C == 64 && G == 64 && dense_f32_tiles(H, W) >= dense_f32_min_tiles();
+    bool dense32 = !dense16 && C == 64 && G == 64 && min_tiles > 0 && dense_f32_tiles(H, W) >= min_tiles;
     for (int i = 0; i < NB * NL && dense32; ++i) dense32 = w->dense[i].frag != nullptr;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
@@ -136,7 +137,7 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
         } else if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
             // scatter form: input group s (64 channels) feeds every later dense layer in ONE convolution with
             // N = 64*(NL-s) output channels and K = 576: no split-K slabs, 8 launches instead of 16
-            const bool small = w->scatter_frag && (long)HW <= dense_scatter_small_max_pixels();
+            const bool small = w->scatter_frag && (long)HW <= small_max;
             for (int st = 0; st < NL; ++st) {
                 if (small && w->scatter_frag[b * NL + st])
                     RUN(dense_scatter_small(x, cb, H, W, st, NL, w->scatter_frag[b * NL + st], w->scatter_bias + (size_t)b * NL * 64,
@@ -177,13 +178,15 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
 }
 
 extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
-                                      float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, workspace, workspace_bytes, stream, false);
+                                      float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, false);
 }
 
 extern "C" int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
-                                       float* feat_hwc, void* workspace, size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, workspace, workspace_bytes, stream, true);
+                                       float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, true);
 }
 
 extern "C" size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w) {

@@ -230,8 +230,7 @@ int gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int 
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
     p.n_wg = ceil_div(M, GM) * p.tiles_n;
-    static const bool attr = (allow_big_lds(gemm_bf16_kernel, kGemm16Lds), true);      // thread-safe one-time setup (C++11 static init)
-    (void)attr;
+    CIAOSR_BIG_LDS(gemm_bf16_kernel, kGemm16Lds);
     ProfScope prof(tag ? tag : "gemm_bf16", s);
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
     return launch_status("gemm_bf16");

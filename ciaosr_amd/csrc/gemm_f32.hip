@@ -256,8 +256,8 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
 
 static int gemm_launch(GemmP& p, bool b_kn, hipStream_t stream, const char* tag) {
     const size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);
-    static const bool attr_done = (allow_big_lds(gemm_f32_kernel<true>, smem), allow_big_lds(gemm_f32_kernel<false>, smem), true);
-    (void)attr_done;
+    CIAOSR_BIG_LDS(gemm_f32_kernel<true>, smem);
+    CIAOSR_BIG_LDS(gemm_f32_kernel<false>, smem);
     {
         ProfScope prof(tag ? tag : (b_kn ? "gemm_f32_nn" : "gemm_f32_nt"), stream);
         if (b_kn)

@@ -79,9 +79,6 @@ static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA
     return CIAOSR_OK;
 }
 
-static int g_head_mode = 0;
-static int g_logit_table = 1; // exact output-layer fold of imnet_k (head_ops.hip qk_rows)
-
 // fused kernels: hidden width 256 everywhere, fragments packed, 4 key samples
 static bool chain_fused_ok(const ciaosr_mlp_t& m, bool is_q, bool bf16) {
     if (m.n_layers < 2) return false;
@@ -110,14 +107,6 @@ static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table,
 
 using namespace ciaosr;
 
-extern "C" int ciaosr_set_head_mode(int mode) {
-    // bit 0: force the staged path; bit 1: disable the logit table of the fused path
-    g_logit_table = (mode & 2) ? 0 : 1;
-    mode &= 1;
-    g_head_mode = mode;
-    return CIAOSR_OK;
-}
-
 extern "C" size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w, int Q) {
     if (!w || H <= 0 || W <= 0 || Q <= 0) return 0;
     return head_ws_bytes(head_plan(H, W, w, Q));
@@ -125,8 +114,10 @@ extern "C" size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_we
 
 static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                         const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw, const float* coord,
-                        const float* cell, int Q, int chunk, float* rgb, void* workspace, size_t workspace_bytes,
-                        void* stream_, bool bf16) {
+                        const float* cell, int Q, int chunk, float* rgb, const ciaosr_options_t* opt, void* workspace,
+                        size_t workspace_bytes, void* stream_, bool bf16) {
+    const int route = opt ? opt->head_route : 0;
+    CIAOSR_CHECK_ARG(!opt || (opt->reserved[0] == 0 && opt->reserved[1] == 0));
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
     CIAOSR_CHECK_ARG(w->local_size >= 1 && w->local_size <= 3 && w->softmax_scale != 0.f);
@@ -168,7 +159,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     // unfold rows U[:, :9C] (net:132-136) and the non-local map into U[:, 9C:] (net:134-137)
     RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
     if (csattn)
-        RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, csa_ws, p.csa_bytes, stream_));
+        RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, opt, csa_ws, p.csa_bytes, stream_));
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     if (gemm_small_ok(p.HW, p.wk0, p.D, p.Dv, w->k.ld[0]) && gemm_small_ok(p.HW, p.wv0, p.Dv, p.Dv, w->v.ld[0]) && p.HW <= 4096) {
         RUN(gemm_small_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], w->k.bias[0], Tk, p.wk0, nullptr, 0, nullptr, 0, p.HW, p.wk0, p.D,
@@ -182,11 +173,11 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                      CIAOSR_ACT_NONE, 0.f, s, "head_table"));
     }
 
-    const bool fused = g_head_mode == 0 && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
+    const bool fused = !(route & CIAOSR_HEAD_STAGED) && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
                        chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
     if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the bf16 mode exists for the fused kernels only
     // logit table of imnet_k's output layer (exact fold, head_ops.hip): pays off when queries outnumber LR pixels
-    const bool use_table = fused && g_logit_table && w->k.width[w->k.n_layers - 1] == p.D && w->k.width[w->k.n_layers - 2] == 256 &&
+    const bool use_table = fused && !(route & CIAOSR_HEAD_NO_LOGIT_TABLE) && w->k.width[w->k.n_layers - 1] == p.D && w->k.width[w->k.n_layers - 2] == 256 &&
                            (long)Q * p.J > (long)p.HW * 9 && (size_t)p.HW * 9 * kLdG * sizeof(float) < 0xFFFFFF00ull;
     if (use_table) {
         const int last = w->k.n_layers - 1;
@@ -218,6 +209,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             fill_chain(kp.v, w->v, Tv, p.Dv, bf16);
             kp.softmax_scale = w->softmax_scale;
             kp.Z = Z; kp.ldz = p.Dv;
+            kp.rows_per_wg = opt ? opt->kv_rows : 0;
             kp.G = use_table ? G : nullptr; kp.ldg = kLdG; kp.g_bytes = (unsigned)((size_t)p.HW * 9 * kLdG * sizeof(float));
             RUN(bf16 ? head_kv_fused_bf16(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
@@ -232,6 +224,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             }
             qp.w_last = mq.weight[mq.n_layers - 1]; qp.ld_last = mq.ld[mq.n_layers - 1];
             qp.b_last = mq.bias[mq.n_layers - 1];
+            qp.rows_per_wg = opt ? opt->decode_rows : 0;
             qp.x_lr = x_lr_nchw; qp.coord = coord; qp.q0 = q0; qp.nq = nq; qp.H = H; qp.W = W; qp.rgb = rgb;
             RUN(bf16 ? head_decode_fused_bf16(qp, s) : head_decode_fused(qp, s));
             continue;
@@ -275,16 +268,16 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
 extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                                        const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                                        const float* coord, const float* cell, int Q, int chunk, float* rgb,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
-    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, workspace, workspace_bytes,
+                                       const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
+    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, opt, workspace, workspace_bytes,
                         stream, false);
 }
 
 extern "C" int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                                         const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                                         const float* coord, const float* cell, int Q, int chunk, float* rgb,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
-    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, workspace, workspace_bytes,
+                                        const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
+    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, opt, workspace, workspace_bytes,
                         stream, true);
 }
 

@@ -15,7 +15,6 @@
 // (weights are shared by every workgroup and never staged in LDS).  4 waves split the output columns;
 // layers run in place: all waves finish reading X, barrier, write bias+ReLU results, barrier.
 // Four 32-row workgroups per CU (34.5 KB of LDS each) overlap each other's epilogue/barrier bubbles with MFMAs.
-#include <cstdlib>
 
 #include "bf16_util.h"
 #include "index_math.h"
@@ -524,9 +523,9 @@ constexpr size_t fused_kv_lds() {
 }
 
 int head_kv_fused(const FusedKVP& p, hipStream_t s) {
-    static const bool attr = (allow_big_lds(head_kv_fused_kernel<1>, fused_kv_lds<1>()), allow_big_lds(head_kv_fused_kernel<2>, fused_kv_lds<2>()), true);
-    (void)attr;
-    static const int rows = [] { const char* e = getenv("CIAOSR_KV_ROWS"); return e ? atoi(e) : 32; }();   // 64: experiments
+    CIAOSR_BIG_LDS(head_kv_fused_kernel<1>, fused_kv_lds<1>());
+    CIAOSR_BIG_LDS(head_kv_fused_kernel<2>, fused_kv_lds<2>());
+    const int rows = p.rows_per_wg == 64 ? 64 : 32;   // 64: experiments (ciaosr_options_t.kv_rows)
     ProfScope prof("head_kv_fused", s);
     if (rows == 64)
         hipLaunchKernelGGL(head_kv_fused_kernel<2>, dim3(ceil_div(p.nq, 16)), dim3(256), fused_kv_lds<2>(), s, p);
@@ -536,12 +535,11 @@ int head_kv_fused(const FusedKVP& p, hipStream_t s) {
 }
 
 int head_decode_fused(const FusedQP& p, hipStream_t s) {
-    static const bool attr = (allow_big_lds(head_decode_fused_kernel<2>, (size_t)64 * FLD * sizeof(float)),
-                              allow_big_lds(head_decode_fused_kernel<1>, (size_t)32 * FLD * sizeof(float)), true);
-    (void)attr;
+    CIAOSR_BIG_LDS(head_decode_fused_kernel<2>, (size_t)64 * FLD * sizeof(float));
+    CIAOSR_BIG_LDS(head_decode_fused_kernel<1>, (size_t)32 * FLD * sizeof(float));
     // 32-query workgroups by default (four per CU; measured better than 64-query ones at C2 and at the 192 tile: 0.36 -> 0.29 ms,
     // 3.93 -> 3.83 ms), like the phi_k/phi_v kernel
-    static const int rows = [] { const char* e = getenv("CIAOSR_DECODE_ROWS"); return e ? atoi(e) : 32; }();   // 64: experiments
+    const int rows = p.rows_per_wg == 64 ? 64 : 32;   // 64: experiments (ciaosr_options_t.decode_rows)
     ProfScope prof("head_decode_fused", s);
     if (rows == 64)
         hipLaunchKernelGGL(head_decode_fused_kernel<2>, dim3(ceil_div(p.nq, 64)), dim3(256), (size_t)64 * FLD * sizeof(float), s, p);

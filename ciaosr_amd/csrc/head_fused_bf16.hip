@@ -467,8 +467,7 @@ int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream
 constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32 + HBM_) * sizeof(int);
 
 int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
-    static const bool attr = (allow_big_lds(head_kv_fused_bf16_kernel, kFused16Lds), true);      // thread-safe one-time setup (C++11 static init)
-    (void)attr;
+    CIAOSR_BIG_LDS(head_kv_fused_bf16_kernel, kFused16Lds);
     ProfScope prof("head_kv_fused_bf16", s);
     hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
     return launch_status("head_kv_fused_bf16");
@@ -476,8 +475,7 @@ int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
 
 int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
     const size_t lds = (size_t)HBM_ * HLD * 2;
-    static const bool attr = (allow_big_lds(head_decode_fused_bf16_kernel, lds), true);      // thread-safe one-time setup (C++11 static init)
-    (void)attr;
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel, lds);
     ProfScope prof("head_decode_fused_bf16", s);
     hipLaunchKernelGGL(head_decode_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_)), dim3(256), lds, s, p);
     return launch_status("head_decode_fused_bf16");

@@ -117,6 +117,7 @@ struct FusedKVP {
     const float* G;
     int ldg;
     unsigned g_bytes;
+    int rows_per_wg;   // fp32 kernel: 32 (0 = default) or 64
 };
 struct FusedQP {
     const float* Z; int ldz, Dv;
@@ -133,6 +134,7 @@ struct FusedQP {
     long q0;
     int nq, H, W;
     float* rgb;
+    int rows_per_wg;   // fp32 kernel: 32 (0 = default) or 64
 };
 int head_kv_fused(const FusedKVP& p, hipStream_t s);
 int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s);

@@ -1,4 +1,5 @@
 // Library runtime: version, error strings, launch status, opt-in per-kernel event timing.
+#include <cstring>
 #include "common.h"
 
 #include <mutex>
@@ -70,7 +71,26 @@ int launch_status(const char* what) {
 
 using namespace ciaosr;
 
-extern "C" int ciaosr_version(void) { return 100; }
+extern "C" int ciaosr_version(void) { return 200; }
+
+// sizeof of every struct of the ABI, by name: lets a binding (ciaosr_amd/_lib.py's ctypes mirrors) verify its layout
+extern "C" size_t ciaosr_sizeof(const char* type_name) {
+    if (!type_name) return 0;
+    const struct { const char* n; size_t s; } tab[] = {
+        {"ciaosr_options_t", sizeof(ciaosr_options_t)},
+        {"ciaosr_csattn_weights_t", sizeof(ciaosr_csattn_weights_t)},
+        {"ciaosr_mlp_t", sizeof(ciaosr_mlp_t)},
+        {"ciaosr_head_weights_t", sizeof(ciaosr_head_weights_t)},
+        {"ciaosr_conv_t", sizeof(ciaosr_conv_t)},
+        {"ciaosr_rdn_weights_t", sizeof(ciaosr_rdn_weights_t)},
+        {"ciaosr_edsr_weights_t", sizeof(ciaosr_edsr_weights_t)},
+        {"ciaosr_swin_block_t", sizeof(ciaosr_swin_block_t)},
+        {"ciaosr_swinir_weights_t", sizeof(ciaosr_swinir_weights_t)},
+    };
+    for (const auto& e : tab)
+        if (std::strcmp(e.n, type_name) == 0) return e.s;
+    return 0;
+}
 
 extern "C" const char* ciaosr_error_string(int code) {
     switch (code) {

@@ -135,8 +135,9 @@ class PackedEncoder:
         return n.conv_first.in_channels == 3
 
     @torch.no_grad()
-    def forward_hwc(self, x_chw):
-        """x [3,H,W] normalised LR (GPU) -> feature [H,W,C] channels-last."""
+    def forward_hwc(self, x_chw, options=None):
+        """x [3,H,W] normalised LR (GPU) -> feature [H,W,C] channels-last.  `options`: hip_ops.Options."""
+        opt = hip_ops.as_options(options)
         x_chw = x_chw.contiguous().float()
         hip_ops.require_gpu(x_chw)
         _, H, W = x_chw.shape
@@ -144,12 +145,16 @@ class PackedEncoder:
         lib = _lib.load()
         if self.kind == 'rdn':
             nbytes = lib.ciaosr_rdn_workspace_bytes(H, W, C.byref(st))
-            fn = 'ciaosr_rdn_forward_bf16' if hip_ops.precision() == 'bf16' else 'ciaosr_rdn_forward_f32'
+            fn = 'ciaosr_rdn_forward_bf16' if opt.bf16 else 'ciaosr_rdn_forward_f32'
         else:
             nbytes = lib.ciaosr_edsr_workspace_bytes(H, W, C.byref(st))
             fn = 'ciaosr_edsr_forward_f32'
         ws = hip_ops.workspace(nbytes, x_chw.device, slot='encoder')
         out = torch.empty(H, W, st.mid_channels, dtype=torch.float32, device=x_chw.device)
-        _lib.call(fn, hip_ops.ptr(x_chw), H, W, C.byref(st), hip_ops.ptr(out), hip_ops.ptr(ws), ws.numel(),
-                  hip_ops.stream_ptr())
+        if self.kind == 'rdn':
+            _lib.call(fn, hip_ops.ptr(x_chw), H, W, C.byref(st), hip_ops.ptr(out), opt.c_arg(), hip_ops.ptr(ws), ws.numel(),
+                      hip_ops.stream_ptr())
+        else:
+            _lib.call(fn, hip_ops.ptr(x_chw), H, W, C.byref(st), hip_ops.ptr(out), hip_ops.ptr(ws), ws.numel(),
+                      hip_ops.stream_ptr())
         return out

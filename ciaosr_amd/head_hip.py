@@ -103,10 +103,11 @@ class PackedHead:
         return st
 
     @torch.no_grad()
-    def forward(self, feature_chw, x_lr_chw, coord, cell, chunk, feature_hwc=None):
+    def forward(self, feature_chw, x_lr_chw, coord, cell, chunk, feature_hwc=None, options=None):
         """feature [C,H,W] (or channels-last [H,W,C] via feature_hwc), x_lr [3,H,W] or None,
-        coord/cell [Q,2] -> rgb [Q,3] (all on the GPU)."""
+        coord/cell [Q,2] -> rgb [Q,3] (all on the GPU).  `options`: hip_ops.Options (precision + route)."""
         net = self.net
+        opt = hip_ops.as_options(options)
         if feature_hwc is not None:
             feature_hwc = feature_hwc.contiguous().float()
             feature_chw = feature_hwc.permute(2, 0, 1)      # shape bookkeeping only
@@ -127,14 +128,14 @@ class PackedHead:
         nbytes = _lib.load().ciaosr_head_workspace_bytes(H, W, C.byref(st), Q)
         ws = hip_ops.workspace(nbytes, coord.device)
         rgb = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)
-        _lib.call('ciaosr_head_forward_bf16' if hip_ops.precision() == 'bf16' else 'ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W, C.byref(st),
-                  C.byref(cs) if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
-                  hip_ops.ptr(cell), Q, int(chunk or 0), hip_ops.ptr(rgb), hip_ops.ptr(ws), ws.numel(),
+        _lib.call('ciaosr_head_forward_bf16' if opt.bf16 else 'ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W,
+                  C.byref(st), C.byref(cs) if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
+                  hip_ops.ptr(cell), Q, int(chunk or 0), hip_ops.ptr(rgb), opt.c_arg(), hip_ops.ptr(ws), ws.numel(),
                   hip_ops.stream_ptr())
         return rgb
 
     @torch.no_grad()
-    def forward_as_written(self, feature_chw, x_lr_chw, coord, cell, chunk=None):
+    def forward_as_written(self, feature_chw, x_lr_chw, coord, cell, chunk=None, options=None):
         """The reference's op order, stage by stage through the staged C entry points, with NO algebraic
         restructuring (no layer-1 hoist, no logit table, no fusion): K1 gather rows (net:145-196) ->
         imnet_k / imnet_v on every (query, sample) row (net:202-206) -> K4 local attention (net:211-216) ->
@@ -151,7 +152,7 @@ class PackedHead:
         feat_hwc = hip_ops.nchw_to_hwc(feature_chw)
         U = hip_ops.patch_rows(feat_hwc, 3, 1, 1, H, W)
         if net.non_local_attn:
-            nl = hip_ops.nchw_to_hwc(net.cs_attn(feature_chw.unsqueeze(0))[0].contiguous())
+            nl = hip_ops.nchw_to_hwc(net.cs_attn(feature_chw.unsqueeze(0), options=options)[0].contiguous())
             U = torch.cat([U, nl.view(H * W, Cn)], dim=1).contiguous()
         Q = coord.shape[0]
         step = int(chunk) if chunk else Q

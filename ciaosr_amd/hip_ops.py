@@ -23,16 +23,12 @@ def require_gpu(*tensors, allow_row_stride=False):
             raise CiaoSRHipError('expected a contiguous tensor')
 
 
-_dev_index = None
-
-
-def stream_ptr():
-    """hipStream_t of torch's current stream on the current device (explicit index: the implicit
-    lookup costs ~0.2 ms per call on hosts with many cores)."""
-    global _dev_index
-    if _dev_index is None:
-        _dev_index = torch.cuda.current_device()
-    return C.c_void_p(torch.cuda.current_stream(_dev_index).cuda_stream)
+def stream_ptr(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device, looked up per call so that a
+    process driving several GPUs launches on the right one; the index is passed explicitly because the implicit
+    lookup inside current_stream() costs ~0.2 ms per call on hosts with many cores)."""
+    idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+    return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
 
 
 _coord_cache = {}
@@ -57,8 +53,9 @@ def ptr(t):
 
 
 def workspace(nbytes, device, slot='head'):
-    """Grow-only per-device scratch buffer (never freed while the process lives)."""
-    key = (slot, device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (slot, device, stream): two streams or two devices never share scratch."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (slot, device.type, idx, torch.cuda.current_stream(idx).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None
@@ -159,26 +156,64 @@ def tile_finalize(E, Wt):
     return out
 
 
-def set_head_mode(mode):
-    """0 = automatic (fused head kernels when eligible), 1 = force the staged per-layer path."""
-    _lib.call('ciaosr_set_head_mode', int(mode))
+class Options:
+    """Per-call evaluation options, passed explicitly down the call chain (no process-global switches).
+
+    precision  'fp32' (exact-fp32 MFMA, the contract precision) or 'bf16' (bf16 MFMA inputs, fp32 accumulation):
+               selects the _f32 / _bf16 entry point of the C ABI.
+    the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
+    Immutable; `replace()` returns a modified copy."""
+    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows')
+    __slots__ = ('precision',) + _C_FIELDS + ('_c',)
+
+    def __init__(self, precision='fp32', **kw):
+        object.__setattr__(self, 'precision', {'fp32': 'fp32', 'f32': 'fp32', 'bf16': 'bf16'}[precision])
+        for f in self._C_FIELDS:
+            object.__setattr__(self, f, int(kw.pop(f, 0)))
+        if kw:
+            raise TypeError(f'unknown option(s): {sorted(kw)}')
+        st = None
+        if any(getattr(self, f) for f in self._C_FIELDS):
+            st = _lib.OptionsT()
+            for f in self._C_FIELDS:
+                setattr(st, f, getattr(self, f))
+        object.__setattr__(self, '_c', st)
+
+    def __setattr__(self, k, v):
+        raise AttributeError('Options is immutable; use replace()')
+
+    def replace(self, **kw):
+        cur = {f: getattr(self, f) for f in ('precision',) + self._C_FIELDS}
+        cur.update(kw)
+        return Options(**cur)
+
+    @property
+    def bf16(self):
+        return self.precision == 'bf16'
+
+    def c_arg(self):
+        """ctypes argument for `const ciaosr_options_t* opt` (NULL when every field is default)."""
+        return C.byref(self._c) if self._c is not None else None
+
+    def __repr__(self):
+        extra = ''.join(f', {f}={getattr(self, f)}' for f in self._C_FIELDS if getattr(self, f))
+        return f'Options({self.precision!r}{extra})'
 
 
-_precision = 'fp32'
+DEFAULT_OPTIONS = Options()
 
 
-def set_precision(mode):
-    """'fp32' (exact-fp32 MFMA, default) or 'bf16' (bf16 MFMA inputs, fp32 accumulate): selects which C entry
-    point the host classes call (ciaosr_head_forward_f32 / _bf16).  Host-side switch; the library itself keeps
-    no precision state.  Returns the previous mode name."""
-    global _precision
-    prev = _precision
-    _precision = {'fp32': 'fp32', 'f32': 'fp32', 0: 'fp32', 'bf16': 'bf16', 1: 'bf16'}[mode]
-    return prev
-
-
-def precision():
-    return _precision
+def as_options(options):
+    """None -> defaults; 'fp32'/'bf16' -> Options(precision); Options -> itself; dict -> Options(**dict)."""
+    if options is None:
+        return DEFAULT_OPTIONS
+    if isinstance(options, Options):
+        return options
+    if isinstance(options, str):
+        return Options(options)
+    if isinstance(options, dict):
+        return Options(**options)
+    raise TypeError(f'options must be None, str, dict or hip_ops.Options, got {type(options)}')
 
 
 def gather_rows(unfold, C_, Cn, coord, cell, H, W, local_size=2, chunk=0):

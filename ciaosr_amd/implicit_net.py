@@ -57,30 +57,31 @@ class LocalImplicitSRNet(nn.Module):
         self._head = PackedHead(self)
 
     # -- the reference interface ---------------------------------------------------------------
-    def gen_feature(self, x):
+    def gen_feature(self, x, options=None):
         raise NotImplementedError('subclasses define gen_feature')
 
-    def forward(self, x, coord, cell, test_mode=False):
-        """x [B,3,H,W] normalised LR, coord/cell [B,Q,2] (y,x) -> [B,Q,3]   (ciaosr_net.py:88-110)."""
+    def forward(self, x, coord, cell, test_mode=False, options=None):
+        """x [B,3,H,W] normalised LR, coord/cell [B,Q,2] (y,x) -> [B,Q,3]   (ciaosr_net.py:88-110).
+        `options` (extension, absent from the reference): hip_ops.Options / 'bf16' / None = exact-fp32 defaults."""
         chunk = None if (self.eval_bsize is None or not test_mode) else self.eval_bsize
         enc = getattr(self, '_encoder_hip', None)
         if enc is not None and x.is_cuda and enc.supported():
             # HIP trunk: channels-last feature map goes straight into the head (no NCHW round trip)
             x = x.contiguous().float()
-            outs = [self._head.forward(None, x[b], coord[b], cell[b], chunk, feature_hwc=enc.forward_hwc(x[b]))
-                    for b in range(x.shape[0])]
+            outs = [self._head.forward(None, x[b], coord[b], cell[b], chunk, feature_hwc=enc.forward_hwc(x[b], options),
+                                       options=options) for b in range(x.shape[0])]
             return torch.stack(outs, 0)
-        features = self.gen_feature(x)
-        return self._predict(features, coord, cell, chunk, x)
+        features = self.gen_feature(x, options)
+        return self._predict(features, coord, cell, chunk, x, options)
 
-    def query_rgb(self, features, coord, scale=None):
+    def query_rgb(self, features, coord, scale=None, options=None):
         """ciaosr_net.py:113-224 (no bilinear residual); `scale` is the cell tensor."""
-        return self._predict(features, coord, scale, None, None)
+        return self._predict(features, coord, scale, None, None, options)
 
-    def batched_predict(self, x, coord, cell):
+    def batched_predict(self, x, coord, cell, options=None):
         """ciaosr_net.py:226-248: `x` is the feature list; eval_bsize chunking only matters through
         which query's cell defines the shift radius -- the kernels take it as `chunk`."""
-        return self._predict(x, coord, cell, self.eval_bsize, None)
+        return self._predict(x, coord, cell, self.eval_bsize, None, options)
 
     def init_weights(self, pretrained=None, strict=True):
         if isinstance(pretrained, str):
@@ -91,7 +92,7 @@ class LocalImplicitSRNet(nn.Module):
 
     # -- HIP path ------------------------------------------------------------------------------
     @torch.no_grad()
-    def _predict(self, features, coord, cell, chunk, x_lr):
+    def _predict(self, features, coord, cell, chunk, x_lr, options=None):
         if isinstance(features, torch.Tensor):
             features = [features]
         if len(features) != 1:
@@ -100,7 +101,8 @@ class LocalImplicitSRNet(nn.Module):
         hip_ops.require_gpu(feature.contiguous(), coord.contiguous(), cell.contiguous())
         outs = []
         for b in range(feature.shape[0]):
-            outs.append(self._head.forward(feature[b], None if x_lr is None else x_lr[b], coord[b], cell[b], chunk))
+            outs.append(self._head.forward(feature[b], None if x_lr is None else x_lr[b], coord[b], cell[b], chunk,
+                                           options=options))
         return torch.stack(outs, 0)
 
 
@@ -120,11 +122,11 @@ class LocalImplicitSRRDN(LocalImplicitSRNet):
         del self.encoder
         self._encoder_hip = PackedEncoder(self, 'rdn')
 
-    def gen_feature(self, x):
+    def gen_feature(self, x, options=None):
         enc = self._encoder_hip
         if x.is_cuda and enc.supported():
             x = x.contiguous().float()
-            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b])) for b in range(x.shape[0])])]
+            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b], options)) for b in range(x.shape[0])])]
         return [self.gen_feature_torch(x)]
 
     def gen_feature_torch(self, x):
@@ -152,11 +154,11 @@ class LocalImplicitSREDSR(LocalImplicitSRNet):
         del self.encoder
         self._encoder_hip = PackedEncoder(self, 'edsr')
 
-    def gen_feature(self, x):
+    def gen_feature(self, x, options=None):
         enc = self._encoder_hip
         if x.is_cuda and enc.supported():
             x = x.contiguous().float()
-            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b])) for b in range(x.shape[0])])]
+            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b], options)) for b in range(x.shape[0])])]
         return [self.gen_feature_torch(x)]
 
     def gen_feature_torch(self, x):
@@ -187,11 +189,11 @@ class LocalImplicitSRSWINIR(LocalImplicitSRNet):
         from .swinir_hip import PackedSwinIR
         self._encoder_hip = PackedSwinIR(self)
 
-    def gen_feature(self, img):
+    def gen_feature(self, img, options=None):
         enc = self._encoder_hip
         if img.is_cuda and enc.supported():
             img = img.contiguous().float()
-            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(img[b])) for b in range(img.shape[0])])]
+            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(img[b], options)) for b in range(img.shape[0])])]
         return [self.gen_feature_torch(img)]
 
     def gen_feature_torch(self, img):

@@ -84,9 +84,10 @@ class CrossScaleAttention(nn.Module):
         return self._packed[1]
 
     @torch.no_grad()
-    def forward(self, input):
+    def forward(self, input, options=None):
         """[B,C,H,W] -> [B,C,H,W] like the reference module (batch items are independent,
-        arch_csnln.py:491)."""
+        arch_csnln.py:491).  `options`: hip_ops.Options (precision, csa_composed_min); None = fp32 defaults."""
+        opt = hip_ops.as_options(options)
         x = input.contiguous().float()
         hip_ops.require_gpu(x)
         B, Cc, H, W = x.shape
@@ -97,7 +98,7 @@ class CrossScaleAttention(nn.Module):
         for b in range(B):
             f = hip_ops.nchw_to_hwc(x[b])
             o = torch.empty(H, W, Cc, dtype=torch.float32, device=x.device)
-            _lib.call('ciaosr_cs_attn_bf16' if hip_ops.precision() == 'bf16' else 'ciaosr_cs_attn_f32', hip_ops.ptr(f), Cc, H, W, C.byref(st), hip_ops.ptr(o), Cc,
-                      hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
+            _lib.call('ciaosr_cs_attn_bf16' if opt.bf16 else 'ciaosr_cs_attn_f32', hip_ops.ptr(f), Cc, H, W, C.byref(st),
+                      hip_ops.ptr(o), Cc, opt.c_arg(), hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
             out[b] = hip_ops.hwc_to_nchw(o)
         return out

@@ -100,7 +100,7 @@ class CiaoSR(BasicRestorer):
         return torch.stack([hip_ops.normalize(lq[b], self.rgb_mean, self.rgb_std) for b in range(lq.shape[0])])
 
     @torch.no_grad()
-    def run_tile(self, x_norm, hi, wi, tile, sf):
+    def run_tile(self, x_norm, hi, wi, tile, sf, options=None):
         """One tile of clip_test (ciaosr.py:235-245): [B, th*tw, 3] prediction of the LR crop."""
         patch = x_norm[..., hi:hi + tile, wi:wi + tile].contiguous()
         b = patch.shape[0]
@@ -108,10 +108,10 @@ class CiaoSR(BasicRestorer):
         coord, cell = hip_ops.make_coord_cell(th, tw, patch.device)       # generated on the GPU, cached per shape
         coord = coord.unsqueeze(0).expand(b, -1, 2)
         cell = cell.unsqueeze(0).expand(b, -1, 2)
-        return self.generator(patch, coord, cell, test_mode=True), (th, tw)
+        return self.generator(patch, coord, cell, test_mode=True, options=self.options(options)), (th, tw)
 
     @torch.no_grad()
-    def clip_test(self, img_lq, model=None, tile_fn=None):
+    def clip_test(self, img_lq, model=None, tile_fn=None, options=None):
         """Tiled inference of one large image (ciaosr.py:218-258).  Returns [B, h*sf*w*sf, 3]."""
         sf = self.test_cfg.get('scale', None)
         b, c, h, w = img_lq.shape
@@ -119,28 +119,35 @@ class CiaoSR(BasicRestorer):
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
         for (hi, wi) in origins:
-            out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf) if tile_fn is None else tile_fn(hi, wi)
+            out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf, options) if tile_fn is None else tile_fn(hi, wi)
             for bi in range(b):
                 hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), hi * sf, wi * sf, th, tw)
         return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
 
     @torch.no_grad()
-    def restore(self, lq, coord=None, cell=None):
-        """forward_test body from normalised LR on device to de-normalised, clamped output
-        [B,3,round(h*s),round(w*s)] on device (ciaosr.py:142-169) -- the timed region of bench.py.
-        `test_cfg.precision = 'bf16'` (an extension, absent from the reference) runs the fused head with bf16
-        MFMA inputs; the default is the exact-fp32 path."""
-        prec = self.test_cfg.get('precision', None) if self.test_cfg is not None else None
-        if prec is not None:
-            prev = hip_ops.set_precision(prec)
-            try:
-                return self._restore(lq, coord, cell)
-            finally:
-                hip_ops.set_precision(prev)
-        return self._restore(lq, coord, cell)
+    def options(self, options=None):
+        """The hip_ops.Options a call runs with: the explicit argument if given, else `test_cfg.precision`
+        ('fp32' default | 'bf16'; an extension absent from the reference) + `test_cfg.hip_options` (dict of
+        ciaosr_options_t fields).  Nothing process-global: two restorers in one process can differ."""
+        if options is not None:
+            return hip_ops.as_options(options)
+        cfg = self.test_cfg or {}
+        extra = dict(cfg.get('hip_options', None) or {})
+        prec = cfg.get('precision', None)
+        if prec is None and not extra:
+            return hip_ops.DEFAULT_OPTIONS
+        return hip_ops.Options(prec or 'fp32', **extra)
 
     @torch.no_grad()
-    def clip_test_any_scale(self, img_lq, ht, wt):
+    def restore(self, lq, coord=None, cell=None, options=None):
+        """forward_test body from normalised LR on device to de-normalised, clamped output
+        [B,3,round(h*s),round(w*s)] on device (ciaosr.py:142-169) -- the timed region of bench.py.
+        `options` / `test_cfg.precision = 'bf16'` (an extension, absent from the reference) runs the dense layers
+        with bf16 MFMA inputs; the default is the exact-fp32 path."""
+        return self._restore(lq, coord, cell, self.options(options))
+
+    @torch.no_grad()
+    def clip_test_any_scale(self, img_lq, ht, wt, options=None):
         """Opt-in tiled inference for non-integer / > 4 scales (tile_plan.py): the reference's LR tiling and
         uniform blending, HR rectangles by pixel-centre membership, tile-local coordinates and cells.
         Returns [B, ht*wt, 3]."""
@@ -153,23 +160,23 @@ class CiaoSR(BasicRestorer):
             patch = img_lq[..., t['y0']:t['y0'] + t['th'], t['x0']:t['x0'] + t['tw']].contiguous()
             coord = t['coord'].to(img_lq.device).unsqueeze(0).expand(b, -1, 2)
             cell = t['cell'].to(img_lq.device).unsqueeze(0).expand(b, -1, 2)
-            out = self.generator(patch, coord, cell, test_mode=True)
+            out = self.generator(patch, coord, cell, test_mode=True, options=self.options(options))
             for bi in range(b):
                 hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), t['i0'], t['j0'], t['i1'] - t['i0'], t['j1'] - t['j0'])
         return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
 
-    def _restore(self, lq, coord=None, cell=None):
+    def _restore(self, lq, coord=None, cell=None, options=None):
         x = self.normalize(lq)
         if self.test_cfg.get('tile', None) and self.test_cfg.get('tile_any_scale', False) and coord is not None:
             ih, iw = lq.shape[-2:]
             s = math.sqrt(coord.shape[1] / (ih * iw))                 # the reference's own size rule (ciaosr.py:166-169)
-            pred = self.clip_test_any_scale(x, round(ih * s), round(iw * s))
+            pred = self.clip_test_any_scale(x, round(ih * s), round(iw * s), options)
             n_q = pred.shape[1]
         elif self.test_cfg.get('tile', None):
-            pred = self.clip_test(x, self.generator)
+            pred = self.clip_test(x, self.generator, options=options)
             n_q = pred.shape[1]
         else:
-            pred = self.generator(x, coord, cell, test_mode=True)
+            pred = self.generator(x, coord, cell, test_mode=True, options=options)
             n_q = coord.shape[1]
         ih, iw = lq.shape[-2:]
         s = math.sqrt(n_q / (ih * iw))
@@ -177,7 +184,7 @@ class CiaoSR(BasicRestorer):
         return torch.stack([hip_ops.denorm_clamp(pred[b].contiguous(), H, W, self.rgb_mean, self.rgb_std)
                             for b in range(lq.shape[0])])
 
-    def graphed_restore(self, lq, coord=None, cell=None, warmup=2):
+    def graphed_restore(self, lq, coord=None, cell=None, warmup=2, options=None):
         """Capture `restore(lq)` (a few hundred short launches for a 48x48 tile) into one hipGraph and return a
         callable `run(new_lq=None) -> output` that replays it; input and output live in static buffers.  All
         kernels are launched on torch's current stream, workspaces are allocated during the warm-up calls, and
@@ -188,12 +195,21 @@ class CiaoSR(BasicRestorer):
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             for _ in range(max(warmup, 1)):
-                self.restore(static_lq, coord, cell)
+                self.restore(static_lq, coord, cell, options)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            static_out = self.restore(static_lq, coord, cell)
+            static_out = self.restore(static_lq, coord, cell, options)
+
+        # the graph holds raw pointers into the scratch buffers, the coordinate tensors and the packed weights that were
+        # live during capture: keep exactly those objects alive with the graph (a later, larger eager call re-allocates
+        # hip_ops' workspaces and a 17th coordinate shape clears its cache -- neither may free what the graph reads).
+        # Weights must not change after capture (a repack would be invisible to the captured launches).
+        keep = (dict(hip_ops._workspaces), dict(hip_ops._coord_cache),
+                [getattr(m, '_packed', None) for m in self.modules()],
+                [(getattr(o, '_st', None), getattr(o, '_keep', None), getattr(o, '_mask_keep', None))
+                 for m in self.modules() for o in (getattr(m, '_head', None), getattr(m, '_encoder_hip', None)) if o is not None])
 
         def run(new_lq=None):
             if new_lq is not None:
@@ -201,6 +217,7 @@ class CiaoSR(BasicRestorer):
             graph.replay()
             return static_out
         run.graph = graph
+        run.keep = keep
         return run
 
     def forward_test(self, lq, gt, coord=None, cell=None, meta=None, save_image=False, save_path=None,

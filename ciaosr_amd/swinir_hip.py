@@ -118,7 +118,7 @@ class PackedSwinIR:
         return self._masks[k]
 
     @torch.no_grad()
-    def forward_hwc(self, x_chw):
+    def forward_hwc(self, x_chw, options=None):
         """x [3,H,W] normalised LR (GPU) -> feature [H,W,C] channels-last."""
         x_chw = x_chw.contiguous().float()
         hip_ops.require_gpu(x_chw)

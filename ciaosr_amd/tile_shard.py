@@ -2,11 +2,15 @@
 
 Units = the LR tiles of `CiaoSR.clip_test` (ciaosr.py:233-254): every tile runs encoder + cs_attn +
 head on its own crop with no cross-tile data, so the tile list is partitioned over ranks
-(row-major tile index t -> rank t % R) with no collective on the data path.  The single exchange
-step is the gather of output tiles to rank 0 over RCCL (torch.distributed backend 'nccl' on ROCm;
-'gloo' in the CPU tests), after which rank 0 blends in the reference order (h outer, w inner) so the
-result is bitwise equal to the 1-GPU run.  xGMI is point-to-point: every peer sends its own tiles
-straight to rank 0 over its direct link (all_gather of equal-sized, padded slabs), no ring needed.
+(row-major tile index t -> rank t % R) with no collective on the data path.  The one exchange is
+the delivery of output tiles to rank 0 (RCCL point-to-point over xGMI; torch.distributed backend
+'nccl' on ROCm, 'gloo' in the CPU tests): a peer `isend`s each tile the moment its kernels are
+queued -- the copy runs on RCCL's own stream over that peer's direct xGMI link to rank 0 while the
+peer's next tile computes -- and rank 0 blends the tiles of round k-1 (tiles (k-1)R+1 .. kR-1, which
+have had a whole tile time to arrive) after launching its own tile kR, always in the reference order
+(h outer, w inner), so the result is bitwise equal to the 1-GPU run.  Nothing is all-gathered: a peer
+holds only its own not-yet-delivered tiles, rank 0 a ring of two rounds of receive buffers
+(2 tiles per peer), and exchange + blend hide under compute except for the last round.
 """
 import torch
 import torch.distributed as dist
@@ -18,6 +22,37 @@ def partition(n_tiles, world):
     """tile index -> owning rank, and per-rank tile lists (round-robin keeps neighbours apart so
     each rank's share of the expensive border tiles is even)."""
     return [[t for t in range(n_tiles) if t % world == r] for r in range(world)]
+
+
+class _Mover:
+    """isend / irecv of one tile, hiding the single-GPU rehearsal case (gloo backend with CUDA tensors: staged through
+    the host).  Keeps the tensors alive until their transfer has completed."""
+
+    def __init__(self, group, device):
+        self.group = group
+        self.via_host = device is not None and torch.device(device).type == 'cuda' and dist.get_backend(group) == 'gloo'
+        self.pending = []          # (work, tensors kept alive)
+
+    def send(self, t, dst):
+        buf = t.cpu() if self.via_host else t.contiguous()
+        self.pending.append((dist.isend(buf, dst=dst, group=self.group), buf))
+        # drop what has been delivered: a peer never holds more than its in-flight tiles
+        while self.pending and self.pending[0][0].is_completed():
+            self.pending.pop(0)
+
+    def recv(self, like_shape, src, device):
+        buf = torch.empty(like_shape, dtype=torch.float32, device='cpu' if self.via_host else device)
+        return dist.irecv(buf, src=src, group=self.group), buf
+
+    def take(self, handle, device):
+        work, buf = handle
+        work.wait()                # NCCL: the current stream waits for the copy (no host block); gloo: host waits
+        return buf.to(device) if self.via_host else buf
+
+    def drain(self):
+        for work, _ in self.pending:
+            work.wait()
+        self.pending = []
 
 
 def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_fn, rank, world, group=None,
@@ -32,44 +67,63 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
     b, c, h, w = img_shape
     tile, origins = tile_grid(h, w, tile, overlap)
     th = tw = round(tile * sf)
-    mine = partition(len(origins), world)[rank]
-    n_max = (len(origins) + world - 1) // world
-    slab = torch.zeros(n_max, b, th * tw, 3, dtype=torch.float32, device=device)
-    for slot, t in enumerate(mine):
-        hi, wi = origins[t]
-        slab[slot] = tile_fn(hi, wi, tile)
-    if world > 1:
-        if slab.is_cuda and dist.get_backend(group) == 'gloo':
-            # debugging / single-GPU rehearsal of the N-rank path: gloo gathers host copies
-            host = slab.cpu()
-            hparts = [torch.empty_like(host) for _ in range(world)]
-            dist.all_gather(hparts, host, group=group)
-            parts = [h.to(slab.device) for h in hparts]
-        else:
-            parts = [torch.empty_like(slab) for _ in range(world)]
-            dist.all_gather(parts, slab, group=group)      # the one exchange step (RCCL over xGMI)
+    n = len(origins)
+    shape = (b, th * tw, 3)
+    mover = _Mover(group, device) if world > 1 else None
+
+    if rank != 0:
+        # peer: compute tile t = rank, rank + R, ... and hand each to RCCL as soon as it is queued
+        for t in range(rank, n, world):
+            hi, wi = origins[t]
+            mover.send(tile_fn(hi, wi, tile), 0)
+        mover.drain()
+        result = None
     else:
-        parts = [slab]
-    if rank != 0 and not gather_to_all:
-        return None
-    E = torch.zeros(b, c, round(h * sf), round(w * sf), dtype=torch.float32, device=device)
-    Wt = torch.zeros_like(E)
-    for t, (hi, wi) in enumerate(origins):                 # reference blend order (ciaosr.py:233-234)
-        out = parts[t % world][t // world]
-        blend_fn(E, Wt, out, round(hi * sf), round(wi * sf), th, tw)
-    return finalize_fn(E, Wt)
+        E = torch.zeros(b, c, round(h * sf), round(w * sf), dtype=torch.float32, device=device)
+        Wt = torch.zeros_like(E)
+
+        def blend(t, out):
+            hi, wi = origins[t]
+            blend_fn(E, Wt, out, round(hi * sf), round(wi * sf), th, tw)
+
+        prev = []                  # receive handles of the previous round's peer tiles, in tile order
+        for t0 in range(0, n, world):
+            # receives of THIS round are posted before the own tile is launched, consumed one round later
+            cur = [(t, mover.recv(shape, t % world, device)) for t in range(t0 + 1, min(t0 + world, n))]
+            hi, wi = origins[t0]
+            own = tile_fn(hi, wi, tile)
+            for t, handle in prev:                         # tiles (t0 - R + 1 .. t0 - 1) precede t0 in the reference order
+                blend(t, mover.take(handle, device))
+            blend(t0, own)
+            prev = cur
+        for t, handle in prev:
+            blend(t, mover.take(handle, device))
+        result = finalize_fn(E, Wt)
+    if gather_to_all and world > 1:
+        meta = [tuple(result.shape)] if rank == 0 else [None]
+        dist.broadcast_object_list(meta, src=0, group=group)
+        if rank != 0:
+            result = torch.empty(meta[0], dtype=torch.float32, device=device)
+        if mover.via_host:
+            hostbuf = result.cpu()
+            dist.broadcast(hostbuf, src=0, group=group)
+            result = hostbuf.to(device)
+        else:
+            dist.broadcast(result, src=0, group=group)
+    return result
 
 
-def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False):
+def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False, options=None):
     """Tile-sharded counterpart of CiaoSR.clip_test on the GPUs of one node."""
     from . import hip_ops
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
     cfg = restorer.test_cfg
     sf = cfg.get('scale')
+    opt = restorer.options(options)
 
     def tile_fn(hi, wi, tile):
-        out, _ = restorer.run_tile(x_norm, hi, wi, tile, sf)
+        out, _ = restorer.run_tile(x_norm, hi, wi, tile, sf, opt)
         return out
 
     def blend_fn(E, Wt, out, y0, x0, th, tw):
@@ -126,36 +180,47 @@ def query_sharded_predict(feature_fn, predict_fn, coord, cell, rank, world, chun
         dist.broadcast(buf, src=0, group=group)                                # encoder features -> every rank
         feature = buf.to(coord.device) if via_host else buf
     q0, q1 = slices[rank]
-    n_max = max(s[1] - s[0] for s in slices)
-    slab = torch.zeros(b, n_max, 3, dtype=torch.float32, device=coord.device)
+    slab = torch.zeros(b, max(q1 - q0, 1), 3, dtype=torch.float32, device=coord.device)
     if q1 > q0:
         slab[:, :q1 - q0] = predict_fn(feature, coord[:, q0:q1].contiguous(), cell[:, q0:q1].contiguous())
-    if world > 1:
-        if slab.is_cuda and dist.get_backend(group) == 'gloo':
-            host = slab.cpu()
-            hparts = [torch.empty_like(host) for _ in range(world)]
-            dist.all_gather(hparts, host, group=group)
-            parts = [h.to(slab.device) for h in hparts]
-        else:
-            parts = [torch.empty_like(slab) for _ in range(world)]
-            dist.all_gather(parts, slab, group=group)
+    if world == 1:
+        return slab[:, :q1 - q0]
+    # RGB slices -> rank 0, point to point (each peer over its own xGMI link); only rank 0 allocates the full output
+    mover = _Mover(group, coord.device)
+    if rank != 0:
+        if q1 > q0:
+            mover.send(slab[:, :q1 - q0].contiguous(), 0)
+        mover.drain()
+        out = None
     else:
-        parts = [slab]
-    if rank != 0 and not gather_to_all:
-        return None
-    return torch.cat([parts[r][:, :s[1] - s[0]] for r, s in enumerate(slices)], dim=1)
+        handles = [(r, mover.recv((b, s[1] - s[0], 3), r, coord.device)) for r, s in enumerate(slices) if r > 0 and s[1] > s[0]]
+        out = torch.empty(b, n_query, 3, dtype=torch.float32, device=coord.device)
+        out[:, q0:q1] = slab[:, :q1 - q0]
+        for r, handle in handles:
+            out[:, slices[r][0]:slices[r][1]] = mover.take(handle, coord.device)
+    if gather_to_all:
+        if rank != 0:
+            out = torch.empty(b, n_query, 3, dtype=torch.float32, device=coord.device)
+        if mover.via_host:
+            hostbuf = out.cpu()
+            dist.broadcast(hostbuf, src=0, group=group)
+            out = hostbuf.to(coord.device)
+        else:
+            dist.broadcast(out, src=0, group=group)
+    return out
 
 
-def predict_query_sharded(restorer, x_norm, coord, cell, rank=None, world=None, group=None, gather_to_all=False):
+def predict_query_sharded(restorer, x_norm, coord, cell, rank=None, world=None, group=None, gather_to_all=False, options=None):
     """Whole-image (single tile) counterpart of CiaoSR generator(x, coord, cell, test_mode=True) over the GPUs of a node."""
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
     gen = restorer.generator
+    opt = restorer.options(options)
 
     def feature_fn():
-        return gen.gen_feature(x_norm)[0]
+        return gen.gen_feature(x_norm, opt)[0]
 
     def predict_fn(feature, c, cl):
-        return gen._predict([feature], c, cl, gen.eval_bsize, x_norm)
+        return gen._predict([feature], c, cl, gen.eval_bsize, x_norm, opt)
 
     return query_sharded_predict(feature_fn, predict_fn, coord, cell, rank, world, gen.eval_bsize, group, gather_to_all)

@@ -44,6 +44,8 @@ extern "C" {
 /* ---- library ---------------------------------------------------------------------------- */
 int ciaosr_version(void);
 const char* ciaosr_error_string(int code);
+/* sizeof() of an ABI struct by its typedef name ("ciaosr_mlp_t", ...), 0 if unknown: layout check for bindings */
+size_t ciaosr_sizeof(const char* type_name /*host*/);
 
 /* Opt-in per-kernel HIP-event timing used by bench.py's roofline leg. */
 int ciaosr_prof_enable(int on);
@@ -52,6 +54,27 @@ int ciaosr_prof_reset(void);
 int ciaosr_prof_collect(void); /* synchronises the recorded events and accumulates totals */
 int ciaosr_prof_get(const char* kernel, double* total_ms /*host*/, long* launches /*host*/);
 int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel names seen */
+
+/* ---- per-call options --------------------------------------------------------------------
+ * The library keeps NO mutable state besides the opt-in profiler above: precision is selected by the entry point's
+ * _f32 / _bf16 suffix, and every route choice is an argument.  `opt` may be NULL (all defaults); a zero field means
+ * "default".  The struct only selects between result-equivalent evaluation routes (tests force each of them). */
+#define CIAOSR_HEAD_STAGED 1          /* head_route bit 0: per-layer GEMM path instead of the fused kernels */
+#define CIAOSR_HEAD_NO_LOGIT_TABLE 2  /* head_route bit 1: fused path, imnet_k output layer on the MFMA per (query, sample)
+                                       * row instead of the exact 9-rows-per-LR-pixel fold */
+#define CIAOSR_HEAD_SPLIT_DECODE 4    /* head_route bit 2: fused path with Z materialised and a separate decode launch */
+typedef struct ciaosr_options {
+    int head_route;         /* CIAOSR_HEAD_* bits; 0 = automatic */
+    int csa_composed_min;   /* cs_attn: LR pixels (after padding) from which the composed fold+down tail applies;
+                             * 0 = default (4096), < 0 = never */
+    int dense_min_tiles;    /* RDN trunk: 12x12-pixel tiles from which the halo-resident dense-layer kernels apply;
+                             * 0 = default (128), < 0 = never */
+    int scatter_small_max;  /* RDN trunk: largest map (pixels) for the small-map dense-block kernels; 0 = default (18432),
+                             * < 0 = never */
+    int kv_rows;            /* fp32 fused head: (query, sample) rows per workgroup, 32 (default) or 64 */
+    int decode_rows;        /* fp32 fused decode: queries per workgroup, 32 (default) or 64 */
+    int reserved[2];        /* must be 0 */
+} ciaosr_options_t;
 
 /* ---- layout plumbing -------------------------------------------------------------------- */
 /* [C][H][W] -> [H][W][ld_dst] (first C columns).  Encoder output (net:100) enters here. */
@@ -102,12 +125,14 @@ size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C);
 /* feat_hwc [H][W][ld_feat] -> out [H][W] rows of C floats with leading dimension ld_out
  * (lets the caller write straight into the tail columns of the unfold rows, net:137). */
 int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
-                       float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream);
+                       float* out, int ld_out, const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
+                       size_t workspace_bytes, void* stream);
 /* Same, with the two big contractions (correlation scores csa:497-500 and the attention-weighted patch sum csa:511)
  * on the bf16 MFMA when the composed tail applies (>= 4096 LR pixels, w_down_masked given): inputs rounded to bf16,
  * fp32 accumulation, logits and softmax in fp32, probabilities rounded to bf16.  Smaller maps: identical to _f32. */
 int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
-                        float* out, int ld_out, void* workspace, size_t workspace_bytes, void* stream);
+                        float* out, int ld_out, const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 /* ---- head ---------------------------------------------------------------------------------- */
 typedef struct ciaosr_mlp {
@@ -134,10 +159,6 @@ int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, float* out, 
  * W[32nt+i][16ks+8g .. 16ks+8g+7] rounded to nearest-even bf16; zero padded. */
 size_t ciaosr_fragment_bf16_bytes(int N, int K);
 int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream);
-
-/* bit 0: force the staged per-layer path; bit 1: fused path without the logit table (imnet_k's output layer
- * runs on the MFMA for every (query, sample) row instead of the exact 9-rows-per-LR-pixel fold); 0 = automatic */
-int ciaosr_set_head_mode(int mode);
 
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
@@ -205,7 +226,8 @@ size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w,
 int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                             const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                             const float* coord, const float* cell, int Q, int chunk, float* rgb,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* Same path with bf16 MFMA inputs (fp32 accumulation) in the fused kernels' dense layers; coordinates, index
  * math, the layer-0 tables, logits, softmax and the decode output stay fp32.  Needs the bf16 fragments
@@ -213,7 +235,8 @@ int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, const ciaosr_he
 int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                              const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                              const float* coord, const float* cell, int Q, int chunk, float* rgb,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ---- encoder trunks: gen_feature (net:321-342 RDN, net:393-408 EDSR) -------------------------- */
 typedef struct ciaosr_conv {
@@ -255,12 +278,14 @@ typedef struct ciaosr_edsr_weights {
 size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weights_t* w);
 /* x_nchw [3][H][W] normalised LR image -> feat_hwc [H][W][mid_channels] */
 int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
-                           void* workspace, size_t workspace_bytes, void* stream);
+                           const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
+                           void* stream);
 /* Same trunk with the dense layers (RDB.layers[l].conv) on the bf16 MFMA, fp32 accumulation, when the map has at
  * least 128 tiles of 12x12 pixels (else identical to the f32 entry); first/last convolutions, LFF/GFF and all
  * residual sums stay fp32.  Needs ciaosr_conv_t.frag16 on every dense layer.  Parity is PSNR-based. */
 int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
+                            void* stream);
 size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w);
 int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w, float* feat_hwc,
                             void* workspace, size_t workspace_bytes, void* stream);

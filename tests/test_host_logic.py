@@ -38,6 +38,72 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert _lib.load().ciaosr_error_string(-4).decode().startswith('workspace')
 
 
+def _c_class(decl):
+    """Coarse class of a C parameter / return declaration: 'ptr', 'int', 'float', 'size_t', 'double*' ..."""
+    decl = decl.strip()
+    if '*' in decl:
+        return 'ptr'
+    base = decl.split()[:-1] if len(decl.split()) > 1 else decl.split()
+    base = ' '.join(t for t in base if t != 'const')
+    return {'int': 'int', 'float': 'float', 'size_t': 'size_t', 'void': 'void'}[base]
+
+
+def _ctypes_class(t):
+    if t is None:
+        return 'void'
+    if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, 'contents'):
+        return 'ptr'
+    return {ctypes.c_int: 'int', ctypes.c_float: 'float', ctypes.c_size_t: 'size_t'}[t]
+
+
+def test_ctypes_signatures_and_struct_layouts_match_the_header():
+    """Prototype by prototype: return class, arity and per-argument class (pointer / int / float / size_t) of the
+    ctypes table equal the header's; struct by struct: field count, per-field class and array length equal the
+    header's typedef, and sizeof equals what the built library reports (ciaosr_sizeof)."""
+    from ciaosr_amd import _lib
+    header = open(os.path.join(REPO, 'include', 'ciaosr_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    protos = re.findall(r'^\s*((?:const\s+)?[a-z_]+\s*\*?)\s*(ciaosr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;', header, flags=re.M)
+    assert len(protos) == len(_lib.SIGNATURES), (len(protos), len(_lib.SIGNATURES))
+    for ret, name, args in protos:
+        res, argtypes = _lib.SIGNATURES[name]
+        params = [] if args.strip() in ('', 'void') else [a for a in args.split(',')]
+        assert _c_class(ret + ' x') == _ctypes_class(res), name
+        assert len(params) == len(argtypes), (name, len(params), len(argtypes))
+        for i, (a, t) in enumerate(zip(params, argtypes)):
+            assert _c_class(a) == _ctypes_class(t), (name, i, a.strip(), t)
+    lib = _lib.load()
+    structs = re.findall(r'typedef struct \w+ \{(.*?)\}\s*(ciaosr_\w+_t);', header, flags=re.S)
+    assert {n for _, n in structs} == set(_lib.STRUCTS)
+    for body, name in structs:
+        st = _lib.STRUCTS[name]
+        assert lib.ciaosr_sizeof(name.encode()) == ctypes.sizeof(st), name
+        fields = []
+        for stmt in [x.strip() for x in body.split(';') if x.strip()]:
+            m = re.match(r'(.*?)([\w\s,\*\[\]]+)$', stmt, flags=re.S)
+            first, *more = stmt.split(',')
+            toks = first.rsplit(None, 1)
+            base = toks[0]
+            for d in [toks[1]] + [x.strip() for x in more]:
+                arr = re.search(r'\[(\w+)\]', d)
+                n = None if not arr else (8 if arr.group(1) == 'CIAOSR_MAX_LAYERS' else int(arr.group(1)))
+                nm = re.sub(r'\[.*', '', d).replace('*', '').strip()
+                is_ptr = '*' in base or '*' in d
+                kind = 'ptr' if is_ptr else ('struct' if base.split()[-1].startswith('ciaosr_') else
+                                             {'int': 'int', 'float': 'float'}[base.replace('const', '').strip()])
+                fields.append((nm, kind, n))
+        mine = []
+        for fname, ftype in st._fields_:
+            n = None
+            if hasattr(ftype, '_length_'):
+                n, ftype = ftype._length_, ftype._type_
+            kind = ('struct' if issubclass(ftype, ctypes.Structure) else
+                    'ptr' if (ftype in (ctypes.c_void_p,) or hasattr(ftype, 'contents')) else
+                    {ctypes.c_int: 'int', ctypes.c_float: 'float'}[ftype])
+            mine.append((kind, n))
+        assert [(k, n) for _, k, n in fields] == mine, (name, fields, mine)
+
+
 def test_product_path_rejects_cpu_tensors():
     """No CPU fallback: calling the generator on CPU tensors raises instead of computing."""
     from ciaosr_amd._lib import CiaoSRHipError

@@ -130,3 +130,32 @@ def test_query_sharded_two_rank_gloo_equals_single_process():
     assert (ret['out'] - single).abs().max() < 1e-5
     fx = load_golden('tiny_head_s2p7')
     assert (single - torch.from_numpy(fx['out'])).abs().max() < 2e-5
+
+
+def _collect_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tools.test import collect_results
+    n = 7
+    mine = [dict(eval_result=dict(PSNR=float(10 + i), SSIM=0.1 * i)) for i in range(n) if i % world == rank]
+    out = collect_results(mine, n, rank, world)
+    if rank == 0:
+        ret['out'] = out
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_image_sharded_eval_results_are_collected_in_dataset_order():
+    """tools/test.py with --launcher pytorch on a whole-image config shards the images over the ranks; the Eval-PSNR /
+    Eval-SSIM it prints must equal the single-process numbers (every image, dataset order)."""
+    from ciaosr_amd.dataset import SRFolderDataset
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_collect_worker, args=(2, 29595, ret), nprocs=2, join=True)
+    single = [dict(eval_result=dict(PSNR=float(10 + i), SSIM=0.1 * i)) for i in range(7)]
+    assert ret['out'] == single
+    assert SRFolderDataset.evaluate(ret['out']) == SRFolderDataset.evaluate(single)

@@ -19,7 +19,7 @@ lq = lq.to(dev)
 ht = wt = 158
 coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
 model.test_cfg['tile'] = None
-hip_ops.set_precision(prec)
+model.test_cfg['precision'] = prec
 for _ in range(3):
     out = model.restore(lq, coord, cell)
 torch.cuda.synchronize()

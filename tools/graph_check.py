@@ -8,7 +8,7 @@ model=rdn_ciaosr(dict(scale=4,tile=192,tile_overlap=32)); seeded_init_(model,0);
 lq,_=synthetic_pair(48,48,4); lq=lq.to(dev)
 ref=model.restore(lq).clone()
 for mode in ("fp32","bf16"):
-    hip_ops.set_precision(mode)
+    model.test_cfg["precision"]=mode
     eager=model.restore(lq).clone()
     run=model.graphed_restore(lq)
     out=run()
@@ -22,4 +22,3 @@ for mode in ("fp32","bf16"):
         torch.cuda.synchronize(); t=time.perf_counter()
         for _ in range(30): fn()
         torch.cuda.synchronize(); print(mode, name, round((time.perf_counter()-t)/30*1e3,3), "ms")
-hip_ops.set_precision("fp32")

@@ -185,9 +185,58 @@ def gen_head_c180(ref):
          target=np.array([ht, wt]))
 
 
-def _restorer(ref, gen_cfg_fn, test_cfg):
-    """Build the reference restorer around an already-built generator class config."""
-    raise NotImplementedError
+def gen_csattn_big(ref):
+    """Maps of >= 4096 LR pixels: the size class of every C3/C4 tile (192x192), where the build takes its
+    composed fold+down route.  64x64 is the smallest such map; 67x70 adds reflect-pad (both axes odd -> 68x70),
+    crop, and the row-0 / column-0 edge variants on a non-square map (arch_csnln.py:444-449,462-469,505-526)."""
+    for tag, (h, w) in (('64x64', (64, 64)), ('67x70', (67, 70))):
+        att = ref.CrossScaleAttention(channel=64, scale=[2]).eval()
+        sha = seeded_init_(att, seed=3, gain=1.5)
+        x = randn((1, 64, h, w), 33)
+        with torch.no_grad():
+            y = att(x)
+        print(f'  csattn_{tag}: out std {y.std():.4f}')
+        save(f'csattn_c64_{tag}', out=y[0], sha=np.array(sha), in_seed=np.array(33), weight_seed=np.array(3),
+             gain=np.array(1.5), shape=np.array([h, w]))
+
+
+def tile192_subset(out):
+    """The stored part of a [1,3,768,768] output: every 4th pixel + an 8-pixel frame (tile borders are where
+    the clamp, the zero-padded unfold and the cs_attn edge variants act)."""
+    return dict(out_s4=out[..., ::4, ::4], out_top=out[..., :8, :], out_bot=out[..., -8:, :],
+                out_left=out[..., :, :8], out_right=out[..., :, -8:])
+
+
+def gen_e2e_tile192(ref):
+    """One full C3 tile: 192x192 LR through the reference CiaoSR.forward_test (tile=192 -> clip_test with exactly
+    one tile, ciaosr.py:224-254; 20 eval_bsize chunks each recomputing cs_attn, ciaosr_net.py:241-246 -> :135).
+    ~7 min of CPU.  Encoder gain 1.5: the network term is O(0.2) next to the bilinear residual and only a few per cent
+    of the pixels saturate at the clamp (gain 1.6 saturates 45 % of a 192x192 tile and would hide errors there).  Stores a subset of the 768x768 output, its PSNR/max over the FULL output and the
+    reference's PSNR against the synthetic GT (metrics.py:211-226 formula via ciaosr_amd.metrics)."""
+    from ciaosr_amd.metrics import psnr_tensors
+    mean = (0.4488, 0.4371, 0.4040)
+    q, k, v = mlp_cfg((256,) * 4)
+    gen = dict(type=ref.LocalImplicitSRRDN,
+               encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
+                            upscale_factor=4, num_layers=8, channel_growth=64),
+               imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+    test_cfg = ref.ConfigDict(scale=4, tile=192, tile_overlap=32)
+    model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
+                       rgb_mean=mean, rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
+    sha = seeded_init_(model, seed=0, gain=1.5, head_gain=SQRT6)
+    lq, gt = synthetic_pair(192, 192, 4)
+    coord, cell, (ht, wt) = coords_for(192, 192, 4)
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        res = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+    out = res['output']
+    psnr_ref = psnr_tensors(out, gt, crop_border=4)
+    print(f'  e2e_rdn_x4_tile192: {time.time() - t0:.0f} s, out range [{out.min():.3f},{out.max():.3f}] std '
+          f'{out.std():.3f} frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f} PSNR(ref,GT) {psnr_ref:.4f}')
+    save('e2e_rdn_x4_tile192', sha=np.array(sha), weight_seed=np.array(0), gain=np.array(1.5), scale=np.array(4),
+         psnr_ref_gt=np.array(psnr_ref, dtype=np.float64), out_mean=np.array(out.double().mean().item()),
+         out_sq=np.array((out.double() ** 2).mean().item()), **tile192_subset(out))
 
 
 def gen_e2e(ref):
@@ -281,7 +330,7 @@ def gen_swinir(ref):
 
 ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
-           head_c180=gen_head_c180, e2e=gen_e2e, tiling=gen_tiling, swinir=gen_swinir)
+           head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

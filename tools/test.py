@@ -35,6 +35,18 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+def collect_results(mine, n_items, rank, world, group=None):
+    """Per-rank result lists of an `i % world == rank` image shard -> the full list in dataset order on rank 0
+    (None elsewhere)."""
+    import torch.distributed as dist
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    assert sum(len(p) for p in parts) == n_items, 'a rank lost or duplicated an image'
+    return [parts[i % world][i // world] for i in range(n_items)]
+
+
 def main(argv=None):
     args = parse_args(argv)
     import torch.distributed as dist
@@ -92,6 +104,11 @@ def main(argv=None):
             res = model(lq=lq, gt=gt, test_mode=True, coord=coord, cell=cell, meta=[d['meta']], save_image=save,
                         save_path=args.save_path)
         results.append(res)
+    if world > 1 and not model.test_cfg.get('tile', None):
+        # whole-image configs shard the IMAGES (i % world == rank): collect every rank's results on rank 0 and
+        # re-interleave them into dataset order before evaluating, like the reference's multi_gpu_test
+        # (tools/test.py:82-146 -> mmedit.apis.multi_gpu_test collects before dataset.evaluate)
+        results = collect_results(results, len(dataset), rank, world)
     if rank == 0 and results and 'eval_result' in results[0]:
         stats = SRFolderDataset.evaluate(results)
         print()
