@@ -46,7 +46,7 @@ class OptionsT(C.Structure):
                 ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('reserved', C.c_int * 2)]
 
 
-HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_SPLIT_DECODE = 1, 2, 4
+HEAD_STAGED, HEAD_NO_LOGIT_TABLE = 1, 2
 
 
 class ConvT(C.Structure):

@@ -13,6 +13,10 @@
 //     one per CU;
 //   * the 14x14-pixel halo patch of one 64-channel input group (bf16, 25 KB) is loaded into LDS ONCE and
 //     serves all 9 taps (the next group's patch is prefetched into registers meanwhile, two LDS buffers);
+//     round 2: the patch loads leave in one burst after the tap-3 weights (vmcnt retires in order, so a patch load
+//     issued every tap made every weight wait also a wait for HBM), the LDS reads of tap t+1 are issued before the
+//     MFMAs of tap t (hipcc had placed them directly in front of their use: ~150 exposed cycles per 320-cycle tap),
+//     and the patch row pitch is padded to a bank-conflict-free 2240 B;
 //   * the 4 waves split K (wave w owns channels 16w..16w+15 of every group): each wave accumulates the whole
 //     160(144 used) x 64 tile -- 5x2 MFMA tiles, 160 accumulator registers -- so one 16-B LDS read per pixel
 //     tile feeds two MFMAs and one 1-KB weight fragment read from L2 (pre-packed, coalesced, no LDS) feeds five;
@@ -32,7 +36,11 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int DT = 12;                       // output tile edge (pixels)
 constexpr int DP = DT + 2;                   // patch edge with the 1-pixel halo
 constexpr int DPS = 144;                     // bytes per patch pixel: 64 bf16 + 16 B pad (conflict-free ds_read_b128)
-constexpr int DPATCH = DP * DP * DPS;        // 28 224 B per buffer
+constexpr int DROW = 2240;                   // bytes per patch row: 14 x 144 + 224 B pad.  With the 144-B pixel stride a ds_read_b128 of
+                                             // 16 lanes is conflict-free iff the lanes' (9 x + 12 y) mod 16 differ; a pitch = 192 mod 256
+                                             // gives every 16-lane group of every pixel tile distinct bank quads (round 1's 2016-B
+                                             // pitch: 34 two-way conflicts per 160 lane reads, SQ_LDS_BANK_CONFLICT 32 % of LDS cycles)
+constexpr int DPATCH = DP * DROW;            // 31 360 B per buffer
 constexpr int DCHUNKS = DP * DP * 8;         // 16-byte chunks of a patch
 constexpr int DLOADS = (DCHUNKS + 255) / 256;
 constexpr int DMT = 5;                       // 32-pixel MFMA tiles per workgroup (160 rows, 144 used)
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
         const bool ok = c < DCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         goff[s] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)p.ldxb * 2u + (unsigned)part * 16u) : kOobD;
-        loff[s] = c < DCHUNKS ? px * DPS + part * 16 : -1;
+        loff[s] = c < DCHUNKS ? py * DROW + pxx * DPS + part * 16 : -1;
     }
     i32x4 P[DLOADS];
     auto load_chunk = [&](int s, int g) {
@@ -94,7 +102,7 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
         int idx = 32 * r + li;
         idx = idx < DT * DT ? idx : DT * DT - 1;
         const int y = idx / DT, x = idx - y * DT;
-        poff[r] = ((y + 1) * DP + (x + 1)) * DPS + (16 * w + 8 * lh) * 2;
+        poff[r] = (y + 1) * DROW + (x + 1) * DPS + (16 * w + 8 * lh) * 2;
     }
     const uint4* wl = p.wf + lane;
     const int kpt = 4 * p.groups;            // k16-steps per tap (cin / 16)
@@ -108,41 +116,52 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
 
+    // prologue: the first two weight stages go out BEFORE the patch (vmcnt retires in order: a later wait on the
+    // weights would otherwise also wait for the patch)
+    uint4 wq[3][2];                          // weight fragments of the current tap and the next two
+    wq[0][0] = frag(0, 0, 0); wq[0][1] = frag(1, 0, 0);
+    wq[1][0] = frag(0, 0, 1); wq[1][1] = frag(1, 0, 1);
 #pragma unroll
     for (int s = 0; s < DLOADS; ++s) load_chunk(s, 0);
     store_patch(0);
-    uint4 w0[2], w1[2], w2[2];               // weight fragments of the current tap and the next two
-    w0[0] = frag(0, 0, 0); w0[1] = frag(1, 0, 0);
-    w1[0] = frag(0, 0, 1); w1[1] = frag(1, 0, 1);
     __syncthreads();
 
     const int G = p.groups;
+    bf16x8 b[2][DMT];                        // activation fragments of the current tap and the next one
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const bool more = g + 1 < G;
         const unsigned char* pb = lds + (g & 1) * DPATCH;
 #pragma unroll
+        for (int r = 0; r < DMT; ++r)
+            b[0][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + poff[r] - DROW - DPS));      // tap 0
+#pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             {   // weights two taps ahead
                 int ng = g, ntap = tap + 2;
                 if (ntap >= 9) { ntap -= 9; ng = g + 1; }
-                if (ng < G) { w2[0] = frag(0, ng, ntap); w2[1] = frag(1, ng, ntap); }
+                if (ng < G) { wq[(tap + 2) % 3][0] = frag(0, ng, ntap); wq[(tap + 2) % 3][1] = frag(1, ng, ntap); }
             }
-            if (more && tap < DLOADS) load_chunk(tap, g + 1);      // next group's patch, one chunk per tap
-            const int toff = ((tap / 3 - 1) * DP + (tap % 3 - 1)) * DPS;
-            bf16x8 b[DMT];
+            // next group's whole patch right after the tap-3 weights left: the first wait that covers it is tap 4's
+            if (more && tap == 1) {
 #pragma unroll
-            for (int r = 0; r < DMT; ++r)
-                b[r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + poff[r] + toff));
+                for (int s = 0; s < DLOADS; ++s) load_chunk(s, g + 1);
+            }
+            if (tap + 1 < 9) {               // LDS reads one tap ahead: their latency runs under this tap's 10 MFMAs
+                const int toff = (((tap + 1) / 3 - 1) * DROW) + (((tap + 1) % 3 - 1) * DPS);
+#pragma unroll
+                for (int r = 0; r < DMT; ++r)
+                    b[(tap + 1) & 1][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + poff[r] + toff));
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, w0[nt]);
+                const bf16x8 a = __builtin_bit_cast(bf16x8, wq[tap % 3][nt]);
 #pragma unroll
-                for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[r], acc[nt][r], 0, 0, 0);
+                for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[tap & 1][r], acc[nt][r], 0, 0, 0);
             }
-            w0[0] = w1[0]; w0[1] = w1[1];
-            w1[0] = w2[0]; w1[1] = w2[1];
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // 9 taps = 3 full rotations of the weight ring: stages 0 and 1 now hold taps 0 and 1 of the next group
         if (more) store_patch((g + 1) & 1);
         __syncthreads();
     }

@@ -4,10 +4,13 @@
 // P.V' (arch_csnln.py:511 in the composed form of patch_ops.hip, K = L) when the host asks for bf16.
 //
 // v_mfma_f32_32x32x16_bf16 is 16x the fp32 MFMA rate, so the tile is sized for the operand streams instead:
-// workgroup tile 256 x 128 x 64 (one per CU, 108 KB of LDS double-buffered), 4 waves in a 2 x 2 grid, each wave a
-// 128 x 64 sub-tile = 4 x 2 MFMA tiles (128 accumulator registers): per 16-deep k-step a wave reads 6 KB from LDS
-// for 8 MFMAs (24 B/clk/SIMD, under the 128 B/clk/CU LDS limit) and the workgroup fetches 48 KB from L2/HBM per
-// 4.2 MFLOP stage (12 B/clk at the full MFMA rate).  Rows are padded to 144 B in LDS (conflict-free ds_read_b128).
+// workgroup tile 256 x 128 x 32, 4 waves in a 2 x 2 grid, each wave a 128 x 64 sub-tile = 4 x 2 MFMA tiles (128
+// accumulator registers): per 16-deep k-step a wave reads 6 KB from LDS for 8 MFMAs (24 B/clk/SIMD, under the
+// 128 B/clk/CU LDS limit) and the workgroup fetches 24 KB from L2/HBM per 2.1 MFLOP stage (12 B/clk at the full MFMA
+// rate).  The k-tile is 32 deep (not 64) so that the double-buffered stages take 60 KB and TWO workgroups share a CU:
+// with one wave per SIMD (round 1: 108 KB, one workgroup per CU) every barrier, LDS store and late global load stalled
+// the matrix pipe directly (SQ: 45 % of wave cycles in issue stalls, MFMA pipe 27 % busy); with two, one workgroup's
+// staging runs under the other's MFMAs.  Rows are padded to 80 B in LDS (conflict-free ds_read_b128).
 // Swapped MFMA operands (B rows = A operand, A rows = B operand): a lane owns one output row and 4 consecutive
 // columns per accumulator quad, so the epilogue stores 16 B (fp32) / 8 B (bf16) pieces.
 // Out-of-range rows / k-chunks are buffer loads with an out-of-range offset (return 0, no branches).
@@ -22,10 +25,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GM = 256, GN = 128, GK = 64;
-constexpr int GRS = 144;                                  // LDS row stride in bytes (64 bf16 + 16 B pad)
+constexpr int GM = 256, GN = 128, GK = 32;
+constexpr int GRS = GK * 2 + 16;                          // LDS row stride in bytes (32 bf16 + 16 B pad = 80)
+constexpr int GCH = GK / 8;                               // 16-byte chunks per row
+constexpr int GSA = GM * GCH / 256, GSB = GN * GCH / 256; // staging chunks per thread (A: 4, B: 2)
 constexpr int GA_T = GM * GRS, GB_T = GN * GRS;           // bytes per stage
-constexpr size_t kGemm16Lds = 2 * (size_t)(GA_T + GB_T);  // 110 592 B
+constexpr size_t kGemm16Lds = 2 * (size_t)(GA_T + GB_T);  // 61 440 B: two workgroups per CU
 constexpr unsigned kOob16 = 0xFFFFFFF0u;
 
 struct Gemm16P {
@@ -44,7 +49,7 @@ __device__ __forceinline__ unsigned short f2bf_g(float f) {
     return (unsigned short)(u >> 16);
 }
 
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(Gemm16P p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     unsigned char* As = lds16;                    // [2][GM][GRS]
     unsigned char* Bs = lds16 + 2 * GA_T;         // [2][GN][GRS]
@@ -61,35 +66,36 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Gemm16P p) {
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.B), 0, p.b_bytes, 0x00020000);
 
-    // staging: 16-byte chunk c = t + 256 s -> row c >> 3, k-part c & 7
-    const int part = t & 7, row0 = t >> 3;        // rows row0 + 32 s
-    unsigned a_off[8], b_off[4];
+    // staging: 16-byte chunk c = t + 256 s -> row c / GCH, k-part c % GCH
+    constexpr int RS = 256 / GCH;                 // rows covered per staging step
+    const int part = t % GCH, row0 = t / GCH;     // rows row0 + RS s
+    unsigned a_off[GSA], b_off[GSB];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int gm = m0 + row0 + 32 * s;
+    for (int s = 0; s < GSA; ++s) {
+        const int gm = m0 + row0 + RS * s;
         a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 2u + (unsigned)part * 16u : kOob16;
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int gn = n0 + row0 + 32 * s;
+    for (int s = 0; s < GSB; ++s) {
+        const int gn = n0 + row0 + RS * s;
         b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u : kOob16;
     }
-    i32x4 ra[8], rb[4];
+    i32x4 ra[GSA], rb[GSB];
     auto load_stage = [&](int kt) {
         const int k0 = kt * GK;
         const bool kok = k0 + part * 8 < p.K;     // K % 8 == 0: a chunk is entirely in or out
 #pragma unroll
-        for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < GSA; ++s)
             ra[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (kok && a_off[s] != kOob16) ? (int)(a_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < GSB; ++s)
             rb[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (kok && b_off[s] != kOob16) ? (int)(b_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) *reinterpret_cast<i32x4*>(As + buf * GA_T + (row0 + 32 * s) * GRS + part * 16) = ra[s];
+        for (int s = 0; s < GSA; ++s) *reinterpret_cast<i32x4*>(As + buf * GA_T + (row0 + RS * s) * GRS + part * 16) = ra[s];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<i32x4*>(Bs + buf * GB_T + (row0 + 32 * s) * GRS + part * 16) = rb[s];
+        for (int s = 0; s < GSB; ++s) *reinterpret_cast<i32x4*>(Bs + buf * GB_T + (row0 + RS * s) * GRS + part * 16) = rb[s];
     };
 
     f32x16 acc[4][2];
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(Gemm16P p) {
         const unsigned char* a = As + cur * GA_T + (128 * wm + li) * GRS + lh * 16;
         const unsigned char* b = Bs + cur * GB_T + (64 * wn + li) * GRS + lh * 16;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < GK / 16; ++ks) {
             bf16x8 fb[2], fa[4];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + ks * 32));

@@ -164,7 +164,60 @@ __device__ __forceinline__ void build_rows16(unsigned short* X, const FusedChain
     }
 }
 
-__global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) {
+// last Linear (256 -> 3) in fp32 on the bf16 activations + bilinear/border residual (net:107-108,221)
+__device__ __forceinline__ void decode_tail16(const unsigned short* X, const FusedQP& p, int t, int qbase) {
+    const int row = t >> 1, part = t & 1;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    {
+        const unsigned short* xr = X + row * HLD + 128 * part;
+        const float* w0 = p.w_last + 128 * part;
+        const float* w1 = w0 + p.ld_last;
+        const float* w2 = w1 + p.ld_last;
+#pragma unroll 4
+        for (int n = 0; n < 128; n += 4) {
+            const uint2 xb = *reinterpret_cast<const uint2*>(xr + n);
+            const float x0 = __uint_as_float(xb.x << 16), x1 = __uint_as_float(xb.x & 0xFFFF0000u);
+            const float x2 = __uint_as_float(xb.y << 16), x3 = __uint_as_float(xb.y & 0xFFFF0000u);
+            const float4 u0 = *reinterpret_cast<const float4*>(w0 + n);
+            const float4 u1 = *reinterpret_cast<const float4*>(w1 + n);
+            const float4 u2 = *reinterpret_cast<const float4*>(w2 + n);
+            a0 += x0 * u0.x + x1 * u0.y + x2 * u0.z + x3 * u0.w;
+            a1 += x0 * u1.x + x1 * u1.y + x2 * u1.z + x3 * u1.w;
+            a2 += x0 * u2.x + x1 * u2.y + x2 * u2.z + x3 * u2.w;
+        }
+    }
+    a0 += quad_xor1(a0);
+    a1 += quad_xor1(a1);
+    a2 += quad_xor1(a2);
+    const int ql = qbase + row;
+    if (part == 0 && ql < p.nq) {
+        const long q = p.q0 + ql;
+        float v[3] = {a0 + p.b_last[0], a1 + p.b_last[1], a2 + p.b_last[2]};
+        if (p.x_lr) {
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            float fy = sub_rn(mul_rn(add_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
+            float fx = sub_rn(mul_rn(add_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
+            fy = fminf((float)(p.H - 1), fmaxf(fy, 0.f));
+            fx = fminf((float)(p.W - 1), fmaxf(fx, 0.f));
+            const float y0f = floorf(fy), x0f = floorf(fx);
+            const int y0 = (int)y0f, x0 = (int)x0f;
+            const float wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
+            const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx;
+            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);     // weights of clamped taps are 0
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* img = p.x_lr + (size_t)c * p.H * p.W;
+                v[c] += img[(size_t)y0 * p.W + x0] * (wx0 * wy0) + img[(size_t)y0 * p.W + x1] * (wx1 * wy0) +
+                        img[(size_t)y1 * p.W + x0] * (wx0 * wy1) + img[(size_t)y1 * p.W + x1] * (wx1 * wy1);
+            }
+        }
+        p.rgb[q * 3] = v[0];
+        p.rgb[q * 3 + 1] = v[1];
+        p.rgb[q * 3 + 2] = v[2];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_v1_kernel(FusedKVP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);                 // [128][264] bf16
     float* s_t4 = reinterpret_cast<float*>(smem_raw + (size_t)HBM_ * HLD * 2);        // [128][4]
@@ -356,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP p) {
+__global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_v1_kernel(FusedQP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);   // [128][264] bf16
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -399,56 +452,423 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
     __syncthreads();
     for (int l = 0; l < p.n_hidden; ++l) hidden_layer16(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
 
-    // last Linear (256 -> 3) in fp32 on the bf16 activations: 2 threads per row, 128 columns each
-    const int row = t >> 1, part = t & 1;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    {
-        const unsigned short* xr = X + row * HLD + 128 * part;
-        const float* w0 = p.w_last + 128 * part;
-        const float* w1 = w0 + p.ld_last;
-        const float* w2 = w1 + p.ld_last;
-#pragma unroll 4
-        for (int n = 0; n < 128; n += 4) {
-            const uint2 xb = *reinterpret_cast<const uint2*>(xr + n);
-            const float x0 = __uint_as_float(xb.x << 16), x1 = __uint_as_float(xb.x & 0xFFFF0000u);
-            const float x2 = __uint_as_float(xb.y << 16), x3 = __uint_as_float(xb.y & 0xFFFF0000u);
-            const float4 u0 = *reinterpret_cast<const float4*>(w0 + n);
-            const float4 u1 = *reinterpret_cast<const float4*>(w1 + n);
-            const float4 u2 = *reinterpret_cast<const float4*>(w2 + n);
-            a0 += x0 * u0.x + x1 * u0.y + x2 * u0.z + x3 * u0.w;
-            a1 += x0 * u1.x + x1 * u1.y + x2 * u1.z + x3 * u1.w;
-            a2 += x0 * u2.x + x1 * u2.y + x2 * u2.z + x3 * u2.w;
-        }
-    }
-    a0 += quad_xor1(a0);
-    a1 += quad_xor1(a1);
-    a2 += quad_xor1(a2);
-    const int ql = qbase + row;
-    if (part == 0 && ql < p.nq) {
-        const long q = p.q0 + ql;
-        float v[3] = {a0 + p.b_last[0], a1 + p.b_last[1], a2 + p.b_last[2]};
-        if (p.x_lr) {
-            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
-            float fy = sub_rn(mul_rn(add_rn(cy, 1.0f), (float)p.H * 0.5f), 0.5f);
-            float fx = sub_rn(mul_rn(add_rn(cx, 1.0f), (float)p.W * 0.5f), 0.5f);
-            fy = fminf((float)(p.H - 1), fmaxf(fy, 0.f));
-            fx = fminf((float)(p.W - 1), fmaxf(fx, 0.f));
-            const float y0f = floorf(fy), x0f = floorf(fx);
-            const int y0 = (int)y0f, x0 = (int)x0f;
-            const float wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
-            const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx;
-            const int y1 = min(y0 + 1, p.H - 1), x1 = min(x0 + 1, p.W - 1);     // weights of clamped taps are 0
+    decode_tail16(X, p, t, qbase);
+}
+
+// =================================================================================================================
+// v2 kernels (default).  Same decomposition (128 rows = 32 queries x 4 key samples per workgroup, two workgroups per CU,
+// weights = A operand straight from L2, activations = B operand from LDS), re-cut after the SQ counters of v1 showed the
+// VALU -- not the matrix pipe -- as the busiest issue port (11 VALU instructions per MFMA, MFMA pipe 25 % busy):
+//   * rows are SAMPLE-major: row m = 32 j + q (q = query within the workgroup, j = key sample), so the four samples of a
+//     query sit in the four m-tiles of ONE lane and the attention-weighted sum z = sum_j a_j value_j * w_v,j is four FMAs on
+//     the lane's own accumulators -- no DPP quad reductions, no selects (384 -> 144 VALU per 32-column unit);
+//   * biases are the accumulators' initial values (the zeroing moves were there anyway): epilogues lose an add per element;
+//   * the k-loop is fully unrolled over compile-time buffer indices (3 weight stages, 2 activation stages): no register
+//     rotation moves (24 v_mov per k-step in v1); a sched_barrier per k-step keeps hipcc from hoisting every load to the top;
+//   * gathers are issued BEFORE the MFMA block that hides them: the 16 value-row float4 of a v-out unit before its 64
+//     MFMAs, the first two weight fragments of a layer before the barrier that precedes it, table / logit-table rows 16
+//     (not 8) at a time while no accumulator is live;
+//   * Z leaves the kernel as bf16 (the decode kernel rounds it to bf16 before its first MFMA anyway: bit-identical
+//     result, half the round trip).
+// =================================================================================================================
+template <int NT>
+__device__ __forceinline__ void load_fb01(const uint4* __restrict__ wf, long tile_stride, uint4 (&fb)[3][NT]) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float* img = p.x_lr + (size_t)c * p.H * p.W;
-                v[c] += img[(size_t)y0 * p.W + x0] * (wx0 * wy0) + img[(size_t)y0 * p.W + x1] * (wx1 * wy0) +
-                        img[(size_t)y1 * p.W + x0] * (wx0 * wy1) + img[(size_t)y1 * p.W + x1] * (wx1 * wy1);
+    for (int ni = 0; ni < NT; ++ni) {
+        fb[0][ni] = wf[ni * tile_stride];
+        fb[1][ni] = wf[ni * tile_stride + 64];
+    }
+}
+
+// acc[mi][ni] += W_tile . X_tile^T over NKS (>= 2) k-steps; fb[0], fb[1] hold the first two weight stages already
+template <int NT, int NKS>
+__device__ __forceinline__ void mma_pass16u(const unsigned short* xa, const uint4* __restrict__ wf, long tile_stride,
+                                            f32x16 (&acc)[HMI][NT], uint4 (&fb)[3][NT]) {
+    bf16x8 fa[2][HMI];
+#pragma unroll
+    for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 2 < NKS) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fb[(ks + 2) % 3][ni] = wf[ni * tile_stride + (long)(ks + 2) * 64];
+        }
+        if (ks + 1 < NKS) {
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi)
+                fa[(ks + 1) & 1][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, fb[ks % 3][ni]);
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, fa[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// hidden layer, in place in LDS.  Entry: X may still be being written by other waves (the leading barrier orders it);
+// exit: X holds this layer's activations as far as THIS wave's stores go -- the next consumer starts with a barrier.
+__device__ __forceinline__ void hidden_layer16v2(unsigned short* X, const void* __restrict__ frag, const float* __restrict__ bias,
+                                                 int w, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const uint4* wf = reinterpret_cast<const uint4*>(frag) + (size_t)(2 * w) * HKS * 64 + lane;
+    uint4 fb[3][2];
+    load_fb01<2>(wf, (long)HKS * 64, fb);                     // in flight across the barrier
+    f32x16 acc[HMI][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + 64 * w + 32 * ni + 8 * g + 4 * lh);
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) {
+                acc[mi][ni][4 * g] = b.x; acc[mi][ni][4 * g + 1] = b.y; acc[mi][ni][4 * g + 2] = b.z; acc[mi][ni][4 * g + 3] = b.w;
             }
         }
-        p.rgb[q * 3] = v[0];
-        p.rgb[q * 3 + 1] = v[1];
-        p.rgb[q * 3 + 2] = v[2];
+    __syncthreads();
+    mma_pass16u<2, HKS>(X + li * HLD + 8 * lh, wf, (long)HKS * 64, acc, fb);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) {
+                uint2 o;
+                o.x = pack2(fmaxf(acc[mi][ni][4 * g], 0.f), fmaxf(acc[mi][ni][4 * g + 1], 0.f));
+                o.y = pack2(fmaxf(acc[mi][ni][4 * g + 2], 0.f), fmaxf(acc[mi][ni][4 * g + 3], 0.f));
+                *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
+            }
+        }
+}
+
+// layer-0 rows from the hoisted tables: 32 rows per thread, 16 table gathers in flight at a time (no accumulator is live here)
+__device__ __forceinline__ void build_rows16v2(unsigned short* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
+    const int n4 = t & 63;
+    float4 tw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
+#pragma unroll
+    for (int b = 0; b < HBM_ / 64; ++b) {
+        float4 tv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tv[i] = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[(t >> 6) + 4 * (16 * b + i)] * HH)[n4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = (t >> 6) + 4 * (16 * b + i);
+            const float4 q = *reinterpret_cast<const float4*>(s_t4 + 4 * r);       // rel_y rel_x scale_y scale_x
+            uint2 o;
+            o.x = pack2(fmaxf(tv[i].x + tw[0].x * q.x + tw[0].y * q.y + tw[0].z * q.z + tw[0].w * q.w, 0.f),
+                        fmaxf(tv[i].y + tw[1].x * q.x + tw[1].y * q.y + tw[1].z * q.z + tw[1].w * q.w, 0.f));
+            o.y = pack2(fmaxf(tv[i].z + tw[2].x * q.x + tw[2].y * q.y + tw[2].z * q.z + tw[2].w * q.w, 0.f),
+                        fmaxf(tv[i].w + tw[3].x * q.x + tw[3].y * q.y + tw[3].z * q.z + tw[3].w * q.w, 0.f));
+            *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
+        }
     }
+}
+
+__global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);                 // [128][264] bf16
+    float* s_t4 = reinterpret_cast<float*>(smem_raw + (size_t)HBM_ * HLD * 2);        // [128][4]
+    float* s_part = s_t4 + HBM_ * 4;                                                  // [4][128]
+    float* s_attn = s_part + 4 * HBM_;                                                // [128]
+    int* s_kpix = reinterpret_cast<int*>(s_attn + HBM_);                              // [128]
+    int* s_qpix = s_kpix + HBM_;                                                      // [32]
+    int* s_goff = s_qpix + HBM_ / 4;                                                  // [128]
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * (HBM_ / 4);
+
+    // ---- index math: row m = 32 j + q --------------------------------------------------------------------------
+    int bad = 0;
+    if (t < HBM_) {
+        const int ql = qbase + (t & 31), j = t >> 5;
+        int kpix = 0, goff = -1;
+        float t4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ql < p.nq) {
+            const long q = p.q0 + ql;
+            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+            const long c0 = p.chunk > 0 ? (q / p.chunk) * p.chunk : 0;
+            const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, 2);
+            kpix = s.ky * p.W + s.kx;
+            t4[0] = s.rel_y; t4[1] = s.rel_x;
+            t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
+            t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
+            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+            const bool qin = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (j == 0) s_qpix[t] = qin ? iy * p.W + ix : -1;
+            if (qin) {
+                const int oy = s.ky - iy, ox = s.kx - ix;
+                if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) goff = (iy * p.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
+                else bad = 1;
+            }
+        } else if (j == 0) {
+            s_qpix[t] = -1;
+        }
+        s_kpix[t] = kpix;
+        s_goff[t] = goff;
+        *reinterpret_cast<float4*>(s_t4 + 4 * t) = make_float4(t4[0], t4[1], t4[2], t4[3]);
+    }
+    const bool table = p.G != nullptr && !__syncthreads_or(bad);
+    if (p.G == nullptr) __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
+
+    // ================= phi_k =====================================================================
+    build_rows16v2(X, p.k, s_kpix, s_t4, t);
+    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16v2(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    __syncthreads();
+    if (table) {
+        // logit = h4 . G[query pixel, key offset] + c (fp32 table, bf16 activations): 2 threads per row, 16 gathers in flight
+        const int row = t >> 1, part = t & 1;
+        const int go = s_goff[row];
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
+        const unsigned gbase = go >= 0 ? (unsigned)go * (unsigned)p.ldg * 4u : kOobH;
+        float a = (go >= 0 && part == 0) ? p.G[(size_t)go * p.ldg + 256] : 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            float4 gv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) gv[i] = hload4(rs_g, gbase == kOobH ? kOobH : gbase + (unsigned)(8 * (16 * b + i) + 4 * part) * 4u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint2 xb = *reinterpret_cast<const uint2*>(X + row * HLD + 8 * (16 * b + i) + 4 * part);
+                a += __uint_as_float(xb.x << 16) * gv[i].x + __uint_as_float(xb.x & 0xFFFF0000u) * gv[i].y +
+                     __uint_as_float(xb.y << 16) * gv[i].z + __uint_as_float(xb.y & 0xFFFF0000u) * gv[i].w;
+            }
+        }
+        a += quad_xor1(a);
+        if (part == 0) {
+            s_part[row] = a;
+            s_part[HBM_ + row] = 0.f;
+            s_part[2 * HBM_ + row] = 0.f;
+            s_part[3 * HBM_ + row] = 0.f;
+        }
+    } else {
+        // fallback (no table, or a key outside the query's 3x3 neighbourhood): imnet_k's output layer on the MFMA
+        float part[HMI];
+        unsigned koff[HMI];
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) {
+            part[mi] = 0.f;
+            koff[mi] = (unsigned)s_kpix[32 * mi + li] * (unsigned)p.ldu * 4u;
+        }
+        const int qp = s_qpix[li];
+        const unsigned qoff = qp >= 0 ? (unsigned)qp * (unsigned)p.ldu * 4u : kOobH;
+        const int n_units = (p.k.n_out + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t rs_bk =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.k.bias_out), 0, (unsigned)p.k.n_out * 4u, 0x00020000);
+        for (int u = w; u < n_units; u += 4) {
+            f32x16 acc[HMI][1];
+            zero_acc16<1>(acc);
+            mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.k.frag_out) + (size_t)u * HKS * 64 + lane, HKS,
+                          0, acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.k.n_out ? (unsigned)d0 * 4u : kOobH;
+                const float4 bv = hload4(rs_bk, doff);
+                const float4 qv = hload4(rs_u, (doff == kOobH || qoff == kOobH) ? kOobH : qoff + doff);
+                float4 kv[HMI];
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) kv[mi] = hload4(rs_u, doff == kOobH ? kOobH : koff[mi] + doff);
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi)
+                    part[mi] += qv.x * (kv[mi].x * (acc[mi][0][4 * g] + bv.x)) + qv.y * (kv[mi].y * (acc[mi][0][4 * g + 1] + bv.y)) +
+                                qv.z * (kv[mi].z * (acc[mi][0][4 * g + 2] + bv.z)) + qv.w * (kv[mi].w * (acc[mi][0][4 * g + 3] + bv.w));
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) {
+            part[mi] += __shfl_xor(part[mi], 32, 64);
+            if (lh == 0) s_part[w * HBM_ + 32 * mi + li] = part[mi];
+        }
+    }
+    __syncthreads();
+    if (t < HBM_ / 4) {          // 4-way softmax of query t: rows t, t + 32, t + 64, t + 96
+        float lg[4], m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 32 * j + t;
+            lg[j] = (s_part[row] + s_part[HBM_ + row] + s_part[2 * HBM_ + row] + s_part[3 * HBM_ + row]) / p.softmax_scale;
+            m = fmaxf(m, lg[j]);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lg[j] = expf(lg[j] - m); den += lg[j]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s_attn[32 * j + t] = lg[j] / den;
+    }
+
+    // ================= phi_v =====================================================================
+    build_rows16v2(X, p.v, s_kpix, s_t4, t);          // every wave is past its logit reads of X (barrier above)
+    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer16v2(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    __syncthreads();
+    {
+        const int n_units = (p.v.n_out + 31) >> 5;
+        const __amdgpu_buffer_rsrc_t rs_bv =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v.bias_out), 0, (unsigned)p.v.n_out * 4u, 0x00020000);
+        // Z rows are bf16: [nq][ldz] unsigned short
+        const __amdgpu_buffer_rsrc_t rs_z =
+            __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (unsigned)((size_t)p.nq * p.ldz * 2), 0x00020000);
+        unsigned voff[HMI];
+        float av[HMI];
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) {
+            voff[mi] = (unsigned)s_kpix[32 * mi + li] * (unsigned)p.ldu * 4u;
+            av[mi] = s_attn[32 * mi + li];
+        }
+        const int ql = qbase + li;
+        const unsigned zoff = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 2u : kOobH;
+        for (int u = w; u < n_units; u += 4) {
+            const uint4* wf = reinterpret_cast<const uint4*>(p.v.frag_out) + (size_t)u * HKS * 64 + lane;
+            uint4 fb[3][1];
+            load_fb01<1>(wf, 0, fb);
+            // the unit's value rows and bias: in flight under the 64 MFMAs below
+            float4 vv[4][HMI];
+            f32x16 acc[HMI][1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const unsigned doff = d0 < p.v.n_out ? (unsigned)d0 * 4u : kOobH;
+                const float4 bv = hload4(rs_bv, doff);
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) {
+                    vv[g][mi] = hload4(rs_u, doff == kOobH ? kOobH : voff[mi] + doff);
+                    acc[mi][0][4 * g] = bv.x; acc[mi][0][4 * g + 1] = bv.y; acc[mi][0][4 * g + 2] = bv.z; acc[mi][0][4 * g + 3] = bv.w;
+                }
+            }
+            mma_pass16u<1, HKS>(X + li * HLD + 8 * lh, wf, 0, acc, fb);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) {
+                    z.x = fmaf(av[mi] * vv[g][mi].x, acc[mi][0][4 * g], z.x);
+                    z.y = fmaf(av[mi] * vv[g][mi].y, acc[mi][0][4 * g + 1], z.y);
+                    z.z = fmaf(av[mi] * vv[g][mi].z, acc[mi][0][4 * g + 2], z.z);
+                    z.w = fmaf(av[mi] * vv[g][mi].w, acc[mi][0][4 * g + 3], z.w);
+                }
+                const int d0 = 32 * u + 8 * g + 4 * lh;
+                const uint2 zb = pack_bf16x4(z.x, z.y, z.z, z.w);
+                typedef int i32x2 __attribute__((ext_vector_type(2)));
+                i32x2 zi; zi.x = (int)zb.x; zi.y = (int)zb.y;
+                __builtin_amdgcn_raw_buffer_store_b64(zi, rs_z, (int)((zoff == kOobH || d0 >= p.v.n_out) ? kOobH : zoff + (unsigned)d0 * 2u), 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode: Z arrives as bf16 rows; input layer streamed through LDS in 256-column chunks.
+// One chunk: [weight prefetch] [barrier] [128 x 256 bf16 piece of Z -> LDS] [barrier] [NKS k-steps].  Columns >= kc are
+// zero-filled in LDS, and the weight stream is read through a bounded buffer descriptor (0 beyond its end), so a ragged
+// last chunk may run whole k-steps past Dv.
+template <int NKS>
+__device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP& p, __amdgpu_buffer_rsrc_t rs_z, __amdgpu_buffer_rsrc_t rs_w,
+                                               int k0, int kc, int qbase, int t, int w, int lane, f32x16 (&acc)[HMI][2]) {
+    const int li = lane & 31, lh = lane >> 5;
+    const unsigned tile_bytes = (unsigned)p.nj_in * 64u * 16u;
+    const unsigned wbase = ((unsigned)(2 * w) * (unsigned)p.nj_in + (unsigned)(k0 >> 4)) * 64u * 16u + (unsigned)lane * 16u;
+    auto wload = [&](int ni, int ks) -> uint4 {
+        const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(wbase + (unsigned)ni * tile_bytes + (unsigned)ks * 1024u), 0, 0);
+        return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+    };
+    uint4 fb[3][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) { fb[0][ni] = wload(ni, 0); fb[1][ni] = wload(ni, 1); }
+    if (k0 > 0) __syncthreads();
+    {
+        const int c8 = (t & 31) * 8;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            i32x4 zv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ql = qbase + (t >> 5) + 8 * (8 * b + i);
+                zv[i] = __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_z, (int)((ql < p.nq && c8 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c8)) * 2u : kOobH), 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<i32x4*>(X + ((t >> 5) + 8 * (8 * b + i)) * HLD + c8) = zv[i];
+        }
+    }
+    __syncthreads();
+    const unsigned short* xa = X + li * HLD + 8 * lh;
+    bf16x8 fa[2][HMI];
+#pragma unroll
+    for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (ks + 2 < NKS) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fb[(ks + 2) % 3][ni] = wload(ni, ks + 2);
+        }
+        if (ks + 1 < NKS) {
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi)
+                fa[(ks + 1) & 1][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const bf16x8 wv = __builtin_bit_cast(bf16x8, fb[ks % 3][ni]);
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, fa[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// TAIL = k-steps of the ragged last chunk rounded up to {0: none, 2, 4, 8, 16}
+template <int TAIL>
+__global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);   // [128][264] bf16
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int qbase = blockIdx.x * HBM_;
+
+    f32x16 acc[HMI][2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias_in + 64 * w + 32 * ni + 8 * g + 4 * lh);
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) {
+                acc[mi][ni][4 * g] = b.x; acc[mi][ni][4 * g + 1] = b.y; acc[mi][ni][4 * g + 2] = b.z; acc[mi][ni][4 * g + 3] = b.w;
+            }
+        }
+    const __amdgpu_buffer_rsrc_t rs_z =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.frag_in), 0, (unsigned)(8u * (unsigned)p.nj_in * 1024u), 0x00020000);
+    const int k_full = p.Dv & ~(HH - 1);
+#pragma unroll 1
+    for (int k0 = 0; k0 < k_full; k0 += HH) decode_chunk16<HKS>(X, p, rs_z, rs_w, k0, HH, qbase, t, w, lane, acc);
+    if (TAIL > 0) decode_chunk16<(TAIL > 0 ? TAIL : 2)>(X, p, rs_z, rs_w, k_full, p.Dv - k_full, qbase, t, w, lane, acc);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
+#pragma unroll
+            for (int mi = 0; mi < HMI; ++mi) {
+                uint2 o;
+                o.x = pack2(fmaxf(acc[mi][ni][4 * g], 0.f), fmaxf(acc[mi][ni][4 * g + 1], 0.f));
+                o.y = pack2(fmaxf(acc[mi][ni][4 * g + 2], 0.f), fmaxf(acc[mi][ni][4 * g + 3], 0.f));
+                *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
+            }
+        }
+    for (int l = 0; l < p.n_hidden; ++l) hidden_layer16v2(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
+    __syncthreads();
+    decode_tail16(X, p, t, qbase);
 }
 
 // ---- host side ----------------------------------------------------------------------------------
@@ -466,18 +886,41 @@ int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream
 
 constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32 + HBM_) * sizeof(int);
 
+// rows_per_wg == 1 selects the v1 kernels (fp32 Z, query-major rows): kept one round for A/B measurements
 int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
     CIAOSR_BIG_LDS(head_kv_fused_bf16_kernel, kFused16Lds);
+    CIAOSR_BIG_LDS(head_kv_fused_bf16_v1_kernel, kFused16Lds);
     ProfScope prof("head_kv_fused_bf16", s);
-    hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
+    if (p.rows_per_wg == 1)
+        hipLaunchKernelGGL(head_kv_fused_bf16_v1_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
+    else
+        hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
     return launch_status("head_kv_fused_bf16");
 }
 
 int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
     const size_t lds = (size_t)HBM_ * HLD * 2;
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_v1_kernel, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<0>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<2>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<4>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<8>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<16>, lds);
     ProfScope prof("head_decode_fused_bf16", s);
-    hipLaunchKernelGGL(head_decode_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_)), dim3(256), lds, s, p);
+    const dim3 grid(ceil_div(p.nq, HBM_));
+    const int tail_steps = ((p.Dv & (HH - 1)) + 15) >> 4;      // k-steps of the ragged last chunk (C = 64: 8, C = 180: 1)
+    if (p.rows_per_wg == 1)
+        hipLaunchKernelGGL(head_decode_fused_bf16_v1_kernel, grid, dim3(256), lds, s, p);
+    else if (tail_steps == 0)
+        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<0>, grid, dim3(256), lds, s, p);
+    else if (tail_steps <= 2)
+        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<2>, grid, dim3(256), lds, s, p);
+    else if (tail_steps <= 4)
+        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<4>, grid, dim3(256), lds, s, p);
+    else if (tail_steps <= 8)
+        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<8>, grid, dim3(256), lds, s, p);
+    else
+        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<16>, grid, dim3(256), lds, s, p);
     return launch_status("head_decode_fused_bf16");
 }
 

@@ -62,7 +62,6 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
 #define CIAOSR_HEAD_STAGED 1          /* head_route bit 0: per-layer GEMM path instead of the fused kernels */
 #define CIAOSR_HEAD_NO_LOGIT_TABLE 2  /* head_route bit 1: fused path, imnet_k output layer on the MFMA per (query, sample)
                                        * row instead of the exact 9-rows-per-LR-pixel fold */
-#define CIAOSR_HEAD_SPLIT_DECODE 4    /* head_route bit 2: fused path with Z materialised and a separate decode launch */
 typedef struct ciaosr_options {
     int head_route;         /* CIAOSR_HEAD_* bits; 0 = automatic */
     int csa_composed_min;   /* cs_attn: LR pixels (after padding) from which the composed fold+down tail applies;
