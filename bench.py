@@ -193,6 +193,8 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs, fp32 accumulation')
+    ap.add_argument('--bf16-single', action='store_true',
+                    help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
                     help='c3 (default; the config BASELINE.json\'s metric is quoted on): LR 1356x2040, 117 tiles; c3s: LR 339x510 (6 tiles); '
                          'c3tile: one 192x192 LR tile; c2: LR 48x48 (BASELINE configs[1]); c2q: C2 with its query range sharded over the ranks '
@@ -233,7 +235,7 @@ def main():
     from ciaosr_amd.tile_shard import clip_test_distributed, predict_query_sharded
     from ciaosr_amd.coords import make_coord, make_cell
     _lib.load()
-    opt = hip_ops.Options(args.precision)
+    opt = hip_ops.Options(args.precision, bf16_single=int(args.bf16_single and args.precision == 'bf16'))
 
     scale = 4
     lr_h, lr_w, n_tiles_img, wl_desc = WORKLOADS[args.workload]
@@ -392,7 +394,8 @@ def main():
             'unit': 'Mpix/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True,
             'scaling': 'weak' if world == 1 else 'strong', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else 'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions',
+            'dtype': 'f32' if args.precision == 'fp32' else ('bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
+                      + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),
             'data': 'synthetic',
             'config': {'workload': wl_desc + (', fp32' if args.precision == 'fp32' else ', bf16 mode')
                        + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs, '

@@ -23,7 +23,7 @@ class MlpT(C.Structure):
     _fields_ = [('n_layers', C.c_int), ('in_dim', C.c_int), ('width', C.c_int * MAX_LAYERS),
                 ('weight', C.c_void_p * MAX_LAYERS), ('ld', C.c_int * MAX_LAYERS),
                 ('bias', C.c_void_p * MAX_LAYERS), ('frag', C.c_void_p * MAX_LAYERS),
-                ('frag16', C.c_void_p * MAX_LAYERS)]
+                ('frag16', C.c_void_p * MAX_LAYERS), ('frag16_lo', C.c_void_p * MAX_LAYERS)]
 
 
 class HeadWeightsT(C.Structure):
@@ -43,7 +43,8 @@ class CsAttnWeightsT(C.Structure):
 class OptionsT(C.Structure):
     """ciaosr_options_t: per-call route options (include/ciaosr_hip.h)."""
     _fields_ = [('head_route', C.c_int), ('csa_composed_min', C.c_int), ('dense_min_tiles', C.c_int),
-                ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('reserved', C.c_int * 2)]
+                ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('bf16_single', C.c_int),
+                ('reserved', C.c_int * 1)]
 
 
 HEAD_STAGED, HEAD_NO_LOGIT_TABLE = 1, 2
@@ -51,7 +52,7 @@ HEAD_STAGED, HEAD_NO_LOGIT_TABLE = 1, 2
 
 class ConvT(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int),
-                ('frag16', C.c_void_p), ('frag', C.c_void_p)]
+                ('frag16', C.c_void_p), ('frag16_lo', C.c_void_p), ('frag', C.c_void_p)]
 
 
 class RdnWeightsT(C.Structure):
@@ -107,6 +108,7 @@ SIGNATURES = {
     'ciaosr_pack_fragments_f32': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_fragment_bf16_bytes': (_S, [_I, _I]),
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ciaosr_pack_fragments_bf16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
     'ciaosr_gather_rows_f32': (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),

@@ -53,6 +53,7 @@ struct DenseBf16P {
     int H, W, tiles_x;
     int groups;                              // input groups of this layer (l + 1)
     const uint4* wf; int nks;                // ciaosr_pack_fragments_bf16 of the conv weight [64][9*cin]: [2][nks][64 lanes]
+    const uint4* wf_lo;                      // ciaosr_pack_fragments_bf16_lo of the same matrix (hi + lo weight pair), or null
     const float* bias;                       // [64]
     float* x; int ldx;                       // fp32 feature buffer (written at column col_out)
     unsigned short* xb_out;                  // == xb (written at column col_out)
@@ -107,6 +108,9 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
     const uint4* wl = p.wf + lane;
     const int kpt = 4 * p.groups;            // k16-steps per tap (cin / 16)
     auto frag = [&](int nt, int g, int tap) -> uint4 { return wl[(size_t)(nt * p.nks + tap * kpt + 4 * g + w) * 64]; };
+    const bool has_lo = p.wf_lo != nullptr;                       // uniform: second MFMA per product with the weights' low halves
+    const uint4* wll = (has_lo ? p.wf_lo : p.wf) + lane;
+    auto frag_lo = [&](int nt, int g, int tap) -> uint4 { return wll[(size_t)(nt * p.nks + tap * kpt + 4 * g + w) * 64]; };
 
     f32x16 acc[2][DMT];
 #pragma unroll
@@ -118,9 +122,13 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
 
     // prologue: the first two weight stages go out BEFORE the patch (vmcnt retires in order: a later wait on the
     // weights would otherwise also wait for the patch)
-    uint4 wq[3][2];                          // weight fragments of the current tap and the next two
+    uint4 wq[3][2], wlq[3][2];               // weight fragments (hi, lo) of the current tap and the next two
     wq[0][0] = frag(0, 0, 0); wq[0][1] = frag(1, 0, 0);
     wq[1][0] = frag(0, 0, 1); wq[1][1] = frag(1, 0, 1);
+    if (has_lo) {
+        wlq[0][0] = frag_lo(0, 0, 0); wlq[0][1] = frag_lo(1, 0, 0);
+        wlq[1][0] = frag_lo(0, 0, 1); wlq[1][1] = frag_lo(1, 0, 1);
+    }
 #pragma unroll
     for (int s = 0; s < DLOADS; ++s) load_chunk(s, 0);
     store_patch(0);
@@ -140,7 +148,10 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
             {   // weights two taps ahead
                 int ng = g, ntap = tap + 2;
                 if (ntap >= 9) { ntap -= 9; ng = g + 1; }
-                if (ng < G) { wq[(tap + 2) % 3][0] = frag(0, ng, ntap); wq[(tap + 2) % 3][1] = frag(1, ng, ntap); }
+                if (ng < G) {
+                    wq[(tap + 2) % 3][0] = frag(0, ng, ntap); wq[(tap + 2) % 3][1] = frag(1, ng, ntap);
+                    if (has_lo) { wlq[(tap + 2) % 3][0] = frag_lo(0, ng, ntap); wlq[(tap + 2) % 3][1] = frag_lo(1, ng, ntap); }
+                }
             }
             // next group's whole patch right after the tap-3 weights left: the first wait that covers it is tap 4's
             if (more && tap == 1) {
@@ -158,6 +169,14 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, wq[tap % 3][nt]);
 #pragma unroll
                 for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[tap & 1][r], acc[nt][r], 0, 0, 0);
+            }
+            if (has_lo) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, wlq[tap % 3][nt]);
+#pragma unroll
+                    for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[tap & 1][r], acc[nt][r], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -228,7 +247,7 @@ int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int c
 }
 
 // dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb)
-int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
+int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
                      const float* bias, hipStream_t s) {
     CIAOSR_CHECK_ARG(X && Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);
     const size_t xb_bytes = (size_t)H * W * ldxb * 2;
@@ -238,6 +257,7 @@ int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int
     p.H = H; p.W = W; p.tiles_x = ceil_div(W, DT);
     p.groups = l + 1;
     p.wf = reinterpret_cast<const uint4*>(frag16); p.nks = 9 * 64 * (l + 1) / 16;
+    p.wf_lo = reinterpret_cast<const uint4*>(frag16_lo);
     p.bias = bias;
     p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
     CIAOSR_BIG_LDS(dense_bf16_kernel, kDenseLds);

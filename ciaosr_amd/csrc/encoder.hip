@@ -16,7 +16,7 @@ int dense_scatter_step(float* X, int ldx, int H, int W, int step, int num_layers
 // dense_bf16.hip
 int dense_bf16_tiles(int H, int W);
 int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);
-int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,
+int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
                      const float* bias, hipStream_t s);
 
 // dense_scatter_f32.hip
@@ -126,7 +126,7 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
-                RUN(dense_layer_bf16(x, cb, Xb, cb, H, W, l, c.frag16, c.bias, s));
+                RUN(dense_layer_bf16(x, cb, Xb, cb, H, W, l, c.frag16, (opt && opt->bf16_single) ? nullptr : c.frag16_lo, c.bias, s));
             }
         } else if (dense32) {
             for (int l = 0; l < NL; ++l) {

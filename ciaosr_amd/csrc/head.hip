@@ -89,16 +89,18 @@ static bool chain_fused_ok(const ciaosr_mlp_t& m, bool is_q, bool bf16) {
     return true;
 }
 
-static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table, int fan, bool bf16) {
+static void fill_chain(FusedChain& c, const ciaosr_mlp_t& m, const float* table, int fan, bool bf16, bool lo) {
     c.table = table;
     c.tail = m.weight[0] + fan;
     c.ld_tail = m.ld[0];
     c.n_hidden = m.n_layers - 2;
     for (int i = 0; i < c.n_hidden; ++i) {
         c.frag_hidden[i] = bf16 ? m.frag16[i + 1] : (const void*)m.frag[i + 1];
+        c.frag_hidden_lo[i] = (bf16 && lo) ? m.frag16_lo[i + 1] : nullptr;
         c.bias_hidden[i] = m.bias[i + 1];
     }
     c.frag_out = bf16 ? m.frag16[m.n_layers - 1] : (const void*)m.frag[m.n_layers - 1];
+    c.frag_out_lo = (bf16 && lo) ? m.frag16_lo[m.n_layers - 1] : nullptr;
     c.bias_out = m.bias[m.n_layers - 1];
     c.n_out = m.width[m.n_layers - 1];
 }
@@ -117,7 +119,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                         const float* cell, int Q, int chunk, float* rgb, const ciaosr_options_t* opt, void* workspace,
                         size_t workspace_bytes, void* stream_, bool bf16) {
     const int route = opt ? opt->head_route : 0;
-    CIAOSR_CHECK_ARG(!opt || (opt->reserved[0] == 0 && opt->reserved[1] == 0));
+    const bool lo = !(opt && opt->bf16_single);      // bf16 entry: hi + lo weight pairs unless single is asked for
+    CIAOSR_CHECK_ARG(!opt || opt->reserved[0] == 0);
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
     CIAOSR_CHECK_ARG(w->local_size >= 1 && w->local_size <= 3 && w->softmax_scale != 0.f);
@@ -205,8 +208,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             kp.coord = coord; kp.cell = cell; kp.q0 = q0; kp.nq = nq; kp.chunk = chunk; kp.H = H; kp.W = W;
             kp.U = U; kp.ldu = p.Dv; kp.D = p.D; kp.Dv = p.Dv;
             kp.u_bytes = (unsigned)((size_t)p.HW * p.Dv * sizeof(float));
-            fill_chain(kp.k, w->k, Tk, p.D, bf16);
-            fill_chain(kp.v, w->v, Tv, p.Dv, bf16);
+            fill_chain(kp.k, w->k, Tk, p.D, bf16, lo);
+            fill_chain(kp.v, w->v, Tv, p.Dv, bf16, lo);
             kp.softmax_scale = w->softmax_scale;
             kp.Z = Z; kp.ldz = p.Dv;
             kp.rows_per_wg = opt ? opt->kv_rows : 0;
@@ -216,10 +219,12 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             FusedQP qp;
             qp.Z = Z; qp.ldz = p.Dv; qp.Dv = p.Dv;
             qp.frag_in = bf16 ? mq.frag16[0] : (const void*)mq.frag[0]; qp.bias_in = mq.bias[0];
+            qp.frag_in_lo = (bf16 && lo) ? mq.frag16_lo[0] : nullptr;
             qp.nj_in = bf16 ? (p.Dv + 15) / 16 : (p.Dv + 7) / 8;
             qp.n_hidden = mq.n_layers - 2;
             for (int i = 0; i < qp.n_hidden; ++i) {
                 qp.frag_hidden[i] = bf16 ? mq.frag16[i + 1] : (const void*)mq.frag[i + 1];
+                qp.frag_hidden_lo[i] = (bf16 && lo) ? mq.frag16_lo[i + 1] : nullptr;
                 qp.bias_hidden[i] = mq.bias[i + 1];
             }
             qp.w_last = mq.weight[mq.n_layers - 1]; qp.ld_last = mq.ld[mq.n_layers - 1];

@@ -44,8 +44,9 @@ __device__ __forceinline__ void hstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned by
 
 // ---- fragment packing: W [N][ld] fp32 (K valid columns) -> P[nt][ks][lane][8 bf16]; lane (i = lane&31,
 // g = lane>>5) holds W[32nt + i][16ks + 8g .. 16ks + 8g + 7]; zero padded.
+// residual != 0: the element packed is w - bf16(w) (the low half of the hi + lo pair) instead of w
 __global__ void pack_fragments_bf16_kernel(const float* __restrict__ W, int ld, int N, int K, uint4* __restrict__ P,
-                                           int n_tiles, int nks) {
+                                           int n_tiles, int nks, int residual) {
     const long total = (long)n_tiles * nks * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -54,7 +55,10 @@ __global__ void pack_fragments_bf16_kernel(const float* __restrict__ W, int ld, 
         const int n = nt * 32 + (lane & 31), k = 16 * ks + 8 * (lane >> 5);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (n < N && k + e < K) ? W[(size_t)n * ld + k + e] : 0.f;
+        for (int e = 0; e < 8; ++e) {
+            v[e] = (n < N && k + e < K) ? W[(size_t)n * ld + k + e] : 0.f;
+            if (residual) v[e] -= __uint_as_float((unsigned)to_bf16(v[e]) << 16);
+        }
         P[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
     }
 }
@@ -510,8 +514,8 @@ __device__ __forceinline__ void mma_pass16u(const unsigned short* xa, const uint
 
 // hidden layer, in place in LDS.  Entry: X may still be being written by other waves (the leading barrier orders it);
 // exit: X holds this layer's activations as far as THIS wave's stores go -- the next consumer starts with a barrier.
-__device__ __forceinline__ void hidden_layer16v2(unsigned short* X, const void* __restrict__ frag, const float* __restrict__ bias,
-                                                 int w, int lane) {
+__device__ __forceinline__ void hidden_layer16v2(unsigned short* X, const void* __restrict__ frag, const void* __restrict__ frag_lo,
+                                                 const float* __restrict__ bias, int w, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     const uint4* wf = reinterpret_cast<const uint4*>(frag) + (size_t)(2 * w) * HKS * 64 + lane;
     uint4 fb[3][2];
@@ -529,6 +533,11 @@ __device__ __forceinline__ void hidden_layer16v2(unsigned short* X, const void* 
         }
     __syncthreads();
     mma_pass16u<2, HKS>(X + li * HLD + 8 * lh, wf, (long)HKS * 64, acc, fb);
+    if (frag_lo) {      // low halves of the weight pairs against the same activations (uniform branch)
+        const uint4* wl = reinterpret_cast<const uint4*>(frag_lo) + (size_t)(2 * w) * HKS * 64 + lane;
+        load_fb01<2>(wl, (long)HKS * 64, fb);
+        mma_pass16u<2, HKS>(X + li * HLD + 8 * lh, wl, (long)HKS * 64, acc, fb);
+    }
     __syncthreads();
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
 
     // ================= phi_k =====================================================================
     build_rows16v2(X, p.k, s_kpix, s_t4, t);
-    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16v2(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16v2(X, p.k.frag_hidden[l], p.k.frag_hidden_lo[l], p.k.bias_hidden[l], w, lane);
     __syncthreads();
     if (table) {
         // logit = h4 . G[query pixel, key offset] + c (fp32 table, bf16 activations): 2 threads per row, 16 gathers in flight
@@ -668,6 +677,9 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
             zero_acc16<1>(acc);
             mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.k.frag_out) + (size_t)u * HKS * 64 + lane, HKS,
                           0, acc);
+            if (p.k.frag_out_lo)
+                mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.k.frag_out_lo) + (size_t)u * HKS * 64 + lane, HKS,
+                              0, acc);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 32 * u + 8 * g + 4 * lh;
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
 
     // ================= phi_v =====================================================================
     build_rows16v2(X, p.v, s_kpix, s_t4, t);          // every wave is past its logit reads of X (barrier above)
-    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer16v2(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer16v2(X, p.v.frag_hidden[l], p.v.frag_hidden_lo[l], p.v.bias_hidden[l], w, lane);
     __syncthreads();
     {
         const int n_units = (p.v.n_out + 31) >> 5;
@@ -744,6 +756,11 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
                 }
             }
             mma_pass16u<1, HKS>(X + li * HLD + 8 * lh, wf, 0, acc, fb);
+            if (p.v.frag_out_lo) {
+                const uint4* wl = reinterpret_cast<const uint4*>(p.v.frag_out_lo) + (size_t)u * HKS * 64 + lane;
+                load_fb01<1>(wl, 0, fb);
+                mma_pass16u<1, HKS>(X + li * HLD + 8 * lh, wl, 0, acc, fb);
+            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -771,7 +788,8 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
 // last chunk may run whole k-steps past Dv.
 template <int NKS>
 __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP& p, __amdgpu_buffer_rsrc_t rs_z, __amdgpu_buffer_rsrc_t rs_w,
-                                               int k0, int kc, int qbase, int t, int w, int lane, f32x16 (&acc)[HMI][2]) {
+                                               __amdgpu_buffer_rsrc_t rs_wlo, bool has_lo, int k0, int kc, int qbase, int t, int w, int lane,
+                                               f32x16 (&acc)[HMI][2]) {
     const int li = lane & 31, lh = lane >> 5;
     const unsigned tile_bytes = (unsigned)p.nj_in * 64u * 16u;
     const unsigned wbase = ((unsigned)(2 * w) * (unsigned)p.nj_in + (unsigned)(k0 >> 4)) * 64u * 16u + (unsigned)lane * 16u;
@@ -822,6 +840,35 @@ __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP&
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (has_lo) {       // low halves of the weight pairs, same LDS chunk
+        auto wload_lo = [&](int ni, int ks) -> uint4 {
+            const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs_wlo, (int)(wbase + (unsigned)ni * tile_bytes + (unsigned)ks * 1024u), 0, 0);
+            return make_uint4((unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w);
+        };
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) { fb[0][ni] = wload_lo(ni, 0); fb[1][ni] = wload_lo(ni, 1); }
+#pragma unroll
+        for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 2 < NKS) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) fb[(ks + 2) % 3][ni] = wload_lo(ni, ks + 2);
+            }
+            if (ks + 1 < NKS) {
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi)
+                    fa[(ks + 1) & 1][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const bf16x8 wv = __builtin_bit_cast(bf16x8, fb[ks % 3][ni]);
+#pragma unroll
+                for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, fa[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // TAIL = k-steps of the ragged last chunk rounded up to {0: none, 2, 4, 8, 16}
@@ -848,10 +895,14 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.frag_in), 0, (unsigned)(8u * (unsigned)p.nj_in * 1024u), 0x00020000);
+    const bool has_lo = p.frag_in_lo != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_wlo = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(has_lo ? p.frag_in_lo : p.frag_in), 0, (unsigned)(8u * (unsigned)p.nj_in * 1024u), 0x00020000);
     const int k_full = p.Dv & ~(HH - 1);
 #pragma unroll 1
-    for (int k0 = 0; k0 < k_full; k0 += HH) decode_chunk16<HKS>(X, p, rs_z, rs_w, k0, HH, qbase, t, w, lane, acc);
-    if (TAIL > 0) decode_chunk16<(TAIL > 0 ? TAIL : 2)>(X, p, rs_z, rs_w, k_full, p.Dv - k_full, qbase, t, w, lane, acc);
+    for (int k0 = 0; k0 < k_full; k0 += HH) decode_chunk16<HKS>(X, p, rs_z, rs_w, rs_wlo, has_lo, k0, HH, qbase, t, w, lane, acc);
+    if (TAIL > 0)
+        decode_chunk16<(TAIL > 0 ? TAIL : 2)>(X, p, rs_z, rs_w, rs_wlo, has_lo, k_full, p.Dv - k_full, qbase, t, w, lane, acc);
     __syncthreads();
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
@@ -866,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
                 *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
             }
         }
-    for (int l = 0; l < p.n_hidden; ++l) hidden_layer16v2(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.n_hidden; ++l) hidden_layer16v2(X, p.frag_hidden[l], p.frag_hidden_lo[l], p.bias_hidden[l], w, lane);
     __syncthreads();
     decode_tail16(X, p, t, qbase);
 }
@@ -874,13 +925,13 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
 // ---- host side ----------------------------------------------------------------------------------
 size_t fragment_bf16_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 64 * 16; }
 
-int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream_t s) {
+int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual) {
     const int n_tiles = (N + 31) / 32, nks = (K + 15) / 16;
     const long total = (long)n_tiles * nks * 64;
     int grid = (int)((total + 255) / 256);
     ProfScope prof("pack_fragments_bf16", s);
     hipLaunchKernelGGL(pack_fragments_bf16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, W, ld, N, K,
-                       reinterpret_cast<uint4*>(P), n_tiles, nks);
+                       reinterpret_cast<uint4*>(P), n_tiles, nks, residual);
     return launch_status("pack_fragments_bf16");
 }
 
@@ -932,5 +983,10 @@ extern "C" size_t ciaosr_fragment_bf16_bytes(int N, int K) { return fragment_bf1
 
 extern "C" int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return pack_fragments_bf16(W, ld, N, K, out, (hipStream_t)stream);
+    return pack_fragments_bf16(W, ld, N, K, out, (hipStream_t)stream, 0);
+}
+
+extern "C" int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* out, void* stream) {
+    CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
+    return pack_fragments_bf16(W, ld, N, K, out, (hipStream_t)stream, 1);
 }

@@ -95,9 +95,11 @@ struct FusedChain {
     const float* tail;
     int ld_tail;
     const void* frag_hidden[CIAOSR_MAX_LAYERS];
+    const void* frag_hidden_lo[CIAOSR_MAX_LAYERS];   // bf16 kernels: low half of the hi + lo weight pair, or null
     const float* bias_hidden[CIAOSR_MAX_LAYERS];
     int n_hidden;
     const void* frag_out;
+    const void* frag_out_lo;
     const float* bias_out;
     int n_out;
 };
@@ -122,9 +124,11 @@ struct FusedKVP {
 struct FusedQP {
     const float* Z; int ldz, Dv;
     const void* frag_in;
+    const void* frag_in_lo;                          // bf16 kernel: low half of the hi + lo weight pair, or null
     const float* bias_in;
     int nj_in;
     const void* frag_hidden[CIAOSR_MAX_LAYERS];
+    const void* frag_hidden_lo[CIAOSR_MAX_LAYERS];
     const float* bias_hidden[CIAOSR_MAX_LAYERS];
     int n_hidden;
     const float* w_last; int ld_last;

@@ -22,6 +22,7 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False):
     st = _lib.ConvT()
     st.weight, st.bias, st.cin, st.cout, st.ksize = w.data_ptr(), b.data_ptr(), ci, co, kh
     st.frag16 = None
+    st.frag16_lo = None
     st.frag = None
     if frag16:
         # bf16 MFMA fragments of the [cout][k*k*cin] matrix for the bf16 trunk mode (dense_bf16.hip)
@@ -30,6 +31,10 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False):
         _lib.call('ciaosr_pack_fragments_bf16', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f16), hip_ops.stream_ptr())
         keep.append(f16)
         st.frag16 = f16.data_ptr()
+        lo16 = torch.empty_like(f16)                # low half of the hi + lo weight pair
+        _lib.call('ciaosr_pack_fragments_bf16_lo', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(lo16), hip_ops.stream_ptr())
+        keep.append(lo16)
+        st.frag16_lo = lo16.data_ptr()
         # exact-fp32 MFMA fragments for the halo-resident fp32 kernel of big maps (dense_f32.hip)
         f32 = torch.empty(_lib.load().ciaosr_fragment_floats(n_, k_), dtype=torch.float32, device=w.device)
         _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f32), hip_ops.stream_ptr())

@@ -59,6 +59,7 @@ class PackedHead:
             st.bias[i] = b.data_ptr()
             st.frag[i] = None
             st.frag16[i] = None
+            st.frag16_lo[i] = None
             if i in frag_layers and w.shape[1] % 8 == 0:
                 # MFMA fragment order for the fused kernels, packed on the device by the library
                 n, k = w.shape
@@ -72,6 +73,11 @@ class PackedHead:
                           hip_ops.stream_ptr())
                 keep.append(f16)
                 st.frag16[i] = f16.data_ptr()
+                lo16 = torch.empty_like(f16)            # bf16(w - bf16(w)): low half of the hi + lo weight pair
+                _lib.call('ciaosr_pack_fragments_bf16_lo', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(lo16),
+                          hip_ops.stream_ptr())
+                keep.append(lo16)
+                st.frag16_lo[i] = lo16.data_ptr()
         st.in_dim = lin[0].weight.shape[1]
         return st, keep
 

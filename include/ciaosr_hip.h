@@ -72,7 +72,11 @@ typedef struct ciaosr_options {
                              * < 0 = never */
     int kv_rows;            /* fp32 fused head: (query, sample) rows per workgroup, 32 (default) or 64 */
     int decode_rows;        /* fp32 fused decode: queries per workgroup, 32 (default) or 64 */
-    int reserved[2];        /* must be 0 */
+    int bf16_single;        /* _bf16 entries: 0 (default) = every weight enters the MFMA as a bf16 PAIR hi + lo (hi = bf16(w),
+                             * lo = bf16(w - hi): 16 mantissa bits, two MFMAs per product); 1 = hi only (one MFMA, 8 bits).
+                             * Rounding WEIGHTS to 8 bits is a fixed perturbation whose response is spatially coherent and
+                             * fails the 0.01 dB PSNR gate on smooth features; activations stay single bf16 */
+    int reserved[1];        /* must be 0 */
 } ciaosr_options_t;
 
 /* ---- layout plumbing -------------------------------------------------------------------- */
@@ -147,6 +151,9 @@ typedef struct ciaosr_mlp {
     const float* frag[CIAOSR_MAX_LAYERS];
     /* optional: the same layers packed as bf16 MFMA fragments by ciaosr_pack_fragments_bf16 (precision mode 1) */
     const void* frag16[CIAOSR_MAX_LAYERS];
+    /* optional: the rounding residual w - bf16(w) of the same layers, packed by ciaosr_pack_fragments_bf16_lo (NULL = the
+     * bf16 entries run with single-bf16 weights) */
+    const void* frag16_lo[CIAOSR_MAX_LAYERS];
 } ciaosr_mlp_t;
 
 /* MFMA fragment packing of a Linear weight W[N][ld] (K valid columns): out[nt][j][lane][4] with
@@ -158,6 +165,8 @@ int ciaosr_pack_fragments_f32(const float* W, int ld, int N, int K, float* out, 
  * W[32nt+i][16ks+8g .. 16ks+8g+7] rounded to nearest-even bf16; zero padded. */
 size_t ciaosr_fragment_bf16_bytes(int N, int K);
 int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream);
+/* same layout, holding bf16(W - bf16(W)): the low half of the hi + lo weight pair */
+int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* out, void* stream);
 
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
@@ -244,6 +253,7 @@ typedef struct ciaosr_conv {
     int cin, cout, ksize;
     const void* frag16;  /* optional: ciaosr_pack_fragments_bf16(weight, ld = k*k*cin, N = cout, K = k*k*cin); used by
                           * ciaosr_rdn_forward_bf16 for the dense layers, NULL otherwise */
+    const void* frag16_lo; /* optional: ciaosr_pack_fragments_bf16_lo of the same matrix (hi + lo weight pair of the bf16 trunk) */
     const float* frag;   /* optional: ciaosr_pack_fragments_f32 of the same matrix; lets ciaosr_rdn_forward_f32 run the
                           * dense layers of maps with >= 128 tiles of 12x12 pixels through the halo-resident kernel, and any
                           * 3x3 trunk convolution of a map of <= 18432 pixels through the one-launch small-map kernel */

@@ -284,6 +284,31 @@ def test_head_full_width_vs_golden(dev, name, C, hw):
     assert err64 < 2.5e-4, err64
 
 
+@pytest.mark.parametrize('name,C,hw', [('head_c64_x4', 64, 48), ('head_c180_x3p3', 180, 24)])
+def test_head_bf16_mode_full_width_vs_reference(dev, name, C, hw):
+    """The bf16 head kernels at both encoder widths of the configs -- C = 64 (RDN/EDSR: 576/580/644/640) and
+    C = 180 (SwinIR, config C5: 1620/1624/1804/1800, ragged 8-column last chunk of the decode input layer) --
+    against the REFERENCE's head output on the ill-conditioned sqrt(6)-gain fixtures (logit std ~40)."""
+    import math
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    fx = load_golden(name)
+    g = _my_generator(C, (256,) * 4, seeded_head(C, int(fx['weight_seed'])), dev, eval_bsize=30000)
+    feat = randn((1, C, hw, hw), fx['feat_seed']).to(dev)
+    ht, wt = [int(v) for v in fx['target']]
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    with hip_ops.profile():
+        out = g.batched_predict([feat], coord, cell, options='bf16').cpu()
+    prof = hip_ops.profile.results()
+    assert 'head_kv_fused_bf16' in prof and 'head_decode_fused_bf16' in prof, sorted(prof)
+    ref = _t(fx['out'])
+    err = (out[0] - ref).abs()
+    scale = ref.abs().max().item()
+    psnr = 10 * math.log10(scale ** 2 / max((err ** 2).mean().item(), 1e-20))
+    print(f'bf16 head C={C}: max|d| {err.max().item():.3e} (out scale {scale:.3f}), PSNR vs reference {psnr:.1f} dB')
+    assert psnr > 38.0 and err.max().item() < 0.35 * scale
+
+
 def test_fused_and_staged_head_paths_agree(dev):
     """The fused kernels (head_kv_fused / head_decode_fused) against the staged per-layer path on the
     same inputs (both through ciaosr_head_forward_f32), including a ragged last workgroup."""
@@ -442,11 +467,13 @@ def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw):
     assert (generic - want).abs().max().item() < 2e-4 * max(scale, 1.0)
 
 
-def _rdn_trunk_bf16_emulation(x, P, nb, nl):
-    """torch-CPU RDN trunk with the bf16 mode's rounding points: dense-layer inputs and weights rounded to bf16
-    (products are then exact in fp32), fp32 accumulation, everything else fp32."""
+def _rdn_trunk_bf16_emulation(x, P, nb, nl, single=False):
+    """torch-CPU RDN trunk with the bf16 mode's rounding points: dense-layer inputs rounded to bf16, weights as the
+    bf16 pair hi + lo (or hi alone when `single`); products are then exact in fp32; fp32 accumulation, everything
+    else fp32."""
     F = torch.nn.functional
     bf = lambda t: t.bfloat16().float()
+    bw = bf if single else (lambda t: bf(t) + bf(t - bf(t)))
     sfe1 = F.conv2d(x, P['sfe1.weight'], P['sfe1.bias'], padding=1)
     cur = F.conv2d(sfe1, P['sfe2.weight'], P['sfe2.bias'], padding=1)
     outs = []
@@ -454,15 +481,16 @@ def _rdn_trunk_bf16_emulation(x, P, nb, nl):
         feats = [cur]
         for l in range(nl):
             inp = torch.cat([bf(f) for f in feats], 1)
-            feats.append(F.relu(F.conv2d(inp, bf(P[f'rdbs.{b}.layers.{l}.conv.weight']), P[f'rdbs.{b}.layers.{l}.conv.bias'], padding=1)))
+            feats.append(F.relu(F.conv2d(inp, bw(P[f'rdbs.{b}.layers.{l}.conv.weight']), P[f'rdbs.{b}.layers.{l}.conv.bias'], padding=1)))
         cur = cur + F.conv2d(torch.cat(feats, 1), P[f'rdbs.{b}.lff.weight'], P[f'rdbs.{b}.lff.bias'])
         outs.append(cur)
     g = F.conv2d(torch.cat(outs, 1), P['gff.0.weight'], P['gff.0.bias'])
     return F.conv2d(g, P['gff.1.weight'], P['gff.1.bias'], padding=1) + sfe1
 
 
+@pytest.mark.parametrize('single', [0, 1])
 @pytest.mark.parametrize('hw,blocks,layers,tol', [((37, 53), 1, 1, 1e-4), ((29, 40), 2, 3, 5e-4), ((48, 60), 16, 8, 6e-3)])
-def test_rdn_trunk_bf16_dense_layers(dev, hw, blocks, layers, tol):
+def test_rdn_trunk_bf16_dense_layers(dev, hw, blocks, layers, tol, single):
     """ciaosr_rdn_forward_bf16 (dense layers on the bf16 MFMA, dense_bf16.hip; ragged 12x12 tiles) against a torch
     emulation with the same rounding points, and its distance from the fp32 trunk.  The two sides round nearly
     equal fp32 activations to bf16, and the rare value that lands on the other side of a rounding boundary (1 bf16
@@ -477,10 +505,10 @@ def test_rdn_trunk_bf16_dense_layers(dev, hw, blocks, layers, tol):
     x = randn((1, 3) + hw, 78) * 0.3
     gen = model.generator.to(dev)
     nb, nl = len(gen.rdbs), len(gen.rdbs[0].layers)
-    want = _rdn_trunk_bf16_emulation(x, params, nb, nl)
+    want = _rdn_trunk_bf16_emulation(x, params, nb, nl, single=bool(single))
     f32 = orc.encoder_features(x, params)
     with hip_ops.profile():
-        got = gen.gen_feature(x.to(dev), hip_ops.Options('bf16', dense_min_tiles=1))[0].cpu()
+        got = gen.gen_feature(x.to(dev), hip_ops.Options('bf16', dense_min_tiles=1, bf16_single=single))[0].cpu()
     assert 'enc_dense_bf16' in hip_ops.profile.results(), 'bf16 dense kernel did not run'
     scale = want.abs().max().item()
     err, dist = (got - want).abs().max().item(), (got - f32).abs().max().item()
@@ -564,20 +592,21 @@ def _tile192_checks(out, fx, tol):
     return errs
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16-single'])
 def test_e2e_full_c3_tile_vs_reference(dev, precision):
     """One full C3 tile: 192x192 LR -> 768x768 through CiaoSR.forward_test (clip_test with one tile; RDN trunk on the
     halo-resident dense kernels, cs_attn on the composed tail, 589 824 queries = 20 reference eval_bsize chunks) against
     the reference's own output (tests/golden/e2e_rdn_x4_tile192.npz: every 4th pixel + an 8-pixel frame + the
     reference's PSNR against the synthetic GT).
       fp32: |delta| <= 1e-3 and |PSNR(build, GT) - PSNR(ref, GT)| <= 0.01 dB   (north star)
-      bf16 mode (opt-in extension): measured against the SAME reference vector and the same PSNR-delta-vs-GT metric.
-      It does NOT meet the 0.01 dB north-star gate on this fixture: 0.042 dB (rms |d| 1.9e-3).  Cause, reproduced
-      bit-for-bit in a CPU emulation of the rounding points: rounding the MLP WEIGHTS to bf16 is a fixed
-      perturbation whose response on smooth RDN features is spatially coherent -- 62 % of it is a 0.42 % change of
-      the network term's amplitude -- so it does not average out over pixels the way activation rounding does
-      (activation rounding alone: 0.0004 dB).  The bound asserted here is what the mode delivers, with margin; the
-      fp32 path is the one that carries the parity claim."""
+      bf16 mode (opt-in extension; bf16 MFMA inputs, every weight as a bf16 hi + lo pair): the same
+      PSNR-delta-vs-GT gate, <= 0.01 dB (measured 0.00014 dB), plus a loose max bound (isolated attention flips).
+      bf16-single (weights as one bf16, `Options(bf16_single=1)`): does NOT meet the gate -- 0.042 dB.  Cause,
+      reproduced in a CPU emulation of the rounding points: rounding the WEIGHTS to 8 bits is a fixed
+      perturbation whose response on smooth RDN features is spatially coherent (62 % of it is a 0.42 % change of the
+      network term's amplitude), so it does not average out over pixels the way activation rounding does (activation
+      rounding alone: 0.0004 dB).  Kept as a measured, documented fast variant; the bound asserted for it is what it
+      delivers."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.metrics import psnr_tensors
@@ -587,8 +616,10 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     assert sha == str(fx['sha'])
     model = model.to(dev)
     lq, gt = synthetic_pair(192, 192, 4)
+    opt = {'fp32': hip_ops.Options('fp32'), 'bf16': hip_ops.Options('bf16'),
+           'bf16-single': hip_ops.Options('bf16', bf16_single=1)}[precision]
     with hip_ops.profile():
-        out = model.restore(lq.to(dev), options=precision).cpu()
+        out = model.restore(lq.to(dev), options=opt).cpu()
     prof = hip_ops.profile.results()
     if precision == 'fp32':
         for tag in ('enc_dense_gather', 'csa_attn_v_edge', 'head_logit_table'):
@@ -607,17 +638,19 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         assert d_psnr <= 0.01, d_psnr
         assert max(errs.values()) < NORTH_STAR_TOL, errs
         assert mean_err < 1e-5
-    else:
-        assert d_psnr <= 0.08, d_psnr            # measured 0.042 dB: above the 0.01 dB north-star gate (see docstring)
+    elif precision == 'bf16':
+        assert d_psnr <= 0.01, d_psnr            # the north-star gate; measured 0.00014 dB
         assert max(errs.values()) < 0.15, errs
+    else:
+        assert 0.01 < d_psnr <= 0.08, d_psnr     # measured 0.042 dB: single-bf16 weights do NOT meet the gate (see docstring)
+        assert max(errs.values()) < 0.2, errs
 
 
 @pytest.mark.parametrize('tag,kind,scale', [('e2e_rdn_x4_48', 'rdn', 4)])
 def test_e2e_bf16_mode_psnr_delta_vs_gt_on_reference_golden(dev, tag, kind, scale):
-    """The north-star metric for the bf16 mode on the 48x48 reference vector: |PSNR(bf16 build, GT) - PSNR(reference, GT)|.
-    Default routing at this size (bf16 head, fp32 trunk and cs_attn): 0.006 dB, inside the 0.01 dB gate.  With every
-    bf16 kernel forced to engage (per-call options: halo-resident dense layers from 1 tile, composed cs_attn tail from
-    1 pixel -- a route the library never takes by itself on a 48x48 map): 0.011 dB, just outside it; asserted at 0.02."""
+    """The north-star gate for the bf16 mode on the 48x48 reference vector: |PSNR(bf16 build, GT) - PSNR(reference, GT)|
+    <= 0.01 dB, with the default routing at this size (bf16 head, fp32 trunk and cs_attn) AND with every bf16 kernel
+    forced to engage (per-call options: halo-resident dense layers from 1 tile, composed cs_attn tail from 1 pixel)."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.metrics import psnr_tensors
@@ -629,7 +662,7 @@ def test_e2e_bf16_mode_psnr_delta_vs_gt_on_reference_golden(dev, tag, kind, scal
     _, gt = synthetic_pair(48, 48, scale)
     for opt, tags, gate in ((hip_ops.Options('bf16'), ('head_kv_fused_bf16', 'head_decode_fused_bf16'), 0.01),
                             (hip_ops.Options('bf16', dense_min_tiles=1, csa_composed_min=1),
-                             ('enc_dense_bf16', 'csa_attn_v_bf16', 'head_kv_fused_bf16', 'head_decode_fused_bf16'), 0.02)):
+                             ('enc_dense_bf16', 'csa_attn_v_bf16', 'head_kv_fused_bf16', 'head_decode_fused_bf16'), 0.01)):
         with hip_ops.profile():
             out = model.restore(_t(fx['lq']).to(dev), options=opt).cpu()
         prof = hip_ops.profile.results()

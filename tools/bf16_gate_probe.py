@@ -31,9 +31,9 @@ model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
 seeded_init_(model, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=SQRT6)
 model = model.to(dev)
 lq, gt = synthetic_pair(192, 192, 4)
-for name, opt in (('tile192 fp32', O('fp32')), ('tile192 bf16', O('bf16')), ('tile192 bf16 head v1', O('bf16', kv_rows=1, decode_rows=1)),
-                  ('tile192 bf16 trunk fp32', O('bf16', dense_min_tiles=-1)), ('tile192 bf16 csa fp32-route', O('bf16', csa_composed_min=-1)),
-                  ('tile192 bf16 head only', O('bf16', dense_min_tiles=-1, csa_composed_min=-1))):
+for name, opt in (('tile192 fp32', O('fp32')), ('tile192 bf16 (hi+lo weights)', O('bf16')), ('tile192 bf16 single', O('bf16', bf16_single=1)),
+                  ('tile192 bf16 pairs, trunk fp32', O('bf16', dense_min_tiles=-1)),
+                  ('tile192 bf16 pairs, head only', O('bf16', dense_min_tiles=-1, csa_composed_min=-1))):
     out = model.restore(lq.to(dev), options=opt).cpu()
     d = out[..., ::4, ::4] - _t(fx['out_s4'])
     print(f'{name:40s} (gain {float(fx["gain"])}) max|d| {d.abs().max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e} '
