@@ -10,7 +10,11 @@
 // rate).  The k-tile is 32 deep (not 64) so that the double-buffered stages take 60 KB and TWO workgroups share a CU:
 // with one wave per SIMD (round 1: 108 KB, one workgroup per CU) every barrier, LDS store and late global load stalled
 // the matrix pipe directly (SQ: 45 % of wave cycles in issue stalls, MFMA pipe 27 % busy); with two, one workgroup's
-// staging runs under the other's MFMAs.  Rows are padded to 80 B in LDS (conflict-free ds_read_b128).
+// staging runs under the other's MFMAs.  LDS rows are 64 B, unpadded, with the 16-byte chunk index XOR-swizzled by
+// (row >> 2) & 3: the 16 rows a ds_read_b128 lane group touches ({0-3,12-15,20-27} / {4-11,16-19,28-31}) land on 16
+// distinct bank quads, and so do the 2 rows x 4 chunks of every 8-lane ds_write_b128 group (the 80-B padded rows of the
+// first GK = 32 version read conflict-free but wrapped one write per group: SQ_LDS_BANK_CONFLICT 33 % of LDS cycles).
+// Global loads run TWO k-tiles ahead in two register sets (one k-tile is only ~512 MFMA cycles: less than an HBM round trip).
 // Swapped MFMA operands (B rows = A operand, A rows = B operand): a lane owns one output row and 4 consecutive
 // columns per accumulator quad, so the epilogue stores 16 B (fp32) / 8 B (bf16) pieces.
 // Out-of-range rows / k-chunks are buffer loads with an out-of-range offset (return 0, no branches).
@@ -26,11 +30,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GM = 256, GN = 128, GK = 32;
-constexpr int GRS = GK * 2 + 16;                          // LDS row stride in bytes (32 bf16 + 16 B pad = 80)
+constexpr int GRS = GK * 2;                               // LDS row stride in bytes (32 bf16, chunk-swizzled, no pad)
 constexpr int GCH = GK / 8;                               // 16-byte chunks per row
 constexpr int GSA = GM * GCH / 256, GSB = GN * GCH / 256; // staging chunks per thread (A: 4, B: 2)
 constexpr int GA_T = GM * GRS, GB_T = GN * GRS;           // bytes per stage
-constexpr size_t kGemm16Lds = 2 * (size_t)(GA_T + GB_T);  // 61 440 B: two workgroups per CU
+constexpr size_t kGemm16Lds = 2 * (size_t)(GA_T + GB_T);  // 49 152 B: two workgroups per CU (register-limited)
 constexpr unsigned kOob16 = 0xFFFFFFF0u;
 
 struct Gemm16P {
@@ -80,22 +84,23 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
         const int gn = n0 + row0 + RS * s;
         b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u : kOob16;
     }
-    i32x4 ra[GSA], rb[GSB];
-    auto load_stage = [&](int kt) {
+    i32x4 ra[2][GSA], rb[2][GSB];            // two k-tiles in flight
+    const int swz = (row0 >> 2) & 3;              // RS is a multiple of 16: the swizzle key of rows row0 + RS s is that of row0
+    auto load_stage = [&](int kt, int set) {
         const int k0 = kt * GK;
         const bool kok = k0 + part * 8 < p.K;     // K % 8 == 0: a chunk is entirely in or out
 #pragma unroll
         for (int s = 0; s < GSA; ++s)
-            ra[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (kok && a_off[s] != kOob16) ? (int)(a_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+            ra[set][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (kok && a_off[s] != kOob16) ? (int)(a_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
 #pragma unroll
         for (int s = 0; s < GSB; ++s)
-            rb[s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (kok && b_off[s] != kOob16) ? (int)(b_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+            rb[set][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (kok && b_off[s] != kOob16) ? (int)(b_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, int set) {
 #pragma unroll
-        for (int s = 0; s < GSA; ++s) *reinterpret_cast<i32x4*>(As + buf * GA_T + (row0 + RS * s) * GRS + part * 16) = ra[s];
+        for (int s = 0; s < GSA; ++s) *reinterpret_cast<i32x4*>(As + buf * GA_T + (row0 + RS * s) * GRS + ((part ^ swz) * 16)) = ra[set][s];
 #pragma unroll
-        for (int s = 0; s < GSB; ++s) *reinterpret_cast<i32x4*>(Bs + buf * GB_T + (row0 + RS * s) * GRS + part * 16) = rb[s];
+        for (int s = 0; s < GSB; ++s) *reinterpret_cast<i32x4*>(Bs + buf * GB_T + (row0 + RS * s) * GRS + ((part ^ swz) * 16)) = rb[set][s];
     };
 
     f32x16 acc[4][2];
@@ -107,30 +112,42 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
             for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
 
     const int nk = (p.K + GK - 1) / GK;
-    load_stage(0);
-    store_stage(0);
+    load_stage(0, 0);
+    if (nk > 1) load_stage(1, 1);
+    store_stage(0, 0);                            // waits for k-tile 0 only (vmcnt retires in order)
     __syncthreads();
+    const int lswz = (li >> 2) & 3;               // swizzle key of the lane's rows (row = multiple of 32 + li)
+    const unsigned char* a_base = As + (128 * wm + li) * GRS;
+    const unsigned char* b_base = Bs + (64 * wn + li) * GRS;
+    // k-tile kt is computed from LDS buffer kt & 1 while k-tile kt + 1 sits in register set (kt + 1) & 1 (loaded one
+    // iteration ago) and k-tile kt + 2 is requested into set kt & 1; kt + 1 goes to LDS at the END of the iteration
 #pragma unroll 1
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_stage(kt + 1);
-        const unsigned char* a = As + cur * GA_T + (128 * wm + li) * GRS + lh * 16;
-        const unsigned char* b = Bs + cur * GB_T + (64 * wn + li) * GRS + lh * 16;
+    for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
-        for (int ks = 0; ks < GK / 16; ++ks) {
-            bf16x8 fb[2], fa[4];
+        for (int half = 0; half < 2; ++half) {    // unrolled by 2 so that the register-set indices are compile-time
+            const int k = kt + half;
+            if (k < nk) {
+                if (k + 2 < nk) load_stage(k + 2, half);
+                const unsigned char* a = a_base + half * GA_T;
+                const unsigned char* b = b_base + half * GB_T;
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + ks * 32));
+                for (int ks = 0; ks < GK / 16; ++ks) {
+                    const int co = ((2 * ks + lh) ^ lswz) * 16;
+                    bf16x8 fb[2], fa[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + mt * 32 * GRS + ks * 32));
+                    for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + co));
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+                    for (int mt = 0; mt < 4; ++mt) fa[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + mt * 32 * GRS + co));
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                }
+                if (k + 1 < nk) store_stage(half ^ 1, half ^ 1);       // k-tile k + 1: requested one iteration ago
+                __syncthreads();
+            }
         }
-        if (kt + 1 < nk) store_stage(cur ^ 1);
-        __syncthreads();
     }
 
     // epilogue: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li, columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
