@@ -112,62 +112,6 @@ __device__ __forceinline__ void zero_acc16(f32x16 (&acc)[HMI][NT]) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 }
 
-// X[m][n] <- bf16(relu(acc + bias[n])) for the wave's 64 columns
-__device__ __forceinline__ void store_relu_tile16(unsigned short* X, const f32x16 (&acc)[HMI][2], const float* __restrict__ bias,
-                                                  int w, int li, int lh) {
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
-            const float4 b = *reinterpret_cast<const float4*>(bias + col);
-#pragma unroll
-            for (int mi = 0; mi < HMI; ++mi) {
-                uint2 o;
-                o.x = pack2(fmaxf(acc[mi][ni][4 * g] + b.x, 0.f), fmaxf(acc[mi][ni][4 * g + 1] + b.y, 0.f));
-                o.y = pack2(fmaxf(acc[mi][ni][4 * g + 2] + b.z, 0.f), fmaxf(acc[mi][ni][4 * g + 3] + b.w, 0.f));
-                *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
-            }
-        }
-}
-
-__device__ __forceinline__ void hidden_layer16(unsigned short* X, const void* __restrict__ frag, const float* __restrict__ bias,
-                                               int w, int lane) {
-    const int li = lane & 31, lh = lane >> 5;
-    f32x16 acc[HMI][2];
-    zero_acc16<2>(acc);
-    mma_pass16<2>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(frag) + (size_t)(2 * w) * HKS * 64 + lane, HKS,
-                  (long)HKS * 64, acc);
-    __syncthreads();
-    store_relu_tile16(X, acc, bias, w, li, lh);
-    __syncthreads();
-}
-
-__device__ __forceinline__ void build_rows16(unsigned short* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
-    const int n4 = t & 63;
-    float4 tw[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
-    // 32 rows per thread in batches of 8 table gathers, each batch fully in flight before it is used
-#pragma unroll
-    for (int b = 0; b < HBM_ / 32; ++b) {
-        float4 tv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) tv[i] = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[(t >> 6) + 4 * (8 * b + i)] * HH)[n4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = (t >> 6) + 4 * (8 * b + i);
-            const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
-            uint2 o;
-            o.x = pack2(fmaxf(tv[i].x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f),
-                        fmaxf(tv[i].y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f));
-            o.y = pack2(fmaxf(tv[i].z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f),
-                        fmaxf(tv[i].w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f));
-            *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
-        }
-    }
-}
-
 // last Linear (256 -> 3) in fp32 on the bf16 activations + bilinear/border residual (net:107-108,221)
 __device__ __forceinline__ void decode_tail16(const unsigned short* X, const FusedQP& p, int t, int qbase) {
     const int row = t >> 1, part = t & 1;
@@ -221,254 +165,16 @@ __device__ __forceinline__ void decode_tail16(const unsigned short* X, const Fus
     }
 }
 
-__global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_v1_kernel(FusedKVP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);                 // [128][264] bf16
-    float* s_t4 = reinterpret_cast<float*>(smem_raw + (size_t)HBM_ * HLD * 2);        // [128][4]
-    float* s_part = s_t4 + HBM_ * 4;                                                  // [4][128]
-    float* s_attn = s_part + 4 * HBM_;                                                // [128]
-    int* s_kpix = reinterpret_cast<int*>(s_attn + HBM_);                              // [128]
-    int* s_qpix = s_kpix + HBM_;                                                      // [32]
-    int* s_goff = s_qpix + HBM_ / 4;                                                  // [128]
-
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qbase = blockIdx.x * (HBM_ / 4);
-
-    int bad = 0;
-    if (t < HBM_) {
-        const int ql = qbase + (t >> 2), j = t & 3;
-        int kpix = 0, goff = -1;
-        float t4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (ql < p.nq) {
-            const long q = p.q0 + ql;
-            const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
-            const long c0 = p.chunk > 0 ? (q / p.chunk) * p.chunk : 0;
-            const KeySample s = key_sample(cy, cx, p.cell[2 * c0], p.cell[2 * c0 + 1], p.H, p.W, j, 2);
-            kpix = s.ky * p.W + s.kx;
-            t4[0] = s.rel_y; t4[1] = s.rel_x;
-            t4[2] = mul_rn(p.cell[2 * q], (float)p.H);
-            t4[3] = mul_rn(p.cell[2 * q + 1], (float)p.W);
-            const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
-            const bool qin = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            if (j == 0) s_qpix[t >> 2] = qin ? iy * p.W + ix : -1;
-            if (qin) {
-                const int oy = s.ky - iy, ox = s.kx - ix;
-                if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) goff = (iy * p.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
-                else bad = 1;
-            }
-        } else if (j == 0) {
-            s_qpix[t >> 2] = -1;
-        }
-        s_kpix[t] = kpix;
-        s_goff[t] = goff;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_t4[4 * t + e] = t4[e];
-    }
-    const bool table = p.G != nullptr && !__syncthreads_or(bad);
-    if (p.G == nullptr) __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
-
-    // ================= phi_k =====================================================================
-    build_rows16(X, p.k, s_kpix, s_t4, t);
-    __syncthreads();
-    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
-    if (table) {
-        // logit = h4 . G[query pixel, key offset] + c (fp32 table, bf16 activations): 2 threads per row
-        const int row = t >> 1, part = t & 1;
-        const int go = s_goff[row];
-        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.G), 0, p.g_bytes, 0x00020000);
-        const unsigned gbase = go >= 0 ? (unsigned)go * (unsigned)p.ldg * 4u : kOobH;
-        float a = (go >= 0 && part == 0) ? p.G[(size_t)go * p.ldg + 256] : 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 32; ++i) {
-            const int n = 8 * i + 4 * part;
-            const float4 gv = hload4(rs_g, gbase == kOobH ? kOobH : gbase + (unsigned)n * 4u);
-            const uint2 xb = *reinterpret_cast<const uint2*>(X + row * HLD + n);
-            a += __uint_as_float(xb.x << 16) * gv.x + __uint_as_float(xb.x & 0xFFFF0000u) * gv.y +
-                 __uint_as_float(xb.y << 16) * gv.z + __uint_as_float(xb.y & 0xFFFF0000u) * gv.w;
-        }
-        a += quad_xor1(a);
-        if (part == 0) {
-            s_part[row] = a;
-            s_part[HBM_ + row] = 0.f;
-            s_part[2 * HBM_ + row] = 0.f;
-            s_part[3 * HBM_ + row] = 0.f;
-        }
-    } else
-    {
-        float part[HMI];
-        unsigned koff[HMI], qoff[HMI];
-#pragma unroll
-        for (int mi = 0; mi < HMI; ++mi) {
-            part[mi] = 0.f;
-            const int m = 32 * mi + li;
-            koff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
-            const int qp = s_qpix[m >> 2];
-            qoff[mi] = qp >= 0 ? (unsigned)qp * (unsigned)p.ldu * 4u : kOobH;
-        }
-        const int n_units = (p.k.n_out + 31) >> 5;
-        const __amdgpu_buffer_rsrc_t rs_bk =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.k.bias_out), 0, (unsigned)p.k.n_out * 4u, 0x00020000);
-        for (int u = w; u < n_units; u += 4) {
-            f32x16 acc[HMI][1];
-            zero_acc16<1>(acc);
-            mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.k.frag_out) + (size_t)u * HKS * 64 + lane, HKS,
-                          0, acc);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * u + 8 * g + 4 * lh;
-                const unsigned doff = d0 < p.k.n_out ? (unsigned)d0 * 4u : kOobH;
-                const float4 bv = hload4(rs_bk, doff);
-                float4 kv[HMI], qv[HMI];
-#pragma unroll
-                for (int mi = 0; mi < HMI; ++mi) {
-                    kv[mi] = hload4(rs_u, doff == kOobH ? kOobH : koff[mi] + doff);
-                    qv[mi] = hload4(rs_u, (doff == kOobH || qoff[mi] == kOobH) ? kOobH : qoff[mi] + doff);
-                }
-#pragma unroll
-                for (int mi = 0; mi < HMI; ++mi)
-                    part[mi] += qv[mi].x * (kv[mi].x * (acc[mi][0][4 * g] + bv.x)) + qv[mi].y * (kv[mi].y * (acc[mi][0][4 * g + 1] + bv.y)) +
-                                qv[mi].z * (kv[mi].z * (acc[mi][0][4 * g + 2] + bv.z)) + qv[mi].w * (kv[mi].w * (acc[mi][0][4 * g + 3] + bv.w));
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < HMI; ++mi) {
-            part[mi] += __shfl_xor(part[mi], 32, 64);
-            if (lh == 0) s_part[w * HBM_ + 32 * mi + li] = part[mi];
-        }
-    }
-    __syncthreads();
-    if (t < HBM_ / 4) {
-        float lg[4], m = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = 4 * t + j;
-            lg[j] = (s_part[row] + s_part[HBM_ + row] + s_part[2 * HBM_ + row] + s_part[3 * HBM_ + row]) / p.softmax_scale;
-            m = fmaxf(m, lg[j]);
-        }
-        float den = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { lg[j] = expf(lg[j] - m); den += lg[j]; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s_attn[4 * t + j] = lg[j] / den;
-    }
-
-    // ================= phi_v =====================================================================
-    build_rows16(X, p.v, s_kpix, s_t4, t);
-    __syncthreads();
-    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer16(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
-    {
-        const int n_units = (p.v.n_out + 31) >> 5;
-        const __amdgpu_buffer_rsrc_t rs_bv =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.v.bias_out), 0, (unsigned)p.v.n_out * 4u, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_z =
-            __builtin_amdgcn_make_buffer_rsrc(p.Z, 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
-        unsigned voff[HMI], zoff[HMI];
-        float av[HMI];
-        const int jsel = li & 3;
-#pragma unroll
-        for (int mi = 0; mi < HMI; ++mi) {
-            const int m = 32 * mi + li;
-            voff[mi] = (unsigned)s_kpix[m] * (unsigned)p.ldu * 4u;
-            av[mi] = s_attn[m];
-            const int ql = qbase + (m >> 2);
-            zoff[mi] = ql < p.nq ? (unsigned)ql * (unsigned)p.ldz * 4u : kOobH;
-        }
-        for (int u = w; u < n_units; u += 4) {
-            f32x16 acc[HMI][1];
-            zero_acc16<1>(acc);
-            mma_pass16<1>(X + li * HLD + 8 * lh, reinterpret_cast<const uint4*>(p.v.frag_out) + (size_t)u * HKS * 64 + lane, HKS,
-                          0, acc);
-            float4 zsel[HMI];
-#pragma unroll
-            for (int mi = 0; mi < HMI; ++mi) zsel[mi] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * u + 8 * g + 4 * lh;
-                const unsigned doff = d0 < p.v.n_out ? (unsigned)d0 * 4u : kOobH;
-                const float4 bv = hload4(rs_bv, doff);
-                float4 vv[HMI];
-#pragma unroll
-                for (int mi = 0; mi < HMI; ++mi) vv[mi] = hload4(rs_u, doff == kOobH ? kOobH : voff[mi] + doff);
-#pragma unroll
-                for (int mi = 0; mi < HMI; ++mi) {
-                    float4 z;
-                    z.x = av[mi] * (vv[mi].x * (acc[mi][0][4 * g] + bv.x));
-                    z.y = av[mi] * (vv[mi].y * (acc[mi][0][4 * g + 1] + bv.y));
-                    z.z = av[mi] * (vv[mi].z * (acc[mi][0][4 * g + 2] + bv.z));
-                    z.w = av[mi] * (vv[mi].w * (acc[mi][0][4 * g + 3] + bv.w));
-                    z.x += quad_xor1(z.x); z.y += quad_xor1(z.y); z.z += quad_xor1(z.z); z.w += quad_xor1(z.w);
-                    z.x += quad_xor2(z.x); z.y += quad_xor2(z.y); z.z += quad_xor2(z.z); z.w += quad_xor2(z.w);
-                    if (jsel == g) zsel[mi] = z;
-                }
-            }
-            const int d0 = 32 * u + 8 * jsel + 4 * lh;
-#pragma unroll
-            for (int mi = 0; mi < HMI; ++mi)
-                hstore4(rs_z, (zoff[mi] == kOobH || d0 >= p.v.n_out) ? kOobH : zoff[mi] + (unsigned)d0 * 4u, zsel[mi]);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_v1_kernel(FusedQP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);   // [128][264] bf16
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    const int qbase = blockIdx.x * HBM_;
-
-    f32x16 acc[HMI][2];
-    zero_acc16<2>(acc);
-    const __amdgpu_buffer_rsrc_t rs_z =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
-    for (int k0 = 0; k0 < p.Dv; k0 += HH) {
-        const int kc = min(HH, p.Dv - k0);          // multiple of 8; the fragment stream is zero-padded to 16
-        if (k0 > 0) __syncthreads();
-        {   // 128 x 256 chunk of Z -> bf16 in LDS: 32 float4 per thread in batches of 8, every batch fully in flight
-            const int c4 = (t & 63) * 4;
-#pragma unroll
-            for (int b = 0; b < HBM_ / 32; ++b) {
-                float4 zv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int ql = qbase + (t >> 6) + 4 * (8 * b + i);
-                    zv[i] = hload4(rs_z, (ql < p.nq && c4 < kc) ? ((unsigned)ql * (unsigned)p.ldz + (unsigned)(k0 + c4)) * 4u : kOobH);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    uint2 o;
-                    o.x = pack2(zv[i].x, zv[i].y);
-                    o.y = pack2(zv[i].z, zv[i].w);
-                    *reinterpret_cast<uint2*>(X + ((t >> 6) + 4 * (8 * b + i)) * HLD + c4) = o;
-                }
-            }
-        }
-        __syncthreads();
-        mma_pass16<2>(X + li * HLD + 8 * lh,
-                      reinterpret_cast<const uint4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 4)) * 64 + lane,
-                      (kc + 15) >> 4, (long)p.nj_in * 64, acc);
-    }
-    __syncthreads();
-    store_relu_tile16(X, acc, p.bias_in, w, li, lh);
-    __syncthreads();
-    for (int l = 0; l < p.n_hidden; ++l) hidden_layer16(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
-
-    decode_tail16(X, p, t, qbase);
-}
-
 // =================================================================================================================
-// v2 kernels (default).  Same decomposition (128 rows = 32 queries x 4 key samples per workgroup, two workgroups per CU,
-// weights = A operand straight from L2, activations = B operand from LDS), re-cut after the SQ counters of v1 showed the
-// VALU -- not the matrix pipe -- as the busiest issue port (11 VALU instructions per MFMA, MFMA pipe 25 % busy):
+// The kernels.  128 rows = 32 queries x 4 key samples per workgroup, two workgroups per CU, weights = A operand straight
+// from L2, activations = B operand from LDS.  Round 2 re-cut them after the SQ counters of the round-1 version showed the
+// VALU -- not the matrix pipe -- as the busiest issue port (11-14 VALU instructions per MFMA, MFMA pipe 28 % busy):
 //   * rows are SAMPLE-major: row m = 32 j + q (q = query within the workgroup, j = key sample), so the four samples of a
 //     query sit in the four m-tiles of ONE lane and the attention-weighted sum z = sum_j a_j value_j * w_v,j is four FMAs on
 //     the lane's own accumulators -- no DPP quad reductions, no selects (384 -> 144 VALU per 32-column unit);
 //   * biases are the accumulators' initial values (the zeroing moves were there anyway): epilogues lose an add per element;
 //   * the k-loop is fully unrolled over compile-time buffer indices (3 weight stages, 2 activation stages): no register
-//     rotation moves (24 v_mov per k-step in v1); a sched_barrier per k-step keeps hipcc from hoisting every load to the top;
+//     rotation moves (24 v_mov per k-step in round 1); a sched_barrier per k-step keeps hipcc from hoisting every load to the top;
 //   * gathers are issued BEFORE the MFMA block that hides them: the 16 value-row float4 of a v-out unit before its 64
 //     MFMAs, the first two weight fragments of a layer before the barrier that precedes it, table / logit-table rows 16
 //     (not 8) at a time while no accumulator is live;
@@ -937,21 +643,15 @@ int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream
 
 constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32 + HBM_) * sizeof(int);
 
-// rows_per_wg == 1 selects the v1 kernels (fp32 Z, query-major rows): kept one round for A/B measurements
 int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
     CIAOSR_BIG_LDS(head_kv_fused_bf16_kernel, kFused16Lds);
-    CIAOSR_BIG_LDS(head_kv_fused_bf16_v1_kernel, kFused16Lds);
     ProfScope prof("head_kv_fused_bf16", s);
-    if (p.rows_per_wg == 1)
-        hipLaunchKernelGGL(head_kv_fused_bf16_v1_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
-    else
-        hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
+    hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
     return launch_status("head_kv_fused_bf16");
 }
 
 int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
     const size_t lds = (size_t)HBM_ * HLD * 2;
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_v1_kernel, lds);
     CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<0>, lds);
     CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<2>, lds);
     CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<4>, lds);
@@ -960,9 +660,7 @@ int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
     ProfScope prof("head_decode_fused_bf16", s);
     const dim3 grid(ceil_div(p.nq, HBM_));
     const int tail_steps = ((p.Dv & (HH - 1)) + 15) >> 4;      // k-steps of the ragged last chunk (C = 64: 8, C = 180: 1)
-    if (p.rows_per_wg == 1)
-        hipLaunchKernelGGL(head_decode_fused_bf16_v1_kernel, grid, dim3(256), lds, s, p);
-    else if (tail_steps == 0)
+    if (tail_steps == 0)
         hipLaunchKernelGGL(head_decode_fused_bf16_kernel<0>, grid, dim3(256), lds, s, p);
     else if (tail_steps <= 2)
         hipLaunchKernelGGL(head_decode_fused_bf16_kernel<2>, grid, dim3(256), lds, s, p);

@@ -110,21 +110,79 @@ class CiaoSR(BasicRestorer):
         cell = cell.unsqueeze(0).expand(b, -1, 2)
         return self.generator(patch, coord, cell, test_mode=True, options=self.options(options)), (th, tw)
 
+    def prepare(self, device=None):
+        """Pack every weight for the HIP kernels NOW, on the current stream (idempotent; re-packs only what changed).
+        The tile loop runs tiles on several streams: nothing a tile reads may be first built on another tile's stream."""
+        gen = self.generator
+        head = getattr(gen, '_head', None)
+        if head is not None:
+            head.struct()
+        enc = getattr(gen, '_encoder_hip', None)
+        if enc is not None and enc.supported():
+            enc.struct()
+        if getattr(gen, 'non_local_attn', False):
+            gen.cs_attn.packed()
+
     @torch.no_grad()
     def clip_test(self, img_lq, model=None, tile_fn=None, options=None):
-        """Tiled inference of one large image (ciaosr.py:218-258).  Returns [B, h*sf*w*sf, 3]."""
+        """Tiled inference of one large image (ciaosr.py:218-258).  Returns [B, h*sf*w*sf, 3].
+
+        Tiles are independent, so consecutive tiles run on `test_cfg.tile_streams` (default 2) HIP streams: the ramp,
+        first-load and drain phases of one tile's ~450 launches (8.5 us per dense layer, GEMM tails, the HBM-bound
+        softmax / patch kernels) fill with the other tile's workgroups instead of idling the chip.  Every tile is
+        computed exactly as on one stream (own scratch per stream) and the blend stays on the caller's stream in the
+        reference order (h outer, w inner), so the result is bitwise the single-stream result."""
         sf = self.test_cfg.get('scale', None)
         b, c, h, w = img_lq.shape
         tile, origins = tile_grid(h, w, self.test_cfg.get('tile', None), self.test_cfg.get('tile_overlap', None))
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
-        for (hi, wi) in origins:
-            out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf, options) if tile_fn is None else tile_fn(hi, wi)
+        n_streams = int(self.test_cfg.get('tile_streams', 2) or 1)
+        if tile_fn is not None or n_streams <= 1 or len(origins) < 2 or not img_lq.is_cuda:
+            for (hi, wi) in origins:
+                out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf, options) if tile_fn is None else tile_fn(hi, wi)
+                for bi in range(b):
+                    hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), hi * sf, wi * sf, th, tw)
+            return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
+        cur = torch.cuda.current_stream(img_lq.device)
+        self.prepare()
+        th = tw = round(tile * sf)
+        hip_ops.make_coord_cell(th, tw, img_lq.device)              # cached coordinates exist before any side stream reads them
+        streams = self._tile_streams(n_streams, img_lq.device)
+        for st in streams:
+            st.wait_stream(cur)                                      # the normalised image, E / Wt and the packed weights are ready
+        pending = []                                                 # (origin, out, event) in tile order
+
+        def blend_one():
+            (hi, wi), out, ev = pending.pop(0)
+            cur.wait_event(ev)
             for bi in range(b):
-                hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), hi * sf, wi * sf, th, tw)
+                hip_ops.tile_blend(E[bi], Wt[bi], out[bi], hi * sf, wi * sf, th, tw)
+
+        for i, (hi, wi) in enumerate(origins):
+            st = streams[i % n_streams]
+            with torch.cuda.stream(st):
+                out, _ = self.run_tile(img_lq, hi, wi, tile, sf, options)
+                out = out.contiguous()
+                ev = torch.cuda.Event()
+                ev.record(st)
+            out.record_stream(cur)                                   # consumed by the blend on the caller's stream
+            pending.append(((hi, wi), out, ev))
+            if len(pending) > n_streams:                             # keep at most one finished tile per stream waiting
+                blend_one()
+        while pending:
+            blend_one()
+        for st in streams:
+            cur.wait_stream(st)
         return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
 
-    @torch.no_grad()
+    def _tile_streams(self, n, device):
+        key = (n, device.index)
+        cache = self.__dict__.setdefault('_tile_stream_cache', {})
+        if key not in cache:
+            cache[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return cache[key]
+
     def options(self, options=None):
         """The hip_ops.Options a call runs with: the explicit argument if given, else `test_cfg.precision`
         ('fp32' default | 'bf16'; an extension absent from the reference) + `test_cfg.hip_options` (dict of

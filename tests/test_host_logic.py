@@ -252,6 +252,18 @@ def test_dataset_pipeline_and_checkpoint_roundtrip(tmp_path):
     m2 = _small_restorer(dict(scale=2))
     load_checkpoint(m2, str(tmp_path / 'ck.pth'), strict=True)
     assert state_dict_sha256(m2) == sha
+    # a generator-only file (keys without the 'generator.' prefix) matches nothing: refuse instead of evaluating random init
+    torch.save({'state_dict': m.generator.state_dict()}, tmp_path / 'gen_only.pth')
+    with pytest.raises(RuntimeError, match='none of its'):
+        load_checkpoint(_small_restorer(dict(scale=2)), str(tmp_path / 'gen_only.pth'))
+    # a partially matching file loads non-strictly but says what is missing
+    part = {k: v for k, v in m.state_dict().items() if 'imnet_q' not in k}
+    part['generator.extra.weight'] = torch.zeros(1)
+    torch.save(part, tmp_path / 'part.pth')
+    with pytest.warns(UserWarning, match='missing key'):
+        load_checkpoint(_small_restorer(dict(scale=2)), str(tmp_path / 'part.pth'))
+    with pytest.raises(RuntimeError, match='checkpoint mismatch'):
+        load_checkpoint(_small_restorer(dict(scale=2)), str(tmp_path / 'part.pth'), strict=True)
 
 
 def test_any_scale_tile_plan_properties():

@@ -12,7 +12,7 @@ model = rdn_ciaosr(dict(scale=4, tile=192, tile_overlap=32))
 seeded_init_(model, seed=0, gain=1.0)
 model = model.to(dev)
 lq = synthetic_pair(192, 192, 4)[0].to(dev)
-variants = sys.argv[1:] or ['fp32=fp32', 'bf16=bf16', 'bf16_v1=bf16,kv_rows=1,decode_rows=1']
+variants = sys.argv[1:] or ['fp32=fp32', 'bf16=bf16', 'bf16_single=bf16,bf16_single=1']
 ref = None
 for v in variants:
     name, spec = v.split('=', 1)
@@ -30,3 +30,12 @@ for v in variants:
     d = (out - ref).abs()
     print(f'{name:12s} {ms:8.3f} ms/tile  max|d vs first| {d.max().item():.2e} rms {d.pow(2).mean().sqrt().item():.2e}  ' +
           ' '.join(f'{k}={x["total_ms"]:.2f}' for k, x in top), flush=True)
+
+# tile-stream concurrency on the 6-tile image
+lq6 = synthetic_pair(339, 510, 4)[0].to(dev)
+for prec in ('fp32', 'bf16'):
+    for ns in (1, 2, 3):
+        model.test_cfg['tile_streams'] = ns
+        model.restore(lq6, options=prec)
+        ms = time_steps(lambda: model.restore(lq6, options=prec), 3, dev)
+        print(f'c3s (6 tiles) {prec} tile_streams={ns}: {ms:8.2f} ms', flush=True)
