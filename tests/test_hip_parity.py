@@ -902,6 +902,22 @@ def test_rerun_is_bitwise_deterministic(dev):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_head_rerun_is_bitwise_deterministic_at_scale(dev, precision):
+    """65 536 queries on a 64x64 map, six runs, sqrt(6)-gain weights (every rounding difference flips an attention weight
+    somewhere): all outputs bitwise equal.  Round 2 found the bf16 decode kernel's last-Linear loop NON-deterministic when
+    hipcc's SLP vectoriser packed it into v_pk_* instructions (channel 0 of ~100 of 65 536 queries changed from run to run;
+    the library is built with -fno-slp-vectorize since)."""
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 0, head_gain=SQRT6), dev, eval_bsize=30000)
+    feat = (randn((1, 64, 64, 64), 7) * 0.3).to(dev)
+    coord, cell = make_coord((256, 256)).unsqueeze(0).to(dev), make_cell((256, 256)).unsqueeze(0).to(dev)
+    x = (randn((1, 3, 64, 64), 14) * 0.3).to(dev)
+    outs = [g._predict([feat], coord, cell, 30000, x, precision).clone() for _ in range(6)]
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), int((outs[0] != o).any(-1).sum())
+
+
 def test_linearity_of_the_decode_residual_at_full_tile_size(dev):
     """Size-independent property at BASELINE's full tile size (LR 192x192 -> 768x768, Q = 589 824): the output is
     head(feature) + bilinear(x); changing only x by dx changes the output by exactly bilinear(dx) (fp32 rounding),
