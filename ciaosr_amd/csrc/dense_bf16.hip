@@ -86,9 +86,14 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
         goff[s] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)p.ldxb * 2u + (unsigned)part * 16u) : kOobD;
         loff[s] = c < DCHUNKS ? py * DROW + pxx * DPS + part * 16 : -1;
     }
+    // Every workgroup of a layer walks the same weights: started in lockstep, all 256 would pull the same L2 lines at the
+    // same time (hot channels).  Workgroup b therefore walks the input groups in the rotated order (g + b) mod G -- a
+    // different summation order per workgroup position (fp32 accumulation; deterministic), the same MACs.
+    const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
+    auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
     i32x4 P[DLOADS];
     auto load_chunk = [&](int s, int g) {
-        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobD ? (int)kOobD : (int)(goff[s] + (unsigned)g * 128u), 0, 0);
+        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobD ? (int)kOobD : (int)(goff[s] + (unsigned)phys(g) * 128u), 0, 0);
     };
     auto store_patch = [&](int buf) {
 #pragma unroll
@@ -107,10 +112,10 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
     }
     const uint4* wl = p.wf + lane;
     const int kpt = 4 * p.groups;            // k16-steps per tap (cin / 16)
-    auto frag = [&](int nt, int g, int tap) -> uint4 { return wl[(size_t)(nt * p.nks + tap * kpt + 4 * g + w) * 64]; };
+    auto frag = [&](int nt, int g, int tap) -> uint4 { return wl[(size_t)(nt * p.nks + tap * kpt + 4 * phys(g) + w) * 64]; };
     const bool has_lo = p.wf_lo != nullptr;                       // uniform: second MFMA per product with the weights' low halves
     const uint4* wll = (has_lo ? p.wf_lo : p.wf) + lane;
-    auto frag_lo = [&](int nt, int g, int tap) -> uint4 { return wll[(size_t)(nt * p.nks + tap * kpt + 4 * g + w) * 64]; };
+    auto frag_lo = [&](int nt, int g, int tap) -> uint4 { return wll[(size_t)(nt * p.nks + tap * kpt + 4 * phys(g) + w) * 64]; };
 
     f32x16 acc[2][DMT];
 #pragma unroll

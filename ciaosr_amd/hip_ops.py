@@ -11,9 +11,18 @@ _workspaces = {}
 
 
 def require_gpu(*tensors, allow_row_stride=False):
+    dev = None
     for t in tensors:
         if t is None:
             continue
+        if t.is_cuda:
+            # every launch goes to torch's current stream of the CURRENT device: a tensor living on another GPU would be
+            # dereferenced from the wrong device (run the call under `torch.cuda.device(t.device)`)
+            if dev is None:
+                dev = torch.cuda.current_device()
+            if t.device.index != dev:
+                raise CiaoSRHipError(f'tensor on cuda:{t.device.index} but the current device is cuda:{dev}: '
+                                     f'run the call under torch.cuda.device({t.device.index})')
         if not t.is_cuda:
             raise CiaoSRHipError('the LocalImplicitSR path runs on the MI355X only: got a CPU tensor '
                                  '(no CPU fallback; move the model and inputs to cuda)')
