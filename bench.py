@@ -440,6 +440,14 @@ def main():
                 t_c2 = time_steps(lambda: model.restore(c2), 20, dev)
                 extras['c2_fp32_ms'] = round(t_c2, 4)
                 extras['c2_fp32_mpix_s'] = round(192 * 192 / 1e6 / (t_c2 * 1e-3), 3)
+                # opt-in tile streams (test_cfg.tile_streams = 2: consecutive tiles on two HIP streams, bitwise the same image),
+                # on the 6-tile C3 variant; not used for the headline because it invalidates per-kernel event timing
+                c3s = synthetic_pair(339, 510, scale)[0].to(dev)
+                for ns in (1, 2):
+                    model.test_cfg['tile_streams'] = ns
+                    model.restore(c3s)
+                    extras[f'c3s_6tiles_fp32_ms_tile_streams_{ns}'] = round(time_steps(lambda: model.restore(c3s), 2, dev), 2)
+                model.test_cfg['tile_streams'] = 1
             line['extras'] = extras
         if world == 1 and not args.no_cpu_baseline:
             if args.workload in ('c2', 'c2q'):

@@ -127,17 +127,19 @@ class CiaoSR(BasicRestorer):
     def clip_test(self, img_lq, model=None, tile_fn=None, options=None):
         """Tiled inference of one large image (ciaosr.py:218-258).  Returns [B, h*sf*w*sf, 3].
 
-        Tiles are independent, so consecutive tiles run on `test_cfg.tile_streams` (default 2) HIP streams: the ramp,
-        first-load and drain phases of one tile's ~450 launches (8.5 us per dense layer, GEMM tails, the HBM-bound
-        softmax / patch kernels) fill with the other tile's workgroups instead of idling the chip.  Every tile is
-        computed exactly as on one stream (own scratch per stream) and the blend stays on the caller's stream in the
-        reference order (h outer, w inner), so the result is bitwise the single-stream result."""
+        Tiles are independent, so with `test_cfg.tile_streams = 2` (an extension; default 1) consecutive tiles run on two
+        HIP streams: the ramp, first-load and drain phases of one tile's ~450 launches (8.5 us per dense layer, GEMM
+        tails, the HBM-bound softmax / patch kernels) fill with the other tile's workgroups instead of idling the chip
+        (-2 % fp32, -3.5 % bf16 on a 6-tile image).  Every tile is computed exactly as on one stream (own scratch per
+        stream) and the blend stays on the caller's stream in the reference order (h outer, w inner), so the result is
+        bitwise the single-stream result.  Off by default because per-kernel event timings (bench.py's roofline leg,
+        rocprof) are meaningless while two streams share the chip."""
         sf = self.test_cfg.get('scale', None)
         b, c, h, w = img_lq.shape
         tile, origins = tile_grid(h, w, self.test_cfg.get('tile', None), self.test_cfg.get('tile_overlap', None))
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
-        n_streams = int(self.test_cfg.get('tile_streams', 2) or 1)
+        n_streams = int(self.test_cfg.get('tile_streams', 1) or 1)
         if tile_fn is not None or n_streams <= 1 or len(origins) < 2 or not img_lq.is_cuda:
             for (hi, wi) in origins:
                 out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf, options) if tile_fn is None else tile_fn(hi, wi)
