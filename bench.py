@@ -351,6 +351,10 @@ def main():
                     roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
                                 frac=round(ach / peak, 4), traffic=None)
                     roof['algorithmic_flop_per_launch'] = round(amount / launches_per_step)
+                    if kind == 'flop16' and not args.bf16_single and dominant in ('head_kv_fused_bf16', 'head_decode_fused_bf16', 'enc_dense_bf16'):
+                        # hi + lo weight pairs: the kernel issues two MFMAs per algorithmic product
+                        roof['executed_mfma_flop_per_launch'] = 2 * roof['algorithmic_flop_per_launch']
+                        roof['mfma_pipe_frac'] = round(2 * ach / peak, 4)
                 else:
                     ach = amount / (step_ms * 1e-3) / 1e9
                     roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
