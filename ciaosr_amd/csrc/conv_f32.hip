@@ -495,7 +495,9 @@ static int launch_conv(ConvP& p, float* partial, size_t partial_floats, hipStrea
     const long out32 = (long)ceil_div(p.M, 32) * ceil_div(p.Cout, 32);
     // small output (a 48x48 layer): 32x32 tiles spread it over every CU; large output: 64x64 tiles halve the
     // operand traffic per MAC
-    const int tm = (out32 <= 4096) ? 32 : 64;        // (128x64, one workgroup per CU, measured 7 % slower than 64x64 at the 192 tile)
+    // (a tall narrow output -- the 1x1 LFF of a 192x192 tile, M = 36 864, Cout = 64 -- has few 32x32 tiles per column but plenty
+    // of rows: 64x64 tiles there too)
+    const int tm = (out32 <= 4096 && p.M < 16384) ? 32 : 64;        // (128x64, one workgroup per CU, measured 7 % slower than 64x64 at the 192 tile)
     if (p.dense_step >= 0 && (p.Cout & 63)) return CIAOSR_ERR_BAD_ARG;
     const int tn = tm;
     p.tiles_n = ceil_div(p.Cout, tn);
