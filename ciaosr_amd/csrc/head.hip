@@ -9,7 +9,11 @@ struct HeadPlan {
     int H, W, C, Cn, D, Dv, J, HW;
     int wk0, wv0;            // layer-0 widths
     int wmax;                // widest hidden activation among k / v / q chains
-    int qc;                  // queries per work-chunk
+    int qc;                  // queries per work-chunk of the STAGED route (its [4 qc][..] intermediates are the big buffers)
+    int qcf;                 // queries per launch pair of the FUSED route: only Z [qcf][Dv] scales with it, so a whole 192x192
+                             // tile (589 824 queries) is ONE launch pair instead of nine -- every launch ends with a drain phase
+                             // in which the 4-workgroups-per-CU overlap that the kernels live on decays (probe: a workgroup lives
+                             // 685k cycles, a 65 536-query launch 3.0M, so ~1/4 of every launch ran under-occupied)
     size_t csa_bytes;
 };
 
@@ -30,6 +34,9 @@ static HeadPlan head_plan(int H, int W, const ciaosr_head_weights_t* w, int Q) {
     for (int i = 0; i + 1 < w->q.n_layers; ++i) wm = wm > w->q.width[i] ? wm : w->q.width[i];
     p.wmax = wm;
     p.qc = Q < 65536 ? Q : 65536;
+    p.qcf = Q < (1 << 20) ? Q : (1 << 20);
+    const long zcap = (long)(0xE0000000ull / ((size_t)p.Dv * sizeof(float)));      // Z is addressed through a 32-bit buffer descriptor
+    if (p.qcf > zcap) p.qcf = (int)zcap;
     p.csa_bytes = p.Cn > 0 ? ciaosr_cs_attn_workspace_bytes(H, W, p.C) : 0;
     return p;
 }
@@ -42,7 +49,7 @@ static size_t head_ws_bytes(const HeadPlan& p) {
     n += 2 * R * p.wmax;                      // ping-pong activations
     n += R * p.wv0;                           // Hv (layer-1 rows of the value chain, kept while the key chain runs)
     n += R * p.D + R * p.Dv;                  // WK, WV
-    n += (size_t)p.qc * p.Dv;                 // Z
+    n += (size_t)p.qcf * p.Dv;                // Z (sized for the fused route's chunk)
     n += (size_t)p.qc + R;                    // q_idx, k_idx (ints, same size as float)
     n += (size_t)p.HW * 9 * kLdG + (size_t)kQkChunk * p.D;   // logit table + one chunk of its GEMM rows
     n += (size_t)128 * p.D + 64;                             // bf16 mode: transposed bf16 copy of imnet_k's output layer
@@ -148,7 +155,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     float* Hv = ar.take<float>(R * p.wv0);
     float* WK = ar.take<float>(R * p.D);
     float* WV = ar.take<float>(R * p.Dv);
-    float* Z = ar.take<float>((size_t)p.qc * p.Dv);
+    float* Z = ar.take<float>((size_t)p.qcf * p.Dv);
     int* q_idx = ar.take<int>(p.qc);
     int* k_idx = ar.take<int>(R);
     float* G = ar.take<float>((size_t)p.HW * 9 * kLdG);
@@ -200,8 +207,9 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                          1.f, CIAOSR_ACT_NONE, 0.f, s, "head_logit_table"));
         }
     }
-    for (long q0 = 0; q0 < Q; q0 += p.qc) {
-        const int nq = (int)((Q - q0) < p.qc ? (Q - q0) : p.qc);
+    const int step = fused ? p.qcf : p.qc;
+    for (long q0 = 0; q0 < Q; q0 += step) {
+        const int nq = (int)((Q - q0) < step ? (Q - q0) : step);
         const long rows = (long)nq * p.J;
         if (fused) {
             FusedKVP kp;

@@ -13,7 +13,9 @@ dev = torch.device('cuda')
 model = rdn_ciaosr(dict(scale=4, tile=192, tile_overlap=32))
 seeded_init_(model, 0)
 model = model.to(dev)
-lq, _ = synthetic_pair(48, 48, 4)
+import sys as _s
+HW_ = int(_s.argv[1]) if len(_s.argv) > 1 else 48
+lq, _ = synthetic_pair(HW_, HW_, 4)
 lq = lq.to(dev)
 for _ in range(3):
     model.restore(lq)
