@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CIAOSR_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libciaosr_hip.so')
 MAX_LAYERS = 8
 
-ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_GELU, ACT_SIN, ACT_COS = 0, 1, 2, 3, 4, 5
 
 
 class CiaoSRHipError(RuntimeError):
@@ -20,7 +20,7 @@ class CiaoSRHipError(RuntimeError):
 
 
 class MlpT(C.Structure):
-    _fields_ = [('n_layers', C.c_int), ('in_dim', C.c_int), ('width', C.c_int * MAX_LAYERS),
+    _fields_ = [('n_layers', C.c_int), ('act', C.c_int), ('in_dim', C.c_int), ('width', C.c_int * MAX_LAYERS),
                 ('weight', C.c_void_p * MAX_LAYERS), ('ld', C.c_int * MAX_LAYERS),
                 ('bias', C.c_void_p * MAX_LAYERS), ('frag', C.c_void_p * MAX_LAYERS),
                 ('frag16', C.c_void_p * MAX_LAYERS), ('frag16_lo', C.c_void_p * MAX_LAYERS)]

@@ -203,6 +203,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
                 float v = (acc[mi][ni][r] + bv) * p.alpha;
                 if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
                 else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
+                else if (p.act == CIAOSR_ACT_SIN) v = sinf(v);
+                else if (p.act == CIAOSR_ACT_COS) v = cosf(v);
                 p.C[(size_t)row * p.ldc + col] = v;
             }
         }
@@ -218,6 +220,8 @@ __global__ void gemm_reduce_kernel(GemmP p) {
         v = (v + (p.bias ? p.bias[col] : 0.f)) * p.alpha;
         if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
         else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
+        else if (p.act == CIAOSR_ACT_SIN) v = sinf(v);
+        else if (p.act == CIAOSR_ACT_COS) v = cosf(v);
         p.C[(size_t)row * p.ldc + col] = v;
     }
 }

@@ -56,6 +56,8 @@ static size_t head_ws_bytes(const HeadPlan& p) {
     return n * sizeof(float) + p.csa_bytes + 32 * 256;
 }
 
+static int mlp_act(const ciaosr_mlp_t& m) { return m.act == CIAOSR_ACT_SIN || m.act == CIAOSR_ACT_COS ? m.act : CIAOSR_ACT_RELU; }
+
 static bool mlp_ok(const ciaosr_mlp_t& m) {
     if (m.n_layers < 1 || m.n_layers > CIAOSR_MAX_LAYERS) return false;
     for (int i = 0; i < m.n_layers; ++i)
@@ -76,7 +78,7 @@ static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA
         float* dst = last ? last_out : pp[flip];
         const int ldd = last ? ld_last : m.width[i];
         int rc = gemm_f32(cur, ld_cur, m.weight[i], m.ld[i], false, dst, ldd, m.bias[i], (int)rows, m.width[i],
-                          m.width[i - 1], 1.f, last ? CIAOSR_ACT_NONE : CIAOSR_ACT_RELU, 0.f, s,
+                          m.width[i - 1], 1.f, last ? CIAOSR_ACT_NONE : mlp_act(m), 0.f, s,
                           last ? tag_out : tag_hidden);
         if (rc != CIAOSR_OK) return rc;
         cur = dst;
@@ -88,7 +90,7 @@ static int run_tail(const ciaosr_mlp_t& m, const float* h0, int ld0, float* bufA
 
 // fused kernels: hidden width 256 everywhere, fragments packed, 4 key samples
 static bool chain_fused_ok(const ciaosr_mlp_t& m, bool is_q, bool bf16) {
-    if (m.n_layers < 2) return false;
+    if (m.n_layers < 2 || mlp_act(m) != CIAOSR_ACT_RELU) return false;
     for (int i = 0; i + 1 < m.n_layers; ++i)
         if (m.width[i] != 256) return false;
     for (int i = is_q ? 0 : 1; i < m.n_layers - (is_q ? 1 : 0); ++i)
@@ -248,7 +250,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         hp.Tk = Tk; hp.Tv = Tv;
         hp.tailK = w->k.weight[0] + p.D;      // columns [9C, 9C+4) of layer 0, stride ld -> packed copy below
         hp.tailV = w->v.weight[0] + p.Dv;
-        hp.wk0 = p.wk0; hp.wv0 = p.wv0; hp.relu_k = 1; hp.relu_v = 1;
+        hp.wk0 = p.wk0; hp.wv0 = p.wv0; hp.relu_k = mlp_act(w->k); hp.relu_v = mlp_act(w->v);
         hp.Hk = bufA; hp.Hv = Hv; hp.q_idx = q_idx; hp.k_idx = k_idx;
         hp.ld_tail_k = w->k.ld[0]; hp.ld_tail_v = w->v.ld[0];
         RUN(head_rows(hp, s));
@@ -266,7 +268,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         int flip = 0;
         for (int i = 0; i + 1 < mq.n_layers; ++i) {
             RUN(gemm_f32(cur, ld_cur, mq.weight[i], mq.ld[i], false, pp[flip], mq.width[i], mq.bias[i], nq,
-                         mq.width[i], k_cur, 1.f, CIAOSR_ACT_RELU, 0.f, s, i == 0 ? "mlp_in_q" : "mlp_hidden_q"));
+                         mq.width[i], k_cur, 1.f, mlp_act(mq), 0.f, s, i == 0 ? "mlp_in_q" : "mlp_hidden_q"));
             cur = pp[flip]; ld_cur = mq.width[i]; k_cur = mq.width[i];
             flip ^= 1;
         }
@@ -323,7 +325,7 @@ extern "C" int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp
         float* dst = last ? out : pp[i & 1];
         const int ldd = last ? ld_out : wmax;
         int rc = gemm_f32(cur, ld_cur, m->weight[i], m->ld[i], false, dst, ldd, m->bias[i], rows, m->width[i], k_cur, 1.f,
-                          i + 1 == m->n_layers ? CIAOSR_ACT_NONE : CIAOSR_ACT_RELU, 0.f, (hipStream_t)stream, "mlp_layer");
+                          i + 1 == m->n_layers ? CIAOSR_ACT_NONE : mlp_act(*m), 0.f, (hipStream_t)stream, "mlp_layer");
         if (rc != CIAOSR_OK) return rc;
         cur = dst; ld_cur = ldd; k_cur = m->width[i];
     }

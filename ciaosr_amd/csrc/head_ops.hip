@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadRowsP p) {
             for (int e = 0; e < 4; ++e) {
                 const float4 w = *reinterpret_cast<const float4*>(tw + (size_t)(4 * n4 + e) * p.ld_tail_k);
                 float v = r[e] + w.x * s.rel_y + w.y * s.rel_x + w.z * sy + w.w * sx;
-                r[e] = p.relu_k ? fmaxf(v, 0.f) : v;
+                r[e] = p.relu_k == CIAOSR_ACT_RELU ? fmaxf(v, 0.f) : p.relu_k == CIAOSR_ACT_SIN ? sinf(v) : p.relu_k == CIAOSR_ACT_COS ? cosf(v) : v;
             }
             o[n4] = make_float4(r[0], r[1], r[2], r[3]);
         }
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadRowsP p) {
             for (int e = 0; e < 4; ++e) {
                 const float4 w = *reinterpret_cast<const float4*>(tw + (size_t)(4 * n4 + e) * p.ld_tail_v);
                 float v = r[e] + w.x * s.rel_y + w.y * s.rel_x + w.z * sy + w.w * sx;
-                r[e] = p.relu_v ? fmaxf(v, 0.f) : v;
+                r[e] = p.relu_v == CIAOSR_ACT_RELU ? fmaxf(v, 0.f) : p.relu_v == CIAOSR_ACT_SIN ? sinf(v) : p.relu_v == CIAOSR_ACT_COS ? cosf(v) : v;
             }
             o[n4] = make_float4(r[0], r[1], r[2], r[3]);
         }

@@ -16,7 +16,7 @@ struct HeadRowsP {
     const float* tailK;  // &W1k[0][D]: 4 tail columns (rel_y rel_x scale_y scale_x) of each row, stride ld_tail_k
     const float* tailV;  // &W1v[0][Dv]
     int ld_tail_k, ld_tail_v;
-    int wk0, wv0, relu_k, relu_v;
+    int wk0, wv0, relu_k, relu_v;   // relu_*: CIAOSR_ACT_* code of the layer-0 activation of imnet_k / imnet_v
     float* Hk;  // [nq*J][wk0]
     float* Hv;  // [nq*J][wv0]
     int* q_idx;

@@ -39,6 +39,7 @@ class PackedHead:
         if len(lin) > _lib.MAX_LAYERS:
             raise _lib.CiaoSRHipError(f'MLP deeper than {_lib.MAX_LAYERS} Linear layers')
         st.n_layers = len(lin)
+        st.act = mlp.act_code() if hasattr(mlp, 'act_code') else _lib.ACT_RELU
         keep = []
         for i, l in enumerate(lin):
             w = l.weight.detach().float()

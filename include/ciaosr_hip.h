@@ -38,6 +38,8 @@ extern "C" {
 #define CIAOSR_ACT_RELU 1
 #define CIAOSR_ACT_PRELU 2
 #define CIAOSR_ACT_GELU 3   /* exact erf form (nn.GELU default); convolution epilogues only */
+#define CIAOSR_ACT_SIN 4    /* MLPRefiner(act='sin'), mlp:81-86; ciaosr_gemm_f32 and the staged head route */
+#define CIAOSR_ACT_COS 5    /* MLPRefiner(act='cos') */
 
 #define CIAOSR_MAX_LAYERS 8
 
@@ -140,6 +142,8 @@ int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const 
 /* ---- head ---------------------------------------------------------------------------------- */
 typedef struct ciaosr_mlp {
     int n_layers;                          /* Linear layers = len(hidden_list)+1 (mlp:74-89) */
+    int act;                               /* activation between the layers: CIAOSR_ACT_RELU (default; 0 is read as RELU), _SIN or _COS
+                                            * (mlp:81-86).  The fused head kernels are ReLU-only: sin / cos MLPs take the staged route */
     int in_dim;                            /* fan-in of layer 0 as stored (device channel order) */
     int width[CIAOSR_MAX_LAYERS];          /* fan-out of layer i; width[n_layers-1] = out_dim */
     const float* weight[CIAOSR_MAX_LAYERS];/* layer i: [width[i]][ld[i]] row-major */

@@ -52,14 +52,16 @@ def mlp_layer_ids(params, prefix):
     return ids
 
 
-def mlp(x, params, prefix):
+def mlp(x, params, prefix, act=None):
+    """MLPRefiner.forward (mlp_refiner.py:74-102): Linear / act ... Linear; act = ReLU unless 'cos' / 'sin' (:81-86)."""
     ids = mlp_layer_ids(params, prefix)
     lead = x.shape[:-1]
     h = x.reshape(-1, x.shape[-1])
+    fn = torch.cos if act == 'cos' else torch.sin if act == 'sin' else torch.relu
     for n, i in enumerate(ids):
         h = F.linear(h, params[f'{prefix}.layers.{i}.weight'], params[f'{prefix}.layers.{i}.bias'])
         if n + 1 < len(ids):
-            h = torch.relu(h)
+            h = fn(h)
     return h.reshape(*lead, -1)
 
 
@@ -138,7 +140,7 @@ def shift_list(local_size):
 
 
 def query_rgb(feature, coord, cell, params, local_size=2, softmax_scale=1.0, feat_unfold=True,
-              non_local=True, multi_scale=(2,), nonlocal_map=None, return_intermediates=False):
+              non_local=True, multi_scale=(2,), nonlocal_map=None, return_intermediates=False, act=None):
     B, C, H, W = feature.shape
     if feat_unfold:
         fq = F.unfold(feature, 3, padding=1).view(B, C * 9, H, W)
@@ -176,8 +178,8 @@ def query_rgb(feature, coord, cell, params, local_size=2, softmax_scale=1.0, fea
         bs, q = coord.shape[:2]
         in_k = torch.cat([key, rel, sc], -1).view(bs * q, -1)
         in_v = torch.cat([val, rel, sc], -1).view(bs * q, -1)
-        wk = mlp(in_k, params, 'imnet_k').view(bs, q, -1)
-        wv = mlp(in_v, params, 'imnet_v').view(bs, q, -1)
+        wk = mlp(in_k, params, 'imnet_k', act).view(bs, q, -1)
+        wv = mlp(in_v, params, 'imnet_v', act).view(bs, q, -1)
         pk.append(key * wk)
         pv.append(val * wv)
     pk = torch.stack(pk, dim=-1)                 # [B,Q,D,J]
@@ -185,7 +187,7 @@ def query_rgb(feature, coord, cell, params, local_size=2, softmax_scale=1.0, fea
     logit = query.unsqueeze(2) @ pk              # [B,Q,1,J]
     attn = (logit / softmax_scale).softmax(dim=-1)
     z = (attn @ pv).view(coord.shape[0] * coord.shape[1], -1)
-    out = mlp(z, params, 'imnet_q').view(coord.shape[0], coord.shape[1], -1)
+    out = mlp(z, params, 'imnet_q', act).view(coord.shape[0], coord.shape[1], -1)
     if return_intermediates:
         inter.update(logit=logit[:, :, 0], attn=attn[:, :, 0], z=z.view(coord.shape[0], coord.shape[1], -1))
         return out, inter

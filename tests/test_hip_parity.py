@@ -222,9 +222,9 @@ def test_csattn_bf16_mode_vs_reference(dev, tag):
 # ------------------------------------------------------------------------------------------------
 # head
 # ------------------------------------------------------------------------------------------------
-def _my_generator(C, hidden, params, dev, **kw):
+def _my_generator(C, hidden, params, dev, act=None, **kw):
     from ciaosr_amd import LocalImplicitSREDSR
-    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=list(hidden))
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=list(hidden), **({'act': act} if act else {}))
     g = LocalImplicitSREDSR(dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=C, num_blocks=1),
                             mk(4, 3), mk(64, 64), mk(64, 64), **kw)
     missing, unexpected = g.load_state_dict(params, strict=False)
@@ -249,6 +249,22 @@ def test_head_variants_vs_golden(dev, tag, kw):
     g = _my_generator(8, (32, 32), weights_from(fx), dev, eval_bsize=None, **kw)
     out = g.query_rgb([_t(fx['feature']).to(dev)], _t(fx['coord']).to(dev), _t(fx['cell']).to(dev)).cpu()
     assert (out - _t(fx['out'])).abs().max() < TOL
+
+
+@pytest.mark.parametrize('act', ['sin', 'cos'])
+def test_head_sin_cos_activations_vs_golden(dev, act):
+    """MLPRefiner(act='sin' | 'cos') (mlp_refiner.py:81-86; unused by the configs): the staged route (layer-1 hoist, per-layer
+    GEMMs with sin / cos epilogues, K4, decode) and the as-written route against the reference's output."""
+    from ciaosr_amd import hip_ops
+    fx = load_golden('tiny_head_act_' + act)
+    g = _my_generator(8, (32, 32), weights_from(fx), dev, act=act, eval_bsize=None)
+    feat, coord, cell = _t(fx['feature']).to(dev), _t(fx['coord']).to(dev), _t(fx['cell']).to(dev)
+    with hip_ops.profile():
+        out = g.query_rgb([feat], coord, cell).cpu()
+    assert 'local_attention' in hip_ops.profile.results()        # the fused kernels are ReLU-only
+    assert (out - _t(fx['out'])).abs().max() < TOL
+    written = g._head.forward_as_written(feat[0], None, coord[0], cell[0]).cpu()
+    assert (written - _t(fx['out'])[0]).abs().max() < TOL
 
 
 def test_head_sensitivity(dev):

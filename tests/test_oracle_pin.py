@@ -41,6 +41,13 @@ def test_tiny_head_variants(tag, kw):
     assert (out - _t(fx['out'])).abs().max() < TOL
 
 
+@pytest.mark.parametrize('act', ['sin', 'cos'])
+def test_tiny_head_sin_cos_activations(act):
+    fx = load_golden('tiny_head_act_' + act)
+    out = orc.query_rgb(_t(fx['feature']), _t(fx['coord']), _t(fx['cell']), weights_from(fx), act=act)
+    assert (out - _t(fx['out'])).abs().max() < TOL
+
+
 def test_per_query_restatement_matches_reference():
     """The explicit-index numpy form (what the HIP kernels follow) on every query of the tiny case."""
     fx = load_golden('tiny_head_s2p7')

@@ -28,13 +28,13 @@ OUT = os.path.join(REPO, 'tests', 'golden')
 SQRT6 = math.sqrt(6.0)
 
 
-def mlp_cfg(hidden):
-    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=list(hidden))
+def mlp_cfg(hidden, act=None):
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=list(hidden), **({'act': act} if act else {}))
     return mk(4, 3), mk(64, 64), mk(64, 64)
 
 
-def edsr_generator(ref, mid=64, blocks=16, hidden=(256,) * 4, eval_bsize=30000, **kw):
-    q, k, v = mlp_cfg(hidden)
+def edsr_generator(ref, mid=64, blocks=16, hidden=(256,) * 4, eval_bsize=30000, act=None, **kw):
+    q, k, v = mlp_cfg(hidden, act)
     enc = dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=mid, num_blocks=blocks)
     return ref.LocalImplicitSREDSR(enc, q, k, v, eval_bsize=eval_bsize, **kw)
 
@@ -100,6 +100,22 @@ def gen_tiny_head_variants(ref):
             out = m.query_rgb([feat], coord, cell)
         w = {('w.' + k): v for k, v in head_sd(m).items()}
         save(f'tiny_head_{tag}', feature=feat, coord=coord, cell=cell, out=out, sha=np.array(sha),
+             target=np.array([ht, wt]), **w)
+
+
+def gen_tiny_head_act(ref):
+    """MLPRefiner(act='sin' | 'cos') (mlp_refiner.py:81-86) in all three implicit functions: C = 8, hidden [32,32],
+    LR 6x8 -> x2.5.  The reference resolves type='MLPRefiner' through mmedit's registry; the stub maps it to the in-repo
+    class, which is the one carrying the `act` argument."""
+    for act in ('sin', 'cos'):
+        m = edsr_generator(ref, mid=8, blocks=1, hidden=(32, 32), eval_bsize=None, act=act).eval()
+        sha = seeded_init_(m, seed=13, gain=1.0, head_gain=SQRT6)
+        feat = randn((1, 8, 6, 8), 23)
+        coord, cell, (ht, wt) = coords_for(6, 8, 2.5)
+        with torch.no_grad():
+            out = m.query_rgb([feat], coord, cell)
+        w = {('w.' + k): v for k, v in head_sd(m).items()}
+        save(f'tiny_head_act_{act}', feature=feat, coord=coord, cell=cell, out=out, sha=np.array(sha),
              target=np.array([ht, wt]), **w)
 
 
@@ -328,7 +344,7 @@ def gen_swinir(ref):
          target=np.array([ht, wt]))
 
 
-ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, head_c64=gen_head_c64,
+ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, tiny_act=gen_tiny_head_act, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
            head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir)
 
