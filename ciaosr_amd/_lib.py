@@ -27,7 +27,7 @@ class MlpT(C.Structure):
 
 
 class HeadWeightsT(C.Structure):
-    _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('local_size', C.c_int),
+    _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('local_size', C.c_int), ('no_unfold', C.c_int),
                 ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT)]
 
 

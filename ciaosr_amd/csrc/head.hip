@@ -25,7 +25,7 @@ static int n_samples(int local_size) { return local_size == 1 ? 1 : (local_size 
 static HeadPlan head_plan(int H, int W, const ciaosr_head_weights_t* w, int Q) {
     HeadPlan p;
     p.H = H; p.W = W; p.C = w->channels; p.Cn = w->nonlocal_channels;
-    p.D = 9 * p.C; p.Dv = p.D + p.Cn; p.J = n_samples(w->local_size); p.HW = H * W;
+    p.D = (w->no_unfold ? 1 : 9) * p.C; p.Dv = p.D + p.Cn; p.J = n_samples(w->local_size); p.HW = H * W;
     p.wk0 = w->k.width[0];
     p.wv0 = w->v.width[0];
     int wm = 4;
@@ -169,7 +169,10 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
     // unfold rows U[:, :9C] (net:132-136) and the non-local map into U[:, 9C:] (net:134-137)
-    RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
+    if (w->no_unfold)     // feat_unfold=False (net:139-141): the "unfold" row is the pixel's C features (a 1x1 patch)
+        RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 1, 1, 0, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
+    else
+        RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
     if (csattn)
         RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, opt, csa_ws, p.csa_bytes, stream_));
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel

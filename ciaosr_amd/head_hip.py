@@ -90,8 +90,9 @@ class PackedHead:
         Cc = net.imnet_dim
         Cn = Cc * len(net.multi_scale) if net.non_local_attn else 0
         dev = net.imnet_q.layers[0].weight.device
-        perm = unfold_perm(Cc, dev)
-        D = 9 * Cc
+        unfold = bool(getattr(net, 'feat_unfold', True))
+        perm = unfold_perm(Cc, dev) if unfold else torch.arange(Cc, device=dev)       # feat_unfold=False: rows are the C features
+        D = (9 if unfold else 1) * Cc
         tail_n = torch.arange(D, D + Cn, device=dev)
         k_cols = torch.cat([perm, torch.arange(D, D + 4, device=dev)])
         v_cols = torch.cat([perm, tail_n, torch.arange(D + Cn, D + Cn + 4, device=dev)])
@@ -99,6 +100,7 @@ class PackedHead:
         st = _lib.HeadWeightsT()
         st.channels, st.nonlocal_channels = Cc, Cn
         st.local_size, st.softmax_scale = int(net.local_size), float(net.softmax_scale)
+        st.no_unfold = 0 if unfold else 1
         keep = []
         nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
         st.k, kk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
@@ -150,6 +152,9 @@ class PackedHead:
         eval_bsize chunk like batched_predict (net:238-246), cs_attn once.
         Used by the parity tests as a third evaluation route and to measure K1/K4 against the HBM roofline."""
         net = self.net
+        if not getattr(net, 'feat_unfold', True):
+            raise _lib.CiaoSRHipError('the staged K1 / K4 entry points take 3x3-unfold rows (D = 9C); feat_unfold=False runs through '
+                                      'ciaosr_head_forward_f32 only')
         feature_chw = feature_chw.contiguous().float()
         coord, cell = coord.contiguous().float(), cell.contiguous().float()
         x_lr_chw = x_lr_chw.contiguous().float() if x_lr_chw is not None else None

@@ -32,17 +32,20 @@ class LocalImplicitSRNet(nn.Module):
         self.non_local_attn = non_local_attn
         self.multi_scale = list(multi_scale)
         self.softmax_scale = softmax_scale
-        if not feat_unfold:
-            raise NotImplementedError('feat_unfold=False is not implemented on the HIP path '
-                                      '(every CiaoSR config uses feat_unfold=True)')
         imnet_q, imnet_k, imnet_v = copy.deepcopy(imnet_q), copy.deepcopy(imnet_k), copy.deepcopy(imnet_v)
         self.encoder = build_backbone(encoder)
         dim = self.encoder.mid_channels if hasattr(self.encoder, 'mid_channels') else self.encoder.embed_dim
         self.imnet_dim = dim
         # dims wiring, ciaosr_net.py:61-76
-        imnet_q['in_dim'] = dim * 9
-        imnet_k['in_dim'] = imnet_k['out_dim'] = dim * 9
-        imnet_v['in_dim'] = imnet_v['out_dim'] = dim * 9
+        if not feat_unfold and non_local_attn:
+            # the reference builds imnet_v with the non-local channels (ciaosr_net.py:73-76) but only concatenates the
+            # non-local map inside `if self.feat_unfold:` (:129-141): its own forward fails on the shape mismatch
+            raise ValueError('feat_unfold=False needs non_local_attn=False (the reference concatenates the non-local map '
+                             'only on the unfold branch, ciaosr_net.py:129-141)')
+        mult = 9 if feat_unfold else 1                      # ciaosr_net.py:61-68
+        imnet_q['in_dim'] = dim * mult
+        imnet_k['in_dim'] = imnet_k['out_dim'] = dim * mult
+        imnet_v['in_dim'] = imnet_v['out_dim'] = dim * mult
         imnet_k['in_dim'] += 4
         imnet_v['in_dim'] += 4
         if non_local_attn:

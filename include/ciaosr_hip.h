@@ -176,6 +176,9 @@ typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
     int nonlocal_channels;/* Cn = C*len(multi_scale) or 0                          net:73-76 */
     int local_size;       /* 1, 2 or 3  -> 1, 4 or 9 key samples                   net:152-155 */
+    int no_unfold;        /* 0 (default): feat_unfold=True, the q/k/v maps are 3x3 unfolds, D = 9C (net:129-138);
+                           * 1: feat_unfold=False, they are the feature map itself, D = C (net:139-141; unused by the configs).
+                           * The dims below read with D in place of 9C */
     float softmax_scale;  /*                                                        net:215  */
     /* imnet_k: in = 9C + 4 (unfold | rel_y rel_x scale_y scale_x), out = 9C.      net:63,70
      * imnet_v: in = 9C + Cn + 4, out = 9C + Cn.                                   net:64,71,75-76

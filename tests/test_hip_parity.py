@@ -243,7 +243,8 @@ def test_head_tiny_vs_golden(dev):
 
 
 @pytest.mark.parametrize('tag,kw', [('ls3', dict(local_size=3)), ('ls1', dict(local_size=1)),
-                                    ('nonl0', dict(non_local_attn=False)), ('sm2', dict(softmax_scale=2))])
+                                    ('nonl0', dict(non_local_attn=False)), ('sm2', dict(softmax_scale=2)),
+                                    ('nounfold', dict(feat_unfold=False, non_local_attn=False))])
 def test_head_variants_vs_golden(dev, tag, kw):
     fx = load_golden('tiny_head_' + tag)
     g = _my_generator(8, (32, 32), weights_from(fx), dev, eval_bsize=None, **kw)

@@ -141,6 +141,18 @@ def test_state_dict_names_match_reference(kind):
     assert not hasattr(m.generator, 'encoder')       # re-parented then deleted (ciaosr_net.py:314-319)
 
 
+def test_feat_unfold_false_wiring():
+    """ciaosr_net.py:61-68: without the unfold the implicit functions see C (not 9C) features; the reference's own forward
+    only works with non_local_attn=False then (the non-local concat lives on the unfold branch, :129-141)."""
+    from ciaosr_amd import LocalImplicitSREDSR
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[32, 32])
+    enc = dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=8, num_blocks=1)
+    g = LocalImplicitSREDSR(enc, mk(4, 3), mk(64, 64), mk(64, 64), feat_unfold=False, non_local_attn=False)
+    assert g.imnet_q.in_dim == 8 and g.imnet_k.in_dim == 12 and g.imnet_k.out_dim == 8 and g.imnet_v.in_dim == 12
+    with pytest.raises(ValueError):
+        LocalImplicitSREDSR(enc, mk(4, 3), mk(64, 64), mk(64, 64), feat_unfold=False, non_local_attn=True)
+
+
 def test_dims_wiring():
     """ciaosr_net.py:56-76: the config's in/out dims are overwritten from the encoder width."""
     m = _small_restorer(dict(scale=2)).generator

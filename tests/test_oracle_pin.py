@@ -33,7 +33,8 @@ def test_tiny_head_matches_reference():
 
 
 @pytest.mark.parametrize('tag,kw', [('ls3', dict(local_size=3)), ('ls1', dict(local_size=1)),
-                                    ('nonl0', dict(non_local=False)), ('sm2', dict(softmax_scale=2.0))])
+                                    ('nonl0', dict(non_local=False)), ('sm2', dict(softmax_scale=2.0)),
+                                    ('nounfold', dict(feat_unfold=False, non_local=False))])
 def test_tiny_head_variants(tag, kw):
     fx = load_golden('tiny_head_' + tag)
     P = weights_from(fx)

@@ -91,7 +91,8 @@ def gen_tiny_head(ref):
 def gen_tiny_head_variants(ref):
     """local_size 3 / 1, softmax_scale 2, no non-local: branch coverage of query_rgb."""
     for tag, kw in (('ls3', dict(local_size=3)), ('ls1', dict(local_size=1)),
-                    ('nonl0', dict(non_local_attn=False)), ('sm2', dict(softmax_scale=2))):
+                    ('nonl0', dict(non_local_attn=False)), ('sm2', dict(softmax_scale=2)),
+                    ('nounfold', dict(feat_unfold=False, non_local_attn=False))):
         m = edsr_generator(ref, mid=8, blocks=1, hidden=(32, 32), eval_bsize=None, **kw).eval()
         sha = seeded_init_(m, seed=12, gain=1.0, head_gain=SQRT6)
         feat = randn((1, 8, 6, 8), 22)
