@@ -164,6 +164,43 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
                                      note='same port with cs_attn computed once per tile instead of once per chunk'))
 
 
+def live_pmc_traffic(kernel_substr, unit_workload, precision, timeout_s=300):
+    """HBM bytes per launch of the kernel whose name contains `kernel_substr`, collected NOW by two child processes under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, --kernel-trace only), each running this script on one
+    tile / one small image.  FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request for wide coalesced reads,
+    MI355X_MICROARCH.md, HBM section); units KiB.  Returns (bytes_per_launch, launches) or None if rocprofv3 is unavailable
+    or fails -- the caller then falls back to the committed offline summary."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None
+    vals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='ciaosr_pmc_', dir='/tmp')
+        cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
+               sys.executable, os.path.join(REPO, 'bench.py'), '--workload', unit_workload, '--precision', precision, '--steps', '1',
+               '--warmup', '1', '--no-cpu-baseline', '--no-extras', '--no-live-pmc']
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), timeout=timeout_s, check=True,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            got = []
+            for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r['Counter_Name'] == counter and kernel_substr in r['Kernel_Name']:
+                        got.append(float(r['Counter_Value']))
+            if not got:
+                return None
+            vals[counter] = (sum(got) / len(got) * 1024.0, len(got))
+        except Exception:      # noqa: BLE001 - profiler missing / refused / timed out: offline fallback
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return round(2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]), vals['FETCH_SIZE'][1]
+
+
 WORKLOADS = {
     # name: (LR h, LR w, tiles, description)
     'c3': (1356, 2040, 117, 'C3: RDN-CiaoSR (c64b16) x4, LR 1356x2040 -> 5424x8160 (DIV2K-shaped 2K LR), tiled inference: 117 tiles of '
@@ -190,6 +227,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true', help='do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs, fp32 accumulation')
@@ -385,7 +423,16 @@ def main():
                           'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_bf16_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
                 pmc_path = os.path.join(REPO, 'profiles', f'r2_{unit}_pmc_hbm_traffic.json')
-                if args.precision == 'fp32' and os.path.exists(pmc_path) and dominant in tag2fn:
+                live_traffic = None
+                if world == 1 and not args.no_live_pmc and dominant in tag2fn:
+                    # LIVE: two rocprofv3 --pmc child passes of this script on one tile, now, on this box
+                    live_traffic = live_pmc_traffic(tag2fn[dominant], unit, args.precision)
+                if live_traffic:
+                    roof['traffic'] = live_traffic[0]
+                    roof['traffic_source'] = (f'live: bytes per launch of {tag2fn[dominant]} from two rocprofv3 --pmc child passes (FETCH_SIZE x2 '
+                                              f'gfx950 correction + WRITE_SIZE, KiB units) of this script on one {tile_lr}x{tile_lr} tile, '
+                                              f'{live_traffic[1]} launches')
+                elif args.precision == 'fp32' and os.path.exists(pmc_path) and dominant in tag2fn:
                     hits = [v for k, v in json.load(open(pmc_path)).items() if tag2fn[dominant] in k]
                     if hits:
                         n_l = sum(h['launches'] for h in hits)
