@@ -27,12 +27,13 @@ class MlpT(C.Structure):
 
 
 class HeadWeightsT(C.Structure):
-    _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('local_size', C.c_int), ('no_unfold', C.c_int),
+    _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('nonlocal_max_scale', C.c_int), ('local_size', C.c_int),
+                ('no_unfold', C.c_int),
                 ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT)]
 
 
 class CsAttnWeightsT(C.Structure):
-    _fields_ = [('channels', C.c_int),
+    _fields_ = [('channels', C.c_int), ('scale', C.c_int),
                 ('w_match1', C.c_void_p), ('b_match1', C.c_void_p), ('slope_match1', C.c_float),
                 ('w_match2', C.c_void_p), ('b_match2', C.c_void_p), ('slope_match2', C.c_float),
                 ('w_assembly', C.c_void_p), ('b_assembly', C.c_void_p), ('slope_assembly', C.c_float),
@@ -101,6 +102,7 @@ SIGNATURES = {
     'ciaosr_gemm_f32': (_I, [_P, _I, _P, _I, _I, _P, _I, _P, _I, _I, _I, _F, _I, _F, _P]),
     'ciaosr_patch_rows_f32': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _F, _P]),
     'ciaosr_cs_attn_workspace_bytes': (_S, [_I, _I, _I]),
+    'ciaosr_cs_attn_workspace_bytes_scale': (_S, [_I, _I, _I, _I]),
     'ciaosr_cs_attn_f32': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _O, _P, _S, _P]),
     'ciaosr_cs_attn_bf16': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _O, _P, _S, _P]),
     'ciaosr_make_coord_cell_f32': (_I, [_P, _P, _I, _I, _P]),

@@ -25,11 +25,11 @@ struct CsaPlan {
     int Lld8; size_t n_P16;    // bf16 mode: probabilities [HpWp][Lld8] bf16
 };
 
-static CsaPlan csa_plan(int H, int W, int C) {
+static CsaPlan csa_plan(int H, int W, int C, int sc = 2) {
     CsaPlan p;
     p.H = H; p.W = W; p.C = C; p.Ch = (int)round_up(C / 2, 4);  // zero-padded half width
-    p.Hp = H + (H & 1); p.Wp = W + (W & 1);
-    p.L = (p.Hp / 2) * (p.Wp / 2);
+    p.Hp = (int)round_up((size_t)H, sc); p.Wp = (int)round_up((size_t)W, sc);        // mod_pad to the scale (csa:438-444)
+    p.L = (p.Hp / sc) * (p.Wp / sc);
     p.Lld = (int)round_up(p.L, 4);
     const size_t HW = (size_t)p.Hp * p.Wp;
     p.n_xp = HW * C;
@@ -39,10 +39,10 @@ static CsaPlan csa_plan(int H, int W, int C) {
     p.n_R = (size_t)p.L * p.Ch;
     p.n_Qp = HW * 9 * p.Ch;
     p.n_Kn = (size_t)p.L * 9 * p.Ch;
-    p.n_V = (size_t)p.L * 36 * C;
+    p.n_V = (size_t)p.L * 9 * sc * sc * C;          // (3s)x(3s) patches
     p.n_S = HW * p.Lld;
-    p.n_O = HW * 36 * C;
-    p.n_Y = 4 * HW * C;
+    p.n_O = HW * 9 * sc * sc * C;
+    p.n_Y = (size_t)sc * sc * HW * C;
     p.n_Yp = (size_t)H * W * 9 * C;
     p.n_PE = (size_t)(p.Hp / 2 + 3) * (p.Wp / 2 + 3) * 9 * C;
     p.n_Vp = (size_t)p.L * 25 * C;
@@ -56,8 +56,11 @@ static CsaPlan csa_plan(int H, int W, int C) {
 
 using namespace ciaosr;
 
-extern "C" size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C) {
-    const CsaPlan p = csa_plan(H, W, C);
+extern "C" size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C) { return ciaosr_cs_attn_workspace_bytes_scale(H, W, C, 2); }
+
+extern "C" size_t ciaosr_cs_attn_workspace_bytes_scale(int H, int W, int C, int scale) {
+    if (scale < 2 || scale > 4) scale = 4;          // callers sizing for "any scale" get the largest
+    const CsaPlan p = csa_plan(H, W, C, scale);
     const size_t n = p.n_xp + p.n_E + p.n_M + p.n_x2 + p.n_R + p.n_Qp + p.n_Kn + p.n_V + p.n_S + p.n_O + p.n_Y + p.n_Yp +
                      2 * p.n_PE + p.n_Vp + p.n_Ov + p.n_P16;
     return n * sizeof(float) + 24 * 256;
@@ -67,9 +70,12 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
                    const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
     CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
     const int C = w->channels;
+    const int sc = w->scale ? w->scale : 2;
     CIAOSR_CHECK_ARG(C >= 4 && (C & 3) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
+    CIAOSR_CHECK_ARG(sc >= 2 && sc <= 4 && H >= sc && W >= sc);     // reflect padding needs pad < size
     hipStream_t s = (hipStream_t)stream_;
-    const CsaPlan p = csa_plan(H, W, C);
+    const CsaPlan p = csa_plan(H, W, C, sc);
+    if (workspace_bytes < ciaosr_cs_attn_workspace_bytes_scale(H, W, C, sc)) return CIAOSR_ERR_WORKSPACE;
     Arena ar(workspace, workspace_bytes);
     float* xp = ar.take<float>(p.n_xp);
     float* E = ar.take<float>(p.n_E);
@@ -103,14 +109,15 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     };
     RUN(conv1x1(xp, w->w_assembly, w->b_assembly, w->slope_assembly, E, C, HWp));
     RUN(conv1x1(xp, w->w_match1, w->b_match1, w->slope_match1, M, p.Ch, HWp));
-    RUN(avgpool2(xp, p.Hp, p.Wp, C, x2, s));
+    if (sc == 2) RUN(avgpool2(xp, p.Hp, p.Wp, C, x2, s));
+    else RUN(downsample(xp, p.Hp, p.Wp, C, sc, x2, s));
     RUN(conv1x1(x2, w->w_match2, w->b_match2, w->slope_match2, R, p.Ch, p.L));
     RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
-    RUN(patch_rows(R, p.Ch, p.Hp / 2, p.Wp / 2, p.Ch, 3, 1, 1, p.Hp / 2, p.Wp / 2, Kn, 9 * p.Ch, 1, w->escape_nan, s,
+    RUN(patch_rows(R, p.Ch, p.Hp / sc, p.Wp / sc, p.Ch, 3, 1, 1, p.Hp / sc, p.Wp / sc, Kn, 9 * p.Ch, 1, w->escape_nan, s,
                    "csa_patch_k"));
     // composed fold+down tail from this many (padded) LR pixels on: per-call option, default 4096
     const int composed_min = opt && opt->csa_composed_min ? opt->csa_composed_min : 4096;
-    const bool composed = w->w_down_masked && composed_min > 0 && HWp >= composed_min;
+    const bool composed = sc == 2 && w->w_down_masked && composed_min > 0 && HWp >= composed_min;     // the composed tail is scale 2's
     // bf16 mode (big maps, composed tail): Q.K^T and P.V' on the bf16 MFMA (gemm_bf16.hip); logits and softmax in fp32,
     // probabilities rounded to bf16; 1x1 convolutions, the partial down-convolutions and the final gather stay fp32
     const size_t qk16_bytes = ((size_t)HWp + p.L) * 9 * p.Ch * 2 + 512;
@@ -159,12 +166,14 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
         RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 16L * C, 4L * C, 4L * C, s));
         return CIAOSR_OK;
     }
-    RUN(patch_rows(E, C, p.Hp, p.Wp, C, 6, 2, 2, p.Hp / 2, p.Wp / 2, V, 36 * C, 0, 0.f, s, "csa_patch_v"));
-    RUN(gemm_f32(S, p.Lld, V, 36 * C, true, O, 36 * C, nullptr, HWp, 36 * C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, s,
-                 "csa_attn_v"));
-    RUN(fold(O, 36 * C, p.Hp, p.Wp, C, Y, s));
-    // down conv 3x3 stride 2 pad 1 on Y [2Hp][2Wp][C], only for the H x W output pixels kept by the crop
-    RUN(patch_rows(Y, C, 2 * p.Hp, 2 * p.Wp, C, 3, 2, 1, H, W, Yp, 9 * C, 0, 0.f, s, "csa_patch_down"));
+    // V patches (3s)x(3s), stride s, 'same' padding = s each side (csa:462-465); attn.V; conv_transpose2d(stride s, padding s) as a
+    // gather; the scale's down conv (3x3, stride s, pad 1: down / downx3 / downx4, csa:516-521) on the cropped H x W outputs
+    const int kv = 9 * sc * sc * C;
+    RUN(patch_rows(E, C, p.Hp, p.Wp, C, 3 * sc, sc, sc, p.Hp / sc, p.Wp / sc, V, kv, 0, 0.f, s, "csa_patch_v"));
+    RUN(gemm_f32(S, p.Lld, V, kv, true, O, kv, nullptr, HWp, kv, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, s, "csa_attn_v"));
+    if (sc == 2) RUN(fold(O, kv, p.Hp, p.Wp, C, Y, s));
+    else RUN(fold_s(O, kv, p.Hp, p.Wp, C, sc, Y, s));
+    RUN(patch_rows(Y, C, sc * p.Hp, sc * p.Wp, C, 3, sc, 1, H, W, Yp, 9 * C, 0, 0.f, s, "csa_patch_down"));
     if (gemm_small_ok(H * W, C, 9 * C, 9 * C, 9 * C) && H * W <= 4096)
         RUN(gemm_small_f32(Yp, 9 * C, w->w_down, 9 * C, w->b_down, out, ld_out, nullptr, 0, nullptr, 0, H * W, C, 9 * C, CIAOSR_ACT_NONE,
                            0.f, 1.0f / 6.0f, s, "csa_down"));

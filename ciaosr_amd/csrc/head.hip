@@ -37,7 +37,7 @@ static HeadPlan head_plan(int H, int W, const ciaosr_head_weights_t* w, int Q) {
     p.qcf = Q < (1 << 20) ? Q : (1 << 20);
     const long zcap = (long)(0xE0000000ull / ((size_t)p.Dv * sizeof(float)));      // Z is addressed through a 32-bit buffer descriptor
     if (p.qcf > zcap) p.qcf = (int)zcap;
-    p.csa_bytes = p.Cn > 0 ? ciaosr_cs_attn_workspace_bytes(H, W, p.C) : 0;
+    p.csa_bytes = p.Cn > 0 ? ciaosr_cs_attn_workspace_bytes_scale(H, W, p.C, w->nonlocal_max_scale ? w->nonlocal_max_scale : 2) : 0;
     return p;
 }
 
@@ -143,7 +143,14 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     CIAOSR_CHECK_ARG(w->q.in_dim == p.Dv && w->q.width[w->q.n_layers - 1] == 3);
     CIAOSR_CHECK_ARG(w->k.n_layers >= 2 && w->v.n_layers >= 2 && w->q.n_layers >= 2);
     CIAOSR_CHECK_ARG((p.wk0 & 3) == 0 && (p.wv0 & 3) == 0);
-    if (csattn) CIAOSR_CHECK_ARG(csattn->channels == p.C && p.Cn == p.C);
+    const int n_scales = csattn ? p.Cn / p.C : 0;            // csattn = host array, one struct per entry of multi_scale
+    if (csattn) {
+        CIAOSR_CHECK_ARG(p.Cn == n_scales * p.C && n_scales >= 1 && n_scales <= 3);
+        for (int i = 0; i < n_scales; ++i) {
+            const int sc = csattn[i].scale ? csattn[i].scale : 2;
+            CIAOSR_CHECK_ARG(csattn[i].channels == p.C && sc <= (w->nonlocal_max_scale ? w->nonlocal_max_scale : 2));
+        }
+    }
     if (workspace_bytes < head_ws_bytes(p)) return CIAOSR_ERR_WORKSPACE;
     CIAOSR_CHECK_ARG((size_t)p.HW * p.Dv * sizeof(float) < 0xFFFFFF00ull);   // 32-bit buffer offsets into U
 
@@ -173,8 +180,9 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 1, 1, 0, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
     else
         RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
-    if (csattn)
-        RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn, U + p.D, p.Dv, opt, csa_ws, p.csa_bytes, stream_));
+    for (int i = 0; i < n_scales; ++i)     // one C-column slice per scale, in the order of multi_scale (csa:528 torch.cat(res_y, dim=1))
+        RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn + i, U + p.D + (size_t)i * p.C, p.Dv, opt, csa_ws,
+                                                              p.csa_bytes, stream_));
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     if (gemm_small_ok(p.HW, p.wk0, p.D, p.Dv, w->k.ld[0]) && gemm_small_ok(p.HW, p.wv0, p.Dv, p.Dv, w->v.ld[0]) && p.HW <= 4096) {
         RUN(gemm_small_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], w->k.bias[0], Tk, p.wk0, nullptr, 0, nullptr, 0, p.HW, p.wk0, p.D,

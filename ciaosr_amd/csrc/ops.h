@@ -70,6 +70,8 @@ int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int 
                float* out, int ld_out, int normalize, float floor_, hipStream_t s, const char* tag);
 int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s);
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s);
+int fold_s(const float* O, int ldo, int Hp, int Wp, int C, int scale, float* Y, hipStream_t s);
+int downsample(const float* src, int Hp, int Wp, int C, int scale, float* dst, hipStream_t s);
 int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStream_t s);
 int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const float* Otl, const float* bd, int H, int W,
                    int Hp, int Wp, int C, float* out, int ld_out, long ld_main, long ld_top, long ld_left, hipStream_t s);

@@ -42,7 +42,7 @@ __global__ void hwc_to_nchw_kernel(const float* __restrict__ src, int ld, float*
 }
 
 // ---------------------------------------------------------------------------------------------
-// reflect pad right/bottom by (ph, pw) in {0,1}  (arch_csnln.py:444-449)
+// reflect pad right/bottom up to the next multiple of the scale (pad < size)  (arch_csnln.py:438-444)
 // ---------------------------------------------------------------------------------------------
 __global__ void pad_reflect_kernel(const float* __restrict__ src, int ld_src, int H, int W, int C,
                                    float* __restrict__ dst, int Hp, int Wp) {
@@ -56,6 +56,32 @@ __global__ void pad_reflect_kernel(const float* __restrict__ src, int ld_src, in
         if (x >= W) x = 2 * (W - 1) - x;
         reinterpret_cast<float4*>(dst)[i] =
             *reinterpret_cast<const float4*>(src + ((size_t)y * W + x) * ld_src + 4 * c4);
+    }
+}
+
+// F.interpolate(scale_factor=1/s, 'bilinear', align_corners=False) (arch_csnln.py:474) for integer s: the source coordinate of
+// output d is s (d + 0.5) - 0.5, i.e. the single pixel s d + (s-1)/2 for odd s and the midpoint of pixels s d + s/2 - 1, s d + s/2
+// for even s: a 1x1 (s = 3) or 2x2 (s = 2, 4) mean.
+__global__ void downsample_kernel(const float* __restrict__ src, int Hp, int Wp, int C, int s, float* __restrict__ dst) {
+    const int c4n = C >> 2;
+    const int Ho = Hp / s, Wo = Wp / s;
+    const int o0 = (s - 1) >> 1, o1 = s >> 1;
+    const long n = (long)Ho * Wo * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        const long pix = i / c4n;
+        const int x = (int)(pix % Wo), y = (int)(pix / Wo);
+        const float4* sp = reinterpret_cast<const float4*>(src);
+        const float4 a = sp[((size_t)(s * y + o0) * Wp + s * x + o0) * c4n + c4];
+        const float4 b = sp[((size_t)(s * y + o0) * Wp + s * x + o1) * c4n + c4];
+        const float4 c = sp[((size_t)(s * y + o1) * Wp + s * x + o0) * c4n + c4];
+        const float4 d = sp[((size_t)(s * y + o1) * Wp + s * x + o1) * c4n + c4];
+        float4 o;
+        o.x = ((a.x + b.x) + (c.x + d.x)) * 0.25f;
+        o.y = ((a.y + b.y) + (c.y + d.y)) * 0.25f;
+        o.z = ((a.z + b.z) + (c.z + d.z)) * 0.25f;
+        o.w = ((a.w + b.w) + (c.w + d.w)) * 0.25f;
+        reinterpret_cast<float4*>(dst)[i] = o;
     }
 }
 
@@ -248,6 +274,31 @@ __global__ void fold_kernel(const float* __restrict__ O, int ldo, int Hp, int Wp
                 if (x < 0 || x >= Wp) continue;
                 const float4 t = *reinterpret_cast<const float4*>(
                     O + ((size_t)y * Wp + x) * ldo + (size_t)(i * 6 + j) * C + 4 * c4);
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+        }
+        reinterpret_cast<float4*>(Y)[idx] = acc;
+    }
+}
+
+// fold for a general scale s: F.conv_transpose2d(P, V, stride=s, padding=s) with (3s)x(3s) patches.
+// O[(y,x)][(i*3s+j)*C + c]; output pixel (u,v) of the sHp x sWp map sums the <= 9 (pixel, tap) pairs with s y - s + i == u.
+__global__ void fold_s_kernel(const float* __restrict__ O, int ldo, int Hp, int Wp, int C, int s, float* __restrict__ Y) {
+    const int c4n = C >> 2;
+    const int Hs = s * Hp, Ws = s * Wp, k = 3 * s;
+    const long n = (long)Hs * Ws * c4n;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % c4n);
+        const long pix = idx / c4n;
+        const int v = (int)(pix % Ws), u = (int)(pix / Ws);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = u % s; i < k; i += s) {
+            const int y = (u + s - i) / s;            // u + s - i is a non-negative multiple of s or negative
+            if (u + s - i < 0 || y >= Hp) continue;
+            for (int j = v % s; j < k; j += s) {
+                const int x = (v + s - j) / s;
+                if (v + s - j < 0 || x >= Wp) continue;
+                const float4 t = *reinterpret_cast<const float4*>(O + ((size_t)y * Wp + x) * ldo + (size_t)(i * k + j) * C + 4 * c4);
                 acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
             }
         }
@@ -468,6 +519,20 @@ int csa_gather_vprime_t_bf16(const float* Pc, int Hh, int Wh, int C, unsigned sh
     ProfScope prof("csa_gather_vprime", s);
     hipLaunchKernelGGL(csa_gather_vprime_t_bf16_kernel, dim3(ew_grid((long)25 * C * ldt)), dim3(256), 0, s, Pc, Hh, Wh, C, VpT, ldt);
     return launch_status("csa_gather_vprime_t");
+}
+
+int downsample(const float* src, int Hp, int Wp, int C, int scale, float* dst, hipStream_t s) {
+    CIAOSR_CHECK_ARG(scale >= 2 && scale <= 4 && Hp % scale == 0 && Wp % scale == 0);
+    ProfScope prof("avgpool2", s);
+    hipLaunchKernelGGL(downsample_kernel, dim3(ew_grid((long)(Hp / scale) * (Wp / scale) * C / 4)), dim3(256), 0, s, src, Hp, Wp, C, scale,
+                       dst);
+    return launch_status("downsample");
+}
+
+int fold_s(const float* O, int ldo, int Hp, int Wp, int C, int scale, float* Y, hipStream_t s) {
+    ProfScope prof("fold_gather", s);
+    hipLaunchKernelGGL(fold_s_kernel, dim3(ew_grid((long)scale * scale * Hp * Wp * C / 4)), dim3(256), 0, s, O, ldo, Hp, Wp, C, scale, Y);
+    return launch_status("fold_s");
 }
 
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s) {

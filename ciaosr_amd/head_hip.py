@@ -100,6 +100,7 @@ class PackedHead:
         st = _lib.HeadWeightsT()
         st.channels, st.nonlocal_channels = Cc, Cn
         st.local_size, st.softmax_scale = int(net.local_size), float(net.softmax_scale)
+        st.nonlocal_max_scale = max(net.multi_scale) if (net.non_local_attn and net.multi_scale) else 0
         st.no_unfold = 0 if unfold else 1
         keep = []
         nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
@@ -138,7 +139,7 @@ class PackedHead:
         ws = hip_ops.workspace(nbytes, coord.device)
         rgb = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)
         _lib.call('ciaosr_head_forward_bf16' if opt.bf16 else 'ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W,
-                  C.byref(st), C.byref(cs) if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
+                  C.byref(st), cs if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
                   hip_ops.ptr(cell), Q, int(chunk or 0), hip_ops.ptr(rgb), opt.c_arg(), hip_ops.ptr(ws), ws.numel(),
                   hip_ops.stream_ptr())
         return rgb

@@ -106,6 +106,10 @@ int ciaosr_patch_rows_f32(const float* src_hwc, int ld_src, int Hs, int Ws, int 
 /* ---- CrossScaleAttention, scale 2 (csa:430-532) ------------------------------------------- */
 typedef struct ciaosr_csattn_weights {
     int channels;                 /* C */
+    int scale;                    /* 2 (also when 0), 3 or 4: ONE entry of CrossScaleAttention's scale list (csa:436); a module built
+                                   * with scale=[2,3] is two structs sharing the match / assembly weights and differing in `down`
+                                   * (csa:421-427: down / downx3 / downx4), evaluated one after the other into consecutive C-column
+                                   * slices of the output (csa:528) */
     /* Ch = C/2 rounded up to a multiple of 4; rows >= C/2 of the two match weights and biases are 0 */
     const float* w_match1;        /* [Ch][C]   conv_match_1.0.weight  (csa:418) */
     const float* b_match1;        /* [Ch] */
@@ -116,7 +120,7 @@ typedef struct ciaosr_csattn_weights {
     const float* w_assembly;      /* [C][C]    conv_assembly (csa:420) */
     const float* b_assembly;
     float slope_assembly;
-    const float* w_down;          /* [C][9C]   down.weight (csa:428) packed [co][(a*3+b)*C + ci] */
+    const float* w_down;          /* [C][9C]   down / downx3 / downx4 .weight (csa:421-428) packed [co][(a*3+b)*C + ci] */
     const float* b_down;          /* [C] */
     /* optional (NULL = off): `down` weights masked per tap subset for the composed fold+down form (csattn.hip):
      * [9][C][9C], block 3r+s keeps taps a in R_r, b in S_s with R_0 = {0}, R_1 = {0,1,2}, R_2 = {1,2}; same
@@ -126,7 +130,8 @@ typedef struct ciaosr_csattn_weights {
     float softmax_scale;          /* 10   (csa:408) */
 } ciaosr_csattn_weights_t;
 
-size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C);
+size_t ciaosr_cs_attn_workspace_bytes(int H, int W, int C);          /* scale 2 */
+size_t ciaosr_cs_attn_workspace_bytes_scale(int H, int W, int C, int scale);
 /* feat_hwc [H][W][ld_feat] -> out [H][W] rows of C floats with leading dimension ld_out
  * (lets the caller write straight into the tail columns of the unfold rows, net:137). */
 int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
@@ -175,6 +180,7 @@ int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* ou
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
     int nonlocal_channels;/* Cn = C*len(multi_scale) or 0                          net:73-76 */
+    int nonlocal_max_scale;/* largest entry of multi_scale (2 when 0): sizes the cs_attn scratch inside the head workspace */
     int local_size;       /* 1, 2 or 3  -> 1, 4 or 9 key samples                   net:152-155 */
     int no_unfold;        /* 0 (default): feat_unfold=True, the q/k/v maps are 3x3 unfolds, D = 9C (net:129-138);
                            * 1: feat_unfold=False, they are the feature map itself, D = C (net:139-141; unused by the configs).
@@ -232,7 +238,8 @@ size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_weights_t* w,
 
 /* query_rgb + batched_predict + bilinear residual (net:88-248) given the encoder feature map.
  *   feat_hwc   [H][W][C]                      encoder output, channels-last
- *   csattn     non-NULL iff nonlocal_channels > 0 (net:134-137)
+ *   csattn     non-NULL iff nonlocal_channels > 0 (net:134-137): host array of nonlocal_channels / C structs, one per
+ *              entry of multi_scale (net:44,85), written to consecutive C-column slices of the value rows
  *   x_lr_nchw  [3][H][W] normalised LR image for the residual (net:107-108); NULL = no residual
  *   coord/cell [Q][2] (y,x) fp32                                              (net:88-99)
  *   chunk      the reference's eval_bsize (net:238-246): only selects which query's cell feeds the

@@ -159,6 +159,31 @@ def test_csattn_c64_vs_golden(dev, tag):
     assert (y[0] - _t(fx['out'])).abs().max() < TOL
 
 
+@pytest.mark.parametrize('tag', ['s3', 's4', 's234'])
+def test_csattn_other_scales_vs_golden(dev, tag):
+    """scale entries 3 and 4 and the list [2, 3, 4] (arch_csnln.py:421-427,:436-528; unused by the configs): reflect mod-pad to
+    the scale, (3s)x(3s) value patches, 1/s bilinear downscale, stride-s transposed convolution as a gather, downx3 / downx4,
+    channel concatenation over the list."""
+    from ciaosr_amd import CrossScaleAttention
+    fx = load_golden('csattn_c8_' + tag)
+    att = CrossScaleAttention(channel=8, scale=[int(v) for v in fx['scale']])
+    att.load_state_dict({k[len('cs_attn.'):]: v for k, v in weights_from(fx).items()})
+    y = att.to(dev)(_t(fx['x']).to(dev)).cpu()
+    assert y.shape == _t(fx['out']).shape
+    assert (y - _t(fx['out'])).abs().max() < TOL
+
+
+def test_head_multi_scale_vs_golden(dev):
+    """multi_scale=[2, 3]: two non-local maps in the value rows (ciaosr_net.py:73-76, :134-137), staged and as-written routes."""
+    fx = load_golden('tiny_head_ms23')
+    g = _my_generator(8, (32, 32), weights_from(fx), dev, eval_bsize=None, multi_scale=[2, 3])
+    feat, coord, cell = _t(fx['feature']).to(dev), _t(fx['coord']).to(dev), _t(fx['cell']).to(dev)
+    out = g.query_rgb([feat], coord, cell).cpu()
+    assert (out - _t(fx['out'])).abs().max() < TOL
+    written = g._head.forward_as_written(feat[0], None, coord[0], cell[0]).cpu()
+    assert (written - _t(fx['out'])[0]).abs().max() < TOL
+
+
 def _csattn_golden(tag, dev):
     from ciaosr_amd.init_utils import seeded_state_dict
     fx = load_golden('csattn_c64_' + tag)

@@ -89,6 +89,20 @@ def test_csattn_small(tag):
     assert (y - _t(fx['out'])).abs().max() < TOL
 
 
+@pytest.mark.parametrize('tag', ['s3', 's4', 's234'])
+def test_csattn_other_scales(tag):
+    """scale entries 3 / 4 and the list [2, 3, 4] (arch_csnln.py:421-427,:436-528)."""
+    fx = load_golden('csattn_c8_' + tag)
+    y = orc.cross_scale_attention(_t(fx['x']), weights_from(fx), scales=tuple(int(v) for v in fx['scale']))
+    assert (y - _t(fx['out'])).abs().max() < TOL
+
+
+def test_tiny_head_multi_scale():
+    fx = load_golden('tiny_head_ms23')
+    out = orc.query_rgb(_t(fx['feature']), _t(fx['coord']), _t(fx['cell']), weights_from(fx), multi_scale=(2, 3))
+    assert (out - _t(fx['out'])).abs().max() < TOL
+
+
 @pytest.mark.parametrize('tag', ['48', '45x51', '64x64', '67x70'])
 def test_csattn_c64(tag):
     fx = load_golden('csattn_c64_' + tag)

@@ -217,6 +217,28 @@ def gen_csattn_big(ref):
              gain=np.array(1.5), shape=np.array([h, w]))
 
 
+def gen_csattn_scales(ref):
+    """CrossScaleAttention with scale entries 3, 4 and the list [2, 3, 4] (arch_csnln.py:421-427, :436-528; unused by the configs):
+    C = 8, sizes that need the reflect mod-pad for every scale."""
+    for tag, scale in (('s3', [3]), ('s4', [4]), ('s234', [2, 3, 4])):
+        att = ref.CrossScaleAttention(channel=8, scale=scale).eval()
+        seeded_init_(att, seed=6, gain=1.5)
+        x = randn((2, 8, 10, 13), 34)
+        with torch.no_grad():
+            y = att(x)
+        w_ = {('w.cs_attn.' + k): v for k, v in att.state_dict().items()}
+        save(f'csattn_c8_{tag}', x=x, out=y, scale=np.array(scale), **w_)
+    # and inside the head: multi_scale = [2, 3] widens imnet_q / imnet_v by 2C (ciaosr_net.py:73-76)
+    m = edsr_generator(ref, mid=8, blocks=1, hidden=(32, 32), eval_bsize=None, multi_scale=[2, 3]).eval()
+    sha = seeded_init_(m, seed=14, gain=1.0, head_gain=SQRT6)
+    feat = randn((1, 8, 7, 9), 24)
+    coord, cell, (ht, wt) = coords_for(7, 9, 2.7)
+    with torch.no_grad():
+        out = m.query_rgb([feat], coord, cell)
+    w = {('w.' + k): v for k, v in head_sd(m).items()}
+    save('tiny_head_ms23', feature=feat, coord=coord, cell=cell, out=out, sha=np.array(sha), target=np.array([ht, wt]), **w)
+
+
 def tile192_subset(out):
     """The stored part of a [1,3,768,768] output: every 4th pixel + an 8-pixel frame (tile borders are where
     the clamp, the zero-padded unfold and the cs_attn edge variants act)."""
@@ -345,7 +367,7 @@ def gen_swinir(ref):
          target=np.array([ht, wt]))
 
 
-ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, tiny_act=gen_tiny_head_act, head_c64=gen_head_c64,
+ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, tiny_act=gen_tiny_head_act, csattn_scales=gen_csattn_scales, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
            head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir)
 
