@@ -14,6 +14,13 @@
 
 namespace ciaosr {
 
+#ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/head_probe.py bf16): cycle stamps of workgroup phases
+__device__ unsigned long long g_hprobe16[4096 * 16];
+#define HPROBE16(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_hprobe16[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define HPROBE16(slot) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (HBM_ / 4);
 
+    HPROBE16(0);
     // ---- index math: row m = 32 j + q --------------------------------------------------------------------------
     int bad = 0;
     if (t < HBM_) {
@@ -335,9 +343,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
 
     // ================= phi_k =====================================================================
+    HPROBE16(1);
     build_rows16v2(X, p.k, s_kpix, s_t4, t);
+    HPROBE16(2);
     for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer16v2(X, p.k.frag_hidden[l], p.k.frag_hidden_lo[l], p.k.bias_hidden[l], w, lane);
     __syncthreads();
+    HPROBE16(3);
     if (table) {
         // logit = h4 . G[query pixel, key offset] + c (fp32 table, bf16 activations): 2 threads per row, 16 gathers in flight
         const int row = t >> 1, part = t & 1;
@@ -424,9 +435,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
     }
 
     // ================= phi_v =====================================================================
+    HPROBE16(4);
     build_rows16v2(X, p.v, s_kpix, s_t4, t);          // every wave is past its logit reads of X (barrier above)
+    HPROBE16(5);
     for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer16v2(X, p.v.frag_hidden[l], p.v.frag_hidden_lo[l], p.v.bias_hidden[l], w, lane);
     __syncthreads();
+    HPROBE16(6);
     {
         const int n_units = (p.v.n_out + 31) >> 5;
         const __amdgpu_buffer_rsrc_t rs_bv =
@@ -485,6 +499,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
             }
         }
     }
+    HPROBE16(7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,6 +691,12 @@ int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
 }  // namespace ciaosr
 
 using namespace ciaosr;
+
+#ifdef CIAOSR_PROBE
+extern "C" int ciaosr_debug_probe16_read(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::g_hprobe16), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t ciaosr_fragment_bf16_bytes(int N, int K) { return fragment_bf16_bytes(N, K); }
 

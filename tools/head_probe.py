@@ -17,14 +17,18 @@ import sys as _s
 HW_ = int(_s.argv[1]) if len(_s.argv) > 1 else 48
 lq, _ = synthetic_pair(HW_, HW_, 4)
 lq = lq.to(dev)
+MODE = _s.argv[2] if len(_s.argv) > 2 else 'fp32'          # fp32 | bf16 | bf16-single
+from ciaosr_amd import hip_ops
+OPT = hip_ops.Options('fp32') if MODE == 'fp32' else hip_ops.Options('bf16', bf16_single=int(MODE == 'bf16-single'))
 for _ in range(3):
-    model.restore(lq)
+    model.restore(lq, options=OPT)
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 4096
 buf = (C.c_ulonglong * (4096 * 16))()
-lib.ciaosr_debug_probe_read.restype = C.c_int
-assert lib.ciaosr_debug_probe_read(buf, 4096 * 16) == 0
+reader = lib.ciaosr_debug_probe_read if MODE == 'fp32' else lib.ciaosr_debug_probe16_read
+reader.restype = C.c_int
+assert reader(buf, 4096 * 16) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16)[:n].astype(np.int64)
 names = ['index math', 'build rows k', 'k hidden x3', 'logit + softmax', 'build rows v', 'v hidden x3', 'v out + epilogue']
 d = a[:, 1:8] - a[:, 0:7]
@@ -32,8 +36,12 @@ tot = a[:, 7] - a[:, 0]
 print(f'{n} workgroups; lifetime avg {tot.mean():.0f} ticks (min {tot.min()}, max {tot.max()})')
 for i, nm in enumerate(names):
     print(f'  {nm:20s} {d[:, i].mean():9.0f} ticks avg  ({100 * d[:, i].mean() / tot.mean():5.1f} %)')
-mfma = 64 * (3 * 256 + 3 * 256 + 5 * 128)           # MFMA issue cycles of one wave (32-row workgroup): 6 hidden layers + its 5 v-out units
-print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; four workgroups share a CU)')
+if MODE == 'fp32':
+    mfma = 64 * (3 * 256 + 3 * 256 + 5 * 128)       # MFMA issue cycles of one wave (32-row workgroup): 6 hidden layers + its 5 v-out units
+    print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; four workgroups share a CU)')
+else:
+    mfma = 32 * (6 * 128 + 5 * 64) * (1 if MODE == 'bf16-single' else 2)      # 128-row workgroup: 8 MFMAs per k-step and layer pass
+    print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; two workgroups share a CU)')
 # concurrency on a CU: how many workgroups ran on each CU and their span
 key = (a[:, 9] & 0xF) << 32 | (a[:, 8] & 0xFF00)
 for k in np.unique(key)[:3]:
