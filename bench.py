@@ -51,6 +51,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     """Algorithmic work of ALL launches of kernel `tag` in one step of this workload (one 48x48 tile):
     (amount, 'flop'|'byte').  FLOPs = 2 x MACs of the contraction as the reference writes it, minus the
     exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query."""
+    if tag.endswith('_f16'):               # IEEE-half kernels: the bf16 kernels' work and peak (same MFMA rate)
+        tag = tag[:-4] + '_bf16'
     D, Dv, R = 9 * C, 10 * C, Q * J
     side = HW ** 0.5
     dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
@@ -229,8 +231,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                    help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs, fp32 accumulation')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16'],
+                    help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
+                         'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
@@ -389,7 +392,7 @@ def main():
                     roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
                                 frac=round(ach / peak, 4), traffic=None)
                     roof['algorithmic_flop_per_launch'] = round(amount / launches_per_step)
-                    if kind == 'flop16' and not args.bf16_single and dominant in ('head_kv_fused_bf16', 'head_decode_fused_bf16', 'enc_dense_bf16'):
+                    if kind == 'flop16' and args.precision == 'bf16' and not args.bf16_single and dominant in ('head_kv_fused_bf16', 'head_decode_fused_bf16', 'enc_dense_bf16'):
                         # hi + lo weight pairs: the kernel issues two MFMAs per algorithmic product
                         roof['executed_mfma_flop_per_launch'] = 2 * roof['algorithmic_flop_per_launch']
                         roof['mfma_pipe_frac'] = round(2 * ach / peak, 4)
@@ -420,7 +423,8 @@ def main():
                 # passes, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_summary.py); null when the summary is absent
                 tag2fn = {'enc_dense_scatter': 'dense_scatter_small_kernel', 'enc_rdb_fused': 'rdb_fused_kernel',
                           'head_kv_fused': 'head_kv_fused_kernel', 'head_fused': 'head_fused_kernel',
-                          'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_bf16_kernel'}
+                          'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_h16_kernel',
+                          'head_kv_fused_f16': 'head_kv_fused_h16_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
                 pmc_path = os.path.join(REPO, 'profiles', f'r2_{unit}_pmc_hbm_traffic.json')
                 live_traffic = None
@@ -445,10 +449,13 @@ def main():
             'unit': 'Mpix/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True,
             'scaling': 'weak' if world == 1 else 'strong', 'vs_baseline': None,
-            'dtype': 'f32' if args.precision == 'fp32' else ('bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
-                      + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),
+            'dtype': 'f32' if args.precision == 'fp32' else (
+                'f16 (IEEE half) MFMA inputs, saturating conversions, fp32 accumulate, in the head, the dense layers and the cs_attn contractions'
+                if args.precision == 'f16' else
+                'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
+                + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),
             'data': 'synthetic',
-            'config': {'workload': wl_desc + (', fp32' if args.precision == 'fp32' else ', bf16 mode')
+            'config': {'workload': wl_desc + (', fp32' if args.precision == 'fp32' else f', {args.precision} mode')
                        + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs, '
                                                  'RCCL gather of the RGB slices' if args.workload == 'c2q' else
                                                  f' (C4); tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world}), RCCL gather of '
@@ -484,6 +491,9 @@ def main():
                 o16 = hip_ops.Options('bf16')
                 model.restore(tl, options=o16)
                 extras['c3_tile_bf16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=o16), 3, dev), 3)
+                oh = hip_ops.Options('f16')
+                model.restore(tl, options=oh)
+                extras['c3_tile_f16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=oh), 3, dev), 3)
                 extras['c3_tile_fp32_ms'] = round(time_steps(lambda: model.restore(tl), 3, dev), 3)
                 c2 = synthetic_pair(48, 48, scale)[0].to(dev)
                 for _ in range(3):

@@ -108,7 +108,10 @@ SIGNATURES = {
     'ciaosr_make_coord_cell_f32': (_I, [_P, _P, _I, _I, _P]),
     'ciaosr_fragment_floats': (_S, [_I, _I]),
     'ciaosr_pack_fragments_f32': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ciaosr_cs_attn_f16': (_I, [_P, _I, _I, _I, C.POINTER(CsAttnWeightsT), _P, _I, _O, _P, _S, _P]),
     'ciaosr_fragment_bf16_bytes': (_S, [_I, _I]),
+    'ciaosr_fragment_f16_bytes': (_S, [_I, _I]),
+    'ciaosr_pack_fragments_f16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_bf16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
@@ -122,9 +125,12 @@ SIGNATURES = {
                                      _I, _I, _P, _O, _P, _S, _P]),
     'ciaosr_head_forward_bf16': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
                                       _I, _I, _P, _O, _P, _S, _P]),
+    'ciaosr_head_forward_f16': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,
+                                      _I, _I, _P, _O, _P, _S, _P]),
     'ciaosr_rdn_workspace_bytes': (_S, [_I, _I, C.POINTER(RdnWeightsT)]),
     'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
     'ciaosr_rdn_forward_bf16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
+    'ciaosr_rdn_forward_f16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
     'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),
     'ciaosr_edsr_forward_f32': (_I, [_P, _I, _I, C.POINTER(EdsrWeightsT), _P, _P, _S, _P]),
     'ciaosr_swinir_workspace_bytes': (_S, [_I, _I, C.POINTER(SwinirWeightsT)]),

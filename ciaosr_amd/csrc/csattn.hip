@@ -67,7 +67,7 @@ extern "C" size_t ciaosr_cs_attn_workspace_bytes_scale(int H, int W, int C, int 
 }
 
 static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w, float* out, int ld_out,
-                   const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
+                   const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, Prec prec) {
     CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
     const int C = w->channels;
     const int sc = w->scale ? w->scale : 2;
@@ -118,25 +118,27 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     // composed fold+down tail from this many (padded) LR pixels on: per-call option, default 4096
     const int composed_min = opt && opt->csa_composed_min ? opt->csa_composed_min : 4096;
     const bool composed = sc == 2 && w->w_down_masked && composed_min > 0 && HWp >= composed_min;     // the composed tail is scale 2's
-    // bf16 mode (big maps, composed tail): Q.K^T and P.V' on the bf16 MFMA (gemm_bf16.hip); logits and softmax in fp32,
-    // probabilities rounded to bf16; 1x1 convolutions, the partial down-convolutions and the final gather stay fp32
+    // 16-bit modes (big maps, composed tail): Q.K^T and P.V' on the bf16 / f16 MFMA (gemm_h16.hip); logits and softmax in fp32,
+    // probabilities rounded to 16 bits; 1x1 convolutions, the partial down-convolutions and the final gather stay fp32
     const size_t qk16_bytes = ((size_t)HWp + p.L) * 9 * p.Ch * 2 + 512;
-    if (bf16 && composed && (9 * p.Ch) % 8 == 0 && (p.Lld & 3) == 0 &&
+    if (prec != kF32 && composed && (9 * p.Ch) % 8 == 0 && (p.Lld & 3) == 0 &&
         qk16_bytes <= p.n_Y * sizeof(float) && (size_t)25 * C * p.Lld8 * 2 <= p.n_V * sizeof(float)) {
         const int Hh = p.Hp / 2, Wh = p.Wp / 2, Kq = 9 * p.Ch;
+        const H16Ops& h = h16_ops(prec);
+        const bool f16 = prec == kF16;
         unsigned short* Qb = reinterpret_cast<unsigned short*>(Y);
         unsigned short* Kb = Qb + round_up((size_t)HWp * Kq, 128);
         unsigned short* VpT = reinterpret_cast<unsigned short*>(V);
-        RUN(cast_rows_bf16(Qp, Kq, Qb, Kq, HWp, Kq, s));
-        RUN(cast_rows_bf16(Kn, Kq, Kb, Kq, p.L, Kq, s));
-        RUN(gemm_bf16_nt(Qb, Kq, Kb, Kq, S, p.Lld, false, HWp, p.L, Kq, w->softmax_scale, s, "csa_scores_bf16"));
-        RUN(softmax_rows_bf16(S, HWp, p.L, p.Lld, P16, p.Lld8, s));
+        RUN(h.cast_rows(Qp, Kq, Qb, Kq, HWp, Kq, s));
+        RUN(h.cast_rows(Kn, Kq, Kb, Kq, p.L, Kq, s));
+        RUN(h.gemm_nt(Qb, Kq, Kb, Kq, S, p.Lld, false, HWp, p.L, Kq, w->softmax_scale, s, f16 ? "csa_scores_f16" : "csa_scores_bf16"));
+        RUN(h.softmax_rows(S, HWp, p.L, p.Lld, P16, p.Lld8, s));
         RUN(patch_rows(E, C, p.Hp, p.Wp, C, 3, 2, 3, Hh + 3, Wh + 3, PE, 9 * C, 0, 0.f, s, "csa_patch_down"));
         RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
                      CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));
-        RUN(csa_gather_vprime_t_bf16(Pc, Hh, Wh, C, VpT, p.Lld8, s));
+        RUN(csa_gather_vprime_t_h16(Pc, Hh, Wh, C, VpT, p.Lld8, f16, s));
         // all 25C columns for every row (the 9C edge-variant columns are only read for row 0 / column 0 pixels)
-        RUN(gemm_bf16_nt(P16, p.Lld8, VpT, p.Lld8, O, 25 * C, false, HWp, 25 * C, p.Lld8, 1.f, s, "csa_attn_v_bf16"));
+        RUN(h.gemm_nt(P16, p.Lld8, VpT, p.Lld8, O, 25 * C, false, HWp, 25 * C, p.Lld8, 1.f, s, f16 ? "csa_attn_v_f16" : "csa_attn_v_bf16"));
         RUN(csa_gather_out(O, O + 16 * C, O + 20 * C, O + 24 * C, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 25L * C, 25L * C,
                            (long)p.Wp * 25 * C, s));
         return CIAOSR_OK;
@@ -187,11 +189,17 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
 extern "C" int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
                                   float* out, int ld_out, const ciaosr_options_t* opt, void* workspace,
                                   size_t workspace_bytes, void* stream) {
-    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, false);
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, kF32);
 }
 
 extern "C" int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
                                    float* out, int ld_out, const ciaosr_options_t* opt, void* workspace,
                                    size_t workspace_bytes, void* stream) {
-    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, true);
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, kBF16);
+}
+
+extern "C" int ciaosr_cs_attn_f16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                                  float* out, int ld_out, const ciaosr_options_t* opt, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    return cs_attn(feat_hwc, ld_feat, H, W, w, out, ld_out, opt, workspace, workspace_bytes, stream, kF16);
 }

@@ -1,4 +1,5 @@
-// bf16-MFMA dense-block convolution (precision mode "bf16" of the RDN trunk, big tiles only).
+// 16-bit-MFMA dense-block convolution (precision modes "bf16" / "f16" of the RDN trunk, big tiles only; compiled once per
+// element type, h16_util.h -- "bf16" below = the 16-bit element type of the build).
 //
 // One 3x3 dense layer l of a residual dense block (mmedit RDB.layers[l].conv over cat(x, d_0 .. d_{l-1}),
 // called from ciaosr_net.py:330-337) in GATHER form: K = 9 * 64 (l+1), N = 64 output channels,
@@ -24,13 +25,15 @@
 //   * the K-slices are summed through LDS once per layer (fixed order: deterministic) in the epilogue.
 // Swapped operands (weights = A, activations = B): a lane owns one pixel and 4x4 consecutive channels.
 
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "ops.h"
 
 namespace ciaosr {
+namespace CIAOSR_H16_NS {
+
+constexpr bool kF16 = CIAOSR_F16 != 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int DT = 12;                       // output tile edge (pixels)
@@ -47,7 +50,7 @@ constexpr int DMT = 5;                       // 32-pixel MFMA tiles per workgrou
 constexpr size_t kDenseLds = 81920;          // max(2 patches, K-slice reduction scratch 4 x 5 x 4 x 64 x 16 B)
 constexpr unsigned kOobD = 0xFFFFFFF0u;
 
-struct DenseBf16P {
+struct DenseH16P {
     const unsigned short* xb; int ldxb;      // bf16 feature buffer [HW][ldxb], 64-channel groups
     unsigned xb_bytes;
     int H, W, tiles_x;
@@ -60,13 +63,7 @@ struct DenseBf16P {
     int col_out;
 };
 
-__device__ __forceinline__ unsigned short f2bf_d(float f) {    // round-to-nearest-even
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
-__global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
+__global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int ty0 = (blockIdx.x / p.tiles_x) * DT, tx0 = (blockIdx.x % p.tiles_x) * DT;
@@ -140,14 +137,14 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
     __syncthreads();
 
     const int G = p.groups;
-    bf16x8 b[2][DMT];                        // activation fragments of the current tap and the next one
+    uint4 b[2][DMT];                         // activation fragments of the current tap and the next one
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const bool more = g + 1 < G;
         const unsigned char* pb = lds + (g & 1) * DPATCH;
 #pragma unroll
         for (int r = 0; r < DMT; ++r)
-            b[0][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + poff[r] - DROW - DPS));      // tap 0
+            b[0][r] = *reinterpret_cast<const uint4*>(pb + poff[r] - DROW - DPS);      // tap 0
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             {   // weights two taps ahead
@@ -167,20 +164,20 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
                 const int toff = (((tap + 1) / 3 - 1) * DROW) + (((tap + 1) % 3 - 1) * DPS);
 #pragma unroll
                 for (int r = 0; r < DMT; ++r)
-                    b[(tap + 1) & 1][r] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(pb + poff[r] + toff));
+                    b[(tap + 1) & 1][r] = *reinterpret_cast<const uint4*>(pb + poff[r] + toff);
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, wq[tap % 3][nt]);
+                const uint4 a = wq[tap % 3][nt];
 #pragma unroll
-                for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[tap & 1][r], acc[nt][r], 0, 0, 0);
+                for (int r = 0; r < DMT; ++r) acc[nt][r] = mfma_h16<kF16>(a, b[tap & 1][r], acc[nt][r]);
             }
             if (has_lo) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, wlq[tap % 3][nt]);
+                    const uint4 a = wlq[tap % 3][nt];
 #pragma unroll
-                    for (int r = 0; r < DMT; ++r) acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[tap & 1][r], acc[nt][r], 0, 0, 0);
+                    for (int r = 0; r < DMT; ++r) acc[nt][r] = mfma_h16<kF16>(a, b[tap & 1][r], acc[nt][r]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
                 const size_t pix = (size_t)y * p.W + x;
                 *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
                 *reinterpret_cast<uint2*>(p.xb_out + pix * p.ldxb + p.col_out + co) =
-                    pack_bf16x4(v.x, v.y, v.z, v.w);
+                    pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
             }
         }
         __syncthreads();
@@ -229,7 +226,7 @@ __global__ __launch_bounds__(256) void dense_bf16_kernel(DenseBf16P p) {
 }
 
 // fp32 columns [col, col+64) of X -> the same columns of the bf16 copy
-__global__ void cast_group_bf16_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ Xb, int ldxb, int col,
+__global__ void cast_group_h16_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ Xb, int ldxb, int col,
                                        long HW) {
     const long n = HW * 16;                   // float4 units
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -237,27 +234,27 @@ __global__ void cast_group_bf16_kernel(const float* __restrict__ X, int ldx, uns
         const int c = (int)(i & 15) * 4;
         const float4 v = *reinterpret_cast<const float4*>(X + pix * ldx + col + c);
         *reinterpret_cast<uint2*>(Xb + pix * ldxb + col + c) =
-            pack_bf16x4(v.x, v.y, v.z, v.w);
+            pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
     }
 }
 
-int dense_bf16_tiles(int H, int W) { return ceil_div(H, DT) * ceil_div(W, DT); }
+int dense_h16_tiles(int H, int W) { return ceil_div(H, DT) * ceil_div(W, DT); }
 
-int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s) {
-    ProfScope prof("enc_cast_bf16", s);
+int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s) {
+    ProfScope prof("enc_cast" CIAOSR_H16_SUFFIX, s);
     const long n = HW * 16;
     int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(cast_group_bf16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, X, ldx, Xb, ldxb, col, HW);
-    return launch_status("cast_group_bf16");
+    hipLaunchKernelGGL(cast_group_h16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, X, ldx, Xb, ldxb, col, HW);
+    return launch_status("cast_group" CIAOSR_H16_SUFFIX);
 }
 
 // dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb)
-int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
+int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
                      const float* bias, hipStream_t s) {
     CIAOSR_CHECK_ARG(X && Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);
     const size_t xb_bytes = (size_t)H * W * ldxb * 2;
     CIAOSR_CHECK_ARG(xb_bytes < 0xFFFFFF00ull);
-    DenseBf16P p;
+    DenseH16P p;
     p.xb = Xb; p.ldxb = ldxb; p.xb_bytes = (unsigned)xb_bytes;
     p.H = H; p.W = W; p.tiles_x = ceil_div(W, DT);
     p.groups = l + 1;
@@ -265,10 +262,11 @@ int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int
     p.wf_lo = reinterpret_cast<const uint4*>(frag16_lo);
     p.bias = bias;
     p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
-    CIAOSR_BIG_LDS(dense_bf16_kernel, kDenseLds);
-    ProfScope prof("enc_dense_bf16", s);
-    hipLaunchKernelGGL(dense_bf16_kernel, dim3(dense_bf16_tiles(H, W)), dim3(256), kDenseLds, s, p);
-    return launch_status("dense_bf16");
+    CIAOSR_BIG_LDS(dense_h16_kernel, kDenseLds);
+    ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
+    hipLaunchKernelGGL(dense_h16_kernel, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+    return launch_status("dense" CIAOSR_H16_SUFFIX);
 }
 
+}  // namespace CIAOSR_H16_NS
 }  // namespace ciaosr

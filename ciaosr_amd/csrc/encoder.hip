@@ -13,12 +13,6 @@ int conv2d_hwc(const float* src, int ld_src, int H, int W, int Cin, const float*
 int dense_scatter_step(float* X, int ldx, int H, int W, int step, int num_layers, const float* wgt, const float* bias_all,
                        float* acc_buf, float* partial, size_t partial_floats, hipStream_t s);
 
-// dense_bf16.hip
-int dense_bf16_tiles(int H, int W);
-int cast_group_bf16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);
-int dense_layer_bf16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
-                     const float* bias, hipStream_t s);
-
 // dense_scatter_f32.hip
 int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layers, const float* frag, const float* bias_all,
                         float* acc_buf, hipStream_t s);
@@ -78,7 +72,8 @@ extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weig
 }
 
 static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
-                       const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, bool bf16) {
+                       const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, Prec prec) {
+    const bool bf16 = prec != kF32;      // a 16-bit MFMA mode (bf16 or f16 entry)
     // route thresholds (per-call options; defaults: halo-resident dense layers from 128 tiles of 12x12 pixels on, small-map
     // kernels up to 18432 pixels = 128 such tiles)
     const int min_tiles = opt && opt->dense_min_tiles ? opt->dense_min_tiles : 128;
@@ -105,9 +100,9 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     float* part = ar.take<float>(pf);
     unsigned short* Xb = reinterpret_cast<unsigned short*>(ar.take<float>(HW * cb / 2 + 64));
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
-    // bf16 mode: the dense layers (97 % of the trunk's MACs) run on the bf16 MFMA when the map is big enough to give
-    // every CU a tile (dense_bf16.hip); first/last convolutions, LFF/GFF 1x1 and all residual sums stay fp32
-    bool dense16 = bf16 && C == 64 && G == 64 && min_tiles > 0 && dense_bf16_tiles(H, W) >= min_tiles;
+    // 16-bit modes: the dense layers (97 % of the trunk's MACs) run on the bf16 / f16 MFMA when the map is big enough to give
+    // every CU a tile (dense_h16.hip); first/last convolutions, LFF/GFF 1x1 and all residual sums stay fp32
+    bool dense16 = bf16 && C == 64 && G == 64 && min_tiles > 0 && b16::dense_h16_tiles(H, W) >= min_tiles;
     if (bf16)
         for (int i = 0; i < NB * NL && dense16; ++i) dense16 = w->dense[i].frag16 != nullptr;
     // big maps, fp32: halo-resident gather-form dense layers (dense_f32.hip) instead of the scatter form
@@ -122,11 +117,11 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
         float* x = X[b & 1];
         float* xn = X[(b + 1) & 1];
         if (dense16) {
-            RUN(cast_group_bf16(x, cb, Xb, cb, 0, (long)HW, s));
+            RUN(h16_ops(prec).cast_group(x, cb, Xb, cb, 0, (long)HW, s));
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
-                RUN(dense_layer_bf16(x, cb, Xb, cb, H, W, l, c.frag16, (opt && opt->bf16_single) ? nullptr : c.frag16_lo, c.bias, s));
+                RUN(h16_ops(prec).dense_layer(x, cb, Xb, cb, H, W, l, c.frag16, (prec == kF16 || (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, s));
             }
         } else if (dense32) {
             for (int l = 0; l < NL; ++l) {
@@ -180,13 +175,19 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
 extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
                                       float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
                                       size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, false);
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF32);
 }
 
 extern "C" int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
                                        float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, true);
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kBF16);
+}
+
+extern "C" int ciaosr_rdn_forward_f16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
+                                      float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF16);
 }
 
 extern "C" size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w) {

@@ -1,5 +1,6 @@
-// bf16-MFMA NT GEMM (precision mode "bf16" of CrossScaleAttention's two big contractions):
-//   C[M][N] = alpha * A[M][K] . B[N][K]^T,  A and B bf16 in memory, fp32 accumulation, C fp32 or bf16.
+// 16-bit-MFMA NT GEMM (precision modes "bf16" / "f16" of CrossScaleAttention's two big contractions; compiled once per
+// element type, h16_util.h -- "bf16" below = the 16-bit element type of the build):
+//   C[M][N] = alpha * A[M][K] . B[N][K]^T,  A and B 16-bit in memory, fp32 accumulation, C fp32 or 16-bit.
 // Used for the correlation scores Q.K^T (arch_csnln.py:497-499, K = 9C/2) and the attention-weighted patch sum
 // P.V' (arch_csnln.py:511 in the composed form of patch_ops.hip, K = L) when the host asks for bf16.
 //
@@ -18,15 +19,18 @@
 // Swapped MFMA operands (B rows = A operand, A rows = B operand): a lane owns one output row and 4 consecutive
 // columns per accumulator quad, so the epilogue stores 16 B (fp32) / 8 B (bf16) pieces.
 // Out-of-range rows / k-chunks are buffer loads with an out-of-range offset (return 0, no branches).
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "ops.h"
 
 namespace ciaosr {
 
-bool softmax_rows_reg_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s);   // patch_ops.hip
+bool softmax_rows_reg_h16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, bool f16, hipStream_t s);   // patch_ops.hip
+
+namespace CIAOSR_H16_NS {
+
+constexpr bool kF16 = CIAOSR_F16 != 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GM = 256, GN = 128, GK = 32;
@@ -47,13 +51,7 @@ struct Gemm16P {
     int tiles_n, n_wg;
 };
 
-__device__ __forceinline__ unsigned short f2bf_g(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
+__global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     unsigned char* As = lds16;                    // [2][GM][GRS]
     unsigned char* Bs = lds16 + 2 * GA_T;         // [2][GN][GRS]
@@ -133,16 +131,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
 #pragma unroll
                 for (int ks = 0; ks < GK / 16; ++ks) {
                     const int co = ((2 * ks + lh) ^ lswz) * 16;
-                    bf16x8 fb[2], fa[4];
+                    uint4 fb[2], fa[4];
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) fb[nt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + co));
+                    for (int nt = 0; nt < 2; ++nt) fb[nt] = *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + co);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) fa[mt] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(a + mt * 32 * GRS + co));
+                    for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(a + mt * 32 * GRS + co);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[nt], fa[mt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = mfma_h16<kF16>(fb[nt], fa[mt], acc[mt][nt]);
                 }
                 if (k + 1 < nk) store_stage(half ^ 1, half ^ 1);       // k-tile k + 1: requested one iteration ago
                 __syncthreads();
@@ -166,12 +164,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
                 if (n + 3 >= p.N) {                                        // ragged last columns
                     const float v[4] = {v0, v1, v2, v3};
                     for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                        if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = f2bf_g(v[e]);
+                        if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = to_h16<kF16>(v[e]);
                         else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = v[e];
                     }
                 } else if (p.c_bf16)
                     *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
-                        pack_bf16x4(v0, v1, v2, v3);
+                        pack_h16x4<kF16>(v0, v1, v2, v3);
                 else
                     *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
             }
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(Gemm16P p) {
 }
 
 // fp32 rows -> bf16 rows (first `cols` columns, cols % 4 == 0); pad columns [cols, ld_dst) are zeroed
-__global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int ld_src, unsigned short* __restrict__ dst, int ld_dst,
+__global__ void cast_rows_h16_kernel(const float* __restrict__ src, int ld_src, unsigned short* __restrict__ dst, int ld_dst,
                                       long rows, int cols) {
     const int c4n = ld_dst >> 2;
     const long n = rows * c4n;
@@ -189,12 +187,12 @@ __global__ void cast_rows_bf16_kernel(const float* __restrict__ src, int ld_src,
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < cols) v = *reinterpret_cast<const float4*>(src + r * ld_src + c);
         *reinterpret_cast<uint2*>(dst + r * ld_dst + c) =
-            pack_bf16x4(v.x, v.y, v.z, v.w);
+            pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
     }
 }
 
 // row softmax of fp32 logits S [rows][ld] (first L columns) -> bf16 probabilities P [rows][ldp]; pad columns zeroed
-__global__ __launch_bounds__(256) void softmax_rows_bf16_kernel(const float* __restrict__ S, long rows, int L, int ld,
+__global__ __launch_bounds__(256) void softmax_rows_h16_kernel(const float* __restrict__ S, long rows, int L, int ld,
                                                                 unsigned short* __restrict__ P, int ldp) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -236,11 +234,11 @@ __global__ __launch_bounds__(256) void softmax_rows_bf16_kernel(const float* __r
             v.z = c + 2 < L ? expf(x.z - m) / sum : 0.f;
             v.w = c + 3 < L ? expf(x.w - m) / sum : 0.f;
         }
-        po[t] = pack_bf16x4(v.x, v.y, v.z, v.w);
+        po[t] = pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
     }
 }
 
-int gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,
+int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,
                  int K, float alpha, hipStream_t s, const char* tag) {
     if (M <= 0 || N <= 0) return CIAOSR_OK;
     CIAOSR_CHECK_ARG(A && B && C && K > 0 && (K & 7) == 0);
@@ -253,27 +251,28 @@ int gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int 
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
     p.n_wg = ceil_div(M, GM) * p.tiles_n;
-    CIAOSR_BIG_LDS(gemm_bf16_kernel, kGemm16Lds);
-    ProfScope prof(tag ? tag : "gemm_bf16", s);
-    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
-    return launch_status("gemm_bf16");
+    CIAOSR_BIG_LDS(gemm_h16_kernel, kGemm16Lds);
+    ProfScope prof(tag ? tag : "gemm" CIAOSR_H16_SUFFIX, s);
+    hipLaunchKernelGGL(gemm_h16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    return launch_status("gemm" CIAOSR_H16_SUFFIX);
 }
 
-int cast_rows_bf16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s) {
+int cast_rows_h16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s) {
     CIAOSR_CHECK_ARG(src && dst && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && (cols & 3) == 0 && cols <= ld_dst);
-    ProfScope prof("cast_rows_bf16", s);
+    ProfScope prof("cast_rows" CIAOSR_H16_SUFFIX, s);
     const long n = rows * (ld_dst >> 2);
     int grid = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(cast_rows_bf16_kernel, dim3(grid > 8192 ? 8192 : grid), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
-    return launch_status("cast_rows_bf16");
+    hipLaunchKernelGGL(cast_rows_h16_kernel, dim3(grid > 8192 ? 8192 : grid), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+    return launch_status("cast_rows" CIAOSR_H16_SUFFIX);
 }
 
-int softmax_rows_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s) {
+int softmax_rows_h16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s) {
     CIAOSR_CHECK_ARG(S && P && (ld & 3) == 0 && (ldp & 3) == 0 && ldp <= ld && L <= ldp);
     ProfScope prof("softmax_rows", s);
-    if (softmax_rows_reg_bf16(S, rows, L, ld, P, ldp, s)) return launch_status("softmax_rows_reg_bf16");
-    hipLaunchKernelGGL(softmax_rows_bf16_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, P, ldp);
-    return launch_status("softmax_rows_bf16");
+    if (softmax_rows_reg_h16(S, rows, L, ld, P, ldp, kF16, s)) return launch_status("softmax_rows_reg" CIAOSR_H16_SUFFIX);
+    hipLaunchKernelGGL(softmax_rows_h16_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, P, ldp);
+    return launch_status("softmax_rows" CIAOSR_H16_SUFFIX);
 }
 
+}  // namespace CIAOSR_H16_NS
 }  // namespace ciaosr

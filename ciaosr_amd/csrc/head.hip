@@ -126,9 +126,10 @@ extern "C" size_t ciaosr_head_workspace_bytes(int H, int W, const ciaosr_head_we
 static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                         const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw, const float* coord,
                         const float* cell, int Q, int chunk, float* rgb, const ciaosr_options_t* opt, void* workspace,
-                        size_t workspace_bytes, void* stream_, bool bf16) {
+                        size_t workspace_bytes, void* stream_, Prec prec) {
+    const bool bf16 = prec != kF32;                  // a 16-bit MFMA mode (bf16 or f16 entry)
     const int route = opt ? opt->head_route : 0;
-    const bool lo = !(opt && opt->bf16_single);      // bf16 entry: hi + lo weight pairs unless single is asked for
+    const bool lo = prec == kBF16 && !(opt && opt->bf16_single);      // bf16 entry: hi + lo weight pairs unless single is asked for
     CIAOSR_CHECK_ARG(!opt || opt->reserved[0] == 0);
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
@@ -181,7 +182,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     else
         RUN(patch_rows(feat_hwc, p.C, H, W, p.C, 3, 1, 1, H, W, U, p.Dv, 0, 0.f, s, "head_unfold"));
     for (int i = 0; i < n_scales; ++i)     // one C-column slice per scale, in the order of multi_scale (csa:528 torch.cat(res_y, dim=1))
-        RUN((bf16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn + i, U + p.D + (size_t)i * p.C, p.Dv, opt, csa_ws,
+        RUN((prec == kF16 ? ciaosr_cs_attn_f16 : prec == kBF16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn + i, U + p.D + (size_t)i * p.C, p.Dv, opt, csa_ws,
                                                               p.csa_bytes, stream_));
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     if (gemm_small_ok(p.HW, p.wk0, p.D, p.Dv, w->k.ld[0]) && gemm_small_ok(p.HW, p.wv0, p.Dv, p.Dv, w->v.ld[0]) && p.HW <= 4096) {
@@ -206,13 +207,13 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         const int last = w->k.n_layers - 1;
         const long total = (long)p.HW * 9;
         const bool table16 = bf16 && (p.D & 7) == 0;   // bf16 mode: the table GEMM on the bf16 MFMA (fp32 table out)
-        if (table16) RUN(transpose_cast_bf16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, s));
+        if (table16) RUN(transpose_cast_h16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, prec == kF16, s));
         for (long r0 = 0; r0 < total; r0 += kQkChunk) {
             const int nr = (int)((total - r0) < kQkChunk ? (total - r0) : kQkChunk);
-            RUN(qk_rows(U, p.Dv, p.D, H, W, r0, nr, w->k.bias[last], QK, G, kLdG, table16, s));
+            RUN(qk_rows(U, p.Dv, p.D, H, W, r0, nr, w->k.bias[last], QK, G, kLdG, table16 ? (int)prec : 0, s));
             if (table16) {
-                RUN(gemm_bf16_nt(reinterpret_cast<const unsigned short*>(QK), p.D, W5T, p.D, G + (size_t)r0 * kLdG, kLdG, false, nr,
-                                 256, p.D, 1.f, s, "head_logit_table_bf16"));
+                RUN(h16_ops(prec).gemm_nt(reinterpret_cast<const unsigned short*>(QK), p.D, W5T, p.D, G + (size_t)r0 * kLdG, kLdG, false, nr,
+                                          256, p.D, 1.f, s, prec == kF16 ? "head_logit_table_f16" : "head_logit_table_bf16"));
                 continue;
             }
             // G[r][n] = sum_d QK[r][d] * W5k[d][n]: the Linear weight [D][256] is the [K][N] operand as stored
@@ -235,7 +236,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             kp.Z = Z; kp.ldz = p.Dv;
             kp.rows_per_wg = opt ? opt->kv_rows : 0;
             kp.G = use_table ? G : nullptr; kp.ldg = kLdG; kp.g_bytes = (unsigned)((size_t)p.HW * 9 * kLdG * sizeof(float));
-            RUN(bf16 ? head_kv_fused_bf16(kp, s) : head_kv_fused(kp, s));
+            RUN(bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;
             qp.Z = Z; qp.ldz = p.Dv; qp.Dv = p.Dv;
@@ -252,7 +253,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             qp.b_last = mq.bias[mq.n_layers - 1];
             qp.rows_per_wg = opt ? opt->decode_rows : 0;
             qp.x_lr = x_lr_nchw; qp.coord = coord; qp.q0 = q0; qp.nq = nq; qp.H = H; qp.W = W; qp.rgb = rgb;
-            RUN(bf16 ? head_decode_fused_bf16(qp, s) : head_decode_fused(qp, s));
+            RUN(bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
             continue;
         }
         HeadRowsP hp;
@@ -296,7 +297,7 @@ extern "C" int ciaosr_head_forward_f32(const float* feat_hwc, int H, int W, cons
                                        const float* coord, const float* cell, int Q, int chunk, float* rgb,
                                        const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
     return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, opt, workspace, workspace_bytes,
-                        stream, false);
+                        stream, kF32);
 }
 
 extern "C" int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
@@ -304,7 +305,15 @@ extern "C" int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, con
                                         const float* coord, const float* cell, int Q, int chunk, float* rgb,
                                         const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
     return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, opt, workspace, workspace_bytes,
-                        stream, true);
+                        stream, kBF16);
+}
+
+extern "C" int ciaosr_head_forward_f16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                                       const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                                       const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                                       const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream) {
+    return head_forward(feat_hwc, H, W, w, csattn, x_lr_nchw, coord, cell, Q, chunk, rgb, opt, workspace, workspace_bytes,
+                        stream, kF16);
 }
 
 // ---- staged MLPRefiner (mlp_refiner.py:87-102), layer by layer, no hoist -------------------------------------

@@ -16,7 +16,7 @@
 // layers run in place: all waves finish reading X, barrier, write bias+ReLU results, barrier.
 // Four 32-row workgroups per CU (34.5 KB of LDS each) overlap each other's epilogue/barrier bubbles with MFMAs.
 
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "index_math.h"
 #include "ops.h"
 

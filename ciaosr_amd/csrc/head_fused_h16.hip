@@ -1,18 +1,22 @@
-// bf16-MFMA variant of the fused head kernels (precision mode 1): MFMA inputs bf16, fp32 accumulate;
-// coordinates, index math, layer-0 tables, logits, softmax, the attention-weighted sum and the decode output
-// stay fp32.  v_mfma_f32_32x32x16_bf16 runs 16x the fp32 MFMA rate, which moves the kernel
-// from the MFMA roofline to the per-CU weight stream out of L2, so the row tile doubles to 128 rows
-// (= 32 queries x 4 key samples) per workgroup: bf16 activations [128][264] are 66 KB, two workgroups still
-// fit a CU, and every weight fragment fetched is used for twice as many rows.
+// 16-bit-MFMA variant of the fused head kernels (precision modes "bf16" and "f16"; this file is compiled once per element
+// type, h16_util.h): MFMA inputs 16-bit, fp32 accumulate; coordinates, index math, layer-0 tables, logits, softmax, the
+// attention-weighted sum and the decode output stay fp32.  v_mfma_f32_32x32x16_{bf16,f16} runs 16x
+// the fp32 MFMA rate, which moves the kernel from the MFMA roofline to the per-CU weight stream out of L2, so the row
+// tile doubles to 128 rows (= 32 queries x 4 key samples) per workgroup: 16-bit activations [128][264] are 66 KB, two
+// workgroups still fit a CU, and every weight fragment fetched is used for twice as many rows.
+// ("bf16" in the comments below = the 16-bit element type of the build.)
 //
 // Same structure as head_fused.hip: swapped MFMA operands (weights = A operand from L2 in pre-packed fragment
 // order [n_tile][k16][lane][8 bf16], activations = B operand from LDS via ds_read_b128), a lane owns one
 // activation row and 4x4 consecutive output channels, hidden layers in place in LDS.
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "index_math.h"
 #include "ops.h"
 
 namespace ciaosr {
+namespace CIAOSR_H16_NS {
+
+constexpr bool kF16 = CIAOSR_F16 != 0;
 
 #ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/head_probe.py bf16): cycle stamps of workgroup phases
 __device__ unsigned long long g_hprobe16[4096 * 16];
@@ -22,7 +26,6 @@ __device__ unsigned long long g_hprobe16[4096 * 16];
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int HBM_ = 128;          // rows per workgroup
@@ -32,12 +35,8 @@ constexpr int HLD = HH + 8;        // LDS row stride in bf16 (528 B: conflict-fr
 constexpr int HKS = HH / 16;       // k-steps of 16 per 256-wide layer
 constexpr unsigned kOobH = 0xFFFFFFF0u;
 
-__device__ __forceinline__ unsigned short f2bf(float f) {      // round-to-nearest-even
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ unsigned pack2(float a, float b) { return pack_bf16x2(a, b); }
+__device__ __forceinline__ unsigned pack2(float a, float b) { return pack_h16x2<kF16>(a, b); }
+__device__ __forceinline__ unsigned pack_relu2(float a, float b) { return pack_relu_h16x2<kF16>(a, b); }
 
 __device__ __forceinline__ float4 hload4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
@@ -52,7 +51,7 @@ __device__ __forceinline__ void hstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned by
 // ---- fragment packing: W [N][ld] fp32 (K valid columns) -> P[nt][ks][lane][8 bf16]; lane (i = lane&31,
 // g = lane>>5) holds W[32nt + i][16ks + 8g .. 16ks + 8g + 7]; zero padded.
 // residual != 0: the element packed is w - bf16(w) (the low half of the hi + lo pair) instead of w
-__global__ void pack_fragments_bf16_kernel(const float* __restrict__ W, int ld, int N, int K, uint4* __restrict__ P,
+__global__ void pack_fragments_h16_kernel(const float* __restrict__ W, int ld, int N, int K, uint4* __restrict__ P,
                                            int n_tiles, int nks, int residual) {
     const long total = (long)n_tiles * nks * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -64,7 +63,7 @@ __global__ void pack_fragments_bf16_kernel(const float* __restrict__ W, int ld, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             v[e] = (n < N && k + e < K) ? W[(size_t)n * ld + k + e] : 0.f;
-            if (residual) v[e] -= __uint_as_float((unsigned)to_bf16(v[e]) << 16);
+            if (residual) v[e] -= h16_lo<kF16>(to_h16<kF16>(v[e]));
         }
         P[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
     }
@@ -77,14 +76,14 @@ __device__ __forceinline__ void mma_pass16(const unsigned short* xa, const uint4
     // software pipeline: weight fragments (L2) are requested two k-steps ahead, the activation fragments (LDS) one
     // k-step ahead, so neither latency sits between two MFMA groups
     uint4 fb0[NT], fb1[NT], fb2[NT];
-    bf16x8 fa0[HMI], fa1[HMI];
+    uint4 fa0[HMI], fa1[HMI];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
         fb0[ni] = wf[ni * tile_stride];
         fb1[ni] = wf[ni * tile_stride + (nks > 1 ? 64 : 0)];
     }
 #pragma unroll
-    for (int mi = 0; mi < HMI; ++mi) fa0[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+    for (int mi = 0; mi < HMI; ++mi) fa0[mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD);
 #pragma unroll 1
     for (int ks = 0; ks < nks; ++ks) {
         if (ks + 2 < nks) {
@@ -94,13 +93,13 @@ __device__ __forceinline__ void mma_pass16(const unsigned short* xa, const uint4
         if (ks + 1 < nks) {
 #pragma unroll
             for (int mi = 0; mi < HMI; ++mi)
-                fa1[mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+                fa1[mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1));
         }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-            const bf16x8 w = __builtin_bit_cast(bf16x8, fb0[ni]);
+            const uint4 w = fb0[ni];
 #pragma unroll
-            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, fa0[mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = mfma_h16<kF16>(w, fa0[mi], acc[mi][ni]);
         }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) { fb0[ni] = fb1[ni]; fb1[ni] = fb2[ni]; }
@@ -131,8 +130,8 @@ __device__ __forceinline__ void decode_tail16(const unsigned short* X, const Fus
 #pragma unroll 4
         for (int n = 0; n < 128; n += 4) {
             const uint2 xb = *reinterpret_cast<const uint2*>(xr + n);
-            const float x0 = __uint_as_float(xb.x << 16), x1 = __uint_as_float(xb.x & 0xFFFF0000u);
-            const float x2 = __uint_as_float(xb.y << 16), x3 = __uint_as_float(xb.y & 0xFFFF0000u);
+            const float x0 = h16_lo<kF16>(xb.x), x1 = h16_hi<kF16>(xb.x);
+            const float x2 = h16_lo<kF16>(xb.y), x3 = h16_hi<kF16>(xb.y);
             const float4 u0 = *reinterpret_cast<const float4*>(w0 + n);
             const float4 u1 = *reinterpret_cast<const float4*>(w1 + n);
             const float4 u2 = *reinterpret_cast<const float4*>(w2 + n);
@@ -201,9 +200,9 @@ __device__ __forceinline__ void load_fb01(const uint4* __restrict__ wf, long til
 template <int NT, int NKS>
 __device__ __forceinline__ void mma_pass16u(const unsigned short* xa, const uint4* __restrict__ wf, long tile_stride,
                                             f32x16 (&acc)[HMI][NT], uint4 (&fb)[3][NT]) {
-    bf16x8 fa[2][HMI];
+    uint4 fa[2][HMI];
 #pragma unroll
-    for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+    for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         if (ks + 2 < NKS) {
@@ -213,13 +212,13 @@ __device__ __forceinline__ void mma_pass16u(const unsigned short* xa, const uint
         if (ks + 1 < NKS) {
 #pragma unroll
             for (int mi = 0; mi < HMI; ++mi)
-                fa[(ks + 1) & 1][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+                fa[(ks + 1) & 1][mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1));
         }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
-            const bf16x8 wv = __builtin_bit_cast(bf16x8, fb[ks % 3][ni]);
+            const uint4 wv = fb[ks % 3][ni];
 #pragma unroll
-            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, fa[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = mfma_h16<kF16>(wv, fa[ks & 1][mi], acc[mi][ni]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -260,8 +259,8 @@ __device__ __forceinline__ void hidden_layer16v2(unsigned short* X, const void* 
 #pragma unroll
             for (int mi = 0; mi < HMI; ++mi) {
                 uint2 o;
-                o.x = pack2(fmaxf(acc[mi][ni][4 * g], 0.f), fmaxf(acc[mi][ni][4 * g + 1], 0.f));
-                o.y = pack2(fmaxf(acc[mi][ni][4 * g + 2], 0.f), fmaxf(acc[mi][ni][4 * g + 3], 0.f));
+                o.x = pack_relu2(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1]);
+                o.y = pack_relu2(acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
                 *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
             }
         }
@@ -283,16 +282,16 @@ __device__ __forceinline__ void build_rows16v2(unsigned short* X, const FusedCha
             const int r = (t >> 6) + 4 * (16 * b + i);
             const float4 q = *reinterpret_cast<const float4*>(s_t4 + 4 * r);       // rel_y rel_x scale_y scale_x
             uint2 o;
-            o.x = pack2(fmaxf(tv[i].x + tw[0].x * q.x + tw[0].y * q.y + tw[0].z * q.z + tw[0].w * q.w, 0.f),
-                        fmaxf(tv[i].y + tw[1].x * q.x + tw[1].y * q.y + tw[1].z * q.z + tw[1].w * q.w, 0.f));
-            o.y = pack2(fmaxf(tv[i].z + tw[2].x * q.x + tw[2].y * q.y + tw[2].z * q.z + tw[2].w * q.w, 0.f),
-                        fmaxf(tv[i].w + tw[3].x * q.x + tw[3].y * q.y + tw[3].z * q.z + tw[3].w * q.w, 0.f));
+            o.x = pack_relu2(tv[i].x + tw[0].x * q.x + tw[0].y * q.y + tw[0].z * q.z + tw[0].w * q.w,
+                             tv[i].y + tw[1].x * q.x + tw[1].y * q.y + tw[1].z * q.z + tw[1].w * q.w);
+            o.y = pack_relu2(tv[i].z + tw[2].x * q.x + tw[2].y * q.y + tw[2].z * q.z + tw[2].w * q.w,
+                             tv[i].w + tw[3].x * q.x + tw[3].y * q.y + tw[3].z * q.z + tw[3].w * q.w);
             *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
         }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) {
+__global__ __launch_bounds__(256, 2) void head_kv_fused_h16_kernel(FusedKVP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);                 // [128][264] bf16
     float* s_t4 = reinterpret_cast<float*>(smem_raw + (size_t)HBM_ * HLD * 2);        // [128][4]
@@ -364,8 +363,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const uint2 xb = *reinterpret_cast<const uint2*>(X + row * HLD + 8 * (16 * b + i) + 4 * part);
-                a += __uint_as_float(xb.x << 16) * gv[i].x + __uint_as_float(xb.x & 0xFFFF0000u) * gv[i].y +
-                     __uint_as_float(xb.y << 16) * gv[i].z + __uint_as_float(xb.y & 0xFFFF0000u) * gv[i].w;
+                a += h16_lo<kF16>(xb.x) * gv[i].x + h16_hi<kF16>(xb.x) * gv[i].y + h16_lo<kF16>(xb.y) * gv[i].z + h16_hi<kF16>(xb.y) * gv[i].w;
             }
         }
         a += quad_xor1(a);
@@ -492,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_bf16_kernel(FusedKVP p) 
                     z.w = fmaf(av[mi] * vv[g][mi].w, acc[mi][0][4 * g + 3], z.w);
                 }
                 const int d0 = 32 * u + 8 * g + 4 * lh;
-                const uint2 zb = pack_bf16x4(z.x, z.y, z.z, z.w);
+                const uint2 zb = pack_h16x4<kF16>(z.x, z.y, z.z, z.w);
                 typedef int i32x2 __attribute__((ext_vector_type(2)));
                 i32x2 zi; zi.x = (int)zb.x; zi.y = (int)zb.y;
                 __builtin_amdgcn_raw_buffer_store_b64(zi, rs_z, (int)((zoff == kOobH || d0 >= p.v.n_out) ? kOobH : zoff + (unsigned)d0 * 2u), 0, 0);
@@ -539,9 +537,9 @@ __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP&
     }
     __syncthreads();
     const unsigned short* xa = X + li * HLD + 8 * lh;
-    bf16x8 fa[2][HMI];
+    uint4 fa[2][HMI];
 #pragma unroll
-    for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+    for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         if (ks + 2 < NKS) {
@@ -551,13 +549,13 @@ __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP&
         if (ks + 1 < NKS) {
 #pragma unroll
             for (int mi = 0; mi < HMI; ++mi)
-                fa[(ks + 1) & 1][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+                fa[(ks + 1) & 1][mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1));
         }
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-            const bf16x8 wv = __builtin_bit_cast(bf16x8, fb[ks % 3][ni]);
+            const uint4 wv = fb[ks % 3][ni];
 #pragma unroll
-            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, fa[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = mfma_h16<kF16>(wv, fa[ks & 1][mi], acc[mi][ni]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -569,7 +567,7 @@ __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP&
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) { fb[0][ni] = wload_lo(ni, 0); fb[1][ni] = wload_lo(ni, 1); }
 #pragma unroll
-        for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD));
+        for (int mi = 0; mi < HMI; ++mi) fa[0][mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             if (ks + 2 < NKS) {
@@ -579,13 +577,13 @@ __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP&
             if (ks + 1 < NKS) {
 #pragma unroll
                 for (int mi = 0; mi < HMI; ++mi)
-                    fa[(ks + 1) & 1][mi] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1)));
+                    fa[(ks + 1) & 1][mi] = *reinterpret_cast<const uint4*>(xa + mi * 32 * HLD + 16 * (ks + 1));
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
-                const bf16x8 wv = __builtin_bit_cast(bf16x8, fb[ks % 3][ni]);
+                const uint4 wv = fb[ks % 3][ni];
 #pragma unroll
-                for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, fa[ks & 1][mi], acc[mi][ni], 0, 0, 0);
+                for (int mi = 0; mi < HMI; ++mi) acc[mi][ni] = mfma_h16<kF16>(wv, fa[ks & 1][mi], acc[mi][ni]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -594,7 +592,7 @@ __device__ __forceinline__ void decode_chunk16(unsigned short* X, const FusedQP&
 
 // TAIL = k-steps of the ragged last chunk rounded up to {0: none, 2, 4, 8, 16}
 template <int TAIL>
-__global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP p) {
+__global__ __launch_bounds__(256, 2) void head_decode_fused_h16_kernel(FusedQP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned short* X = reinterpret_cast<unsigned short*>(smem_raw);   // [128][264] bf16
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -633,8 +631,8 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
 #pragma unroll
             for (int mi = 0; mi < HMI; ++mi) {
                 uint2 o;
-                o.x = pack2(fmaxf(acc[mi][ni][4 * g], 0.f), fmaxf(acc[mi][ni][4 * g + 1], 0.f));
-                o.y = pack2(fmaxf(acc[mi][ni][4 * g + 2], 0.f), fmaxf(acc[mi][ni][4 * g + 3], 0.f));
+                o.x = pack_relu2(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1]);
+                o.y = pack_relu2(acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]);
                 *reinterpret_cast<uint2*>(X + (32 * mi + li) * HLD + col) = o;
             }
         }
@@ -644,68 +642,77 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_bf16_kernel(FusedQP 
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-size_t fragment_bf16_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 64 * 16; }
-
-int pack_fragments_bf16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual) {
+int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual) {
     const int n_tiles = (N + 31) / 32, nks = (K + 15) / 16;
     const long total = (long)n_tiles * nks * 64;
     int grid = (int)((total + 255) / 256);
-    ProfScope prof("pack_fragments_bf16", s);
-    hipLaunchKernelGGL(pack_fragments_bf16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, W, ld, N, K,
+    ProfScope prof("pack_fragments" CIAOSR_H16_SUFFIX, s);
+    hipLaunchKernelGGL(pack_fragments_h16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, W, ld, N, K,
                        reinterpret_cast<uint4*>(P), n_tiles, nks, residual);
-    return launch_status("pack_fragments_bf16");
+    return launch_status("pack_fragments" CIAOSR_H16_SUFFIX);
 }
 
 constexpr size_t kFused16Lds = (size_t)HBM_ * HLD * 2 + (size_t)(HBM_ * 4 + 4 * HBM_ + HBM_) * sizeof(float) + (HBM_ + 32 + HBM_) * sizeof(int);
 
-int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s) {
-    CIAOSR_BIG_LDS(head_kv_fused_bf16_kernel, kFused16Lds);
-    ProfScope prof("head_kv_fused_bf16", s);
-    hipLaunchKernelGGL(head_kv_fused_bf16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
-    return launch_status("head_kv_fused_bf16");
+int head_kv_fused_h16(const FusedKVP& p, hipStream_t s) {
+    CIAOSR_BIG_LDS(head_kv_fused_h16_kernel, kFused16Lds);
+    ProfScope prof("head_kv_fused" CIAOSR_H16_SUFFIX, s);
+    hipLaunchKernelGGL(head_kv_fused_h16_kernel, dim3(ceil_div(p.nq, HBM_ / 4)), dim3(256), kFused16Lds, s, p);
+    return launch_status("head_kv_fused" CIAOSR_H16_SUFFIX);
 }
 
-int head_decode_fused_bf16(const FusedQP& p, hipStream_t s) {
+int head_decode_fused_h16(const FusedQP& p, hipStream_t s) {
     const size_t lds = (size_t)HBM_ * HLD * 2;
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<0>, lds);
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<2>, lds);
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<4>, lds);
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<8>, lds);
-    CIAOSR_BIG_LDS(head_decode_fused_bf16_kernel<16>, lds);
-    ProfScope prof("head_decode_fused_bf16", s);
+    CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<0>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<2>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<4>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<8>, lds);
+    CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<16>, lds);
+    ProfScope prof("head_decode_fused" CIAOSR_H16_SUFFIX, s);
     const dim3 grid(ceil_div(p.nq, HBM_));
     const int tail_steps = ((p.Dv & (HH - 1)) + 15) >> 4;      // k-steps of the ragged last chunk (C = 64: 8, C = 180: 1)
     if (tail_steps == 0)
-        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<0>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(head_decode_fused_h16_kernel<0>, grid, dim3(256), lds, s, p);
     else if (tail_steps <= 2)
-        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<2>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(head_decode_fused_h16_kernel<2>, grid, dim3(256), lds, s, p);
     else if (tail_steps <= 4)
-        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<4>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(head_decode_fused_h16_kernel<4>, grid, dim3(256), lds, s, p);
     else if (tail_steps <= 8)
-        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<8>, grid, dim3(256), lds, s, p);
+        hipLaunchKernelGGL(head_decode_fused_h16_kernel<8>, grid, dim3(256), lds, s, p);
     else
-        hipLaunchKernelGGL(head_decode_fused_bf16_kernel<16>, grid, dim3(256), lds, s, p);
-    return launch_status("head_decode_fused_bf16");
+        hipLaunchKernelGGL(head_decode_fused_h16_kernel<16>, grid, dim3(256), lds, s, p);
+    return launch_status("head_decode_fused" CIAOSR_H16_SUFFIX);
 }
 
+}  // namespace CIAOSR_H16_NS
 }  // namespace ciaosr
 
 using namespace ciaosr;
 
+// 16-bit fragment packing: out[nt][ks][lane][8 x 16 bit], same byte count for both element types
+#if CIAOSR_F16
+extern "C" size_t ciaosr_fragment_f16_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 64 * 16; }
+
+extern "C" int ciaosr_pack_fragments_f16(const float* W, int ld, int N, int K, void* out, void* stream) {
+    CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
+    return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0);
+}
+#else
 #ifdef CIAOSR_PROBE
 extern "C" int ciaosr_debug_probe16_read(unsigned long long* host, int n_words) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::g_hprobe16), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::b16::g_hprobe16), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 
-extern "C" size_t ciaosr_fragment_bf16_bytes(int N, int K) { return fragment_bf16_bytes(N, K); }
+extern "C" size_t ciaosr_fragment_bf16_bytes(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 15) / 16) * 64 * 16; }
 
 extern "C" int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return pack_fragments_bf16(W, ld, N, K, out, (hipStream_t)stream, 0);
+    return b16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0);
 }
 
 extern "C" int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return pack_fragments_bf16(W, ld, N, K, out, (hipStream_t)stream, 1);
+    return b16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 1);
 }
+#endif

@@ -8,7 +8,7 @@
 //  decode_residual  last Linear of imnet_q (-> 3) + bilinear/border LR residual       (:107-108,221)
 //
 // One wavefront (64 lanes) per row / query; lanes stride the channel dimension with float4.
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "common.h"
 #include "index_math.h"
 #include "ops.h"
@@ -257,10 +257,11 @@ __global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
 //   pixel one of the 3x3 neighbours of the query pixel: 9 rows per LR pixel instead of one 576-wide output
 //   layer per (query, sample) row.  Row r = p*9 + (oy+1)*3 + (ox+1): A[r][d] = U[p][d] * U[p+o][d].
 // ---------------------------------------------------------------------------------------------
-template <bool B16>       // B16: rows written as bf16 (operand of the bf16 GEMM) instead of fp32
+template <int OUT>        // OUT: 0 = fp32 rows; 1 / 2 = rows written as bf16 / half (operand of the 16-bit GEMM)
 __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ U, int ldu, int D, int H, int W, long row0,
                                                       int nrows, const float* __restrict__ b5, float* __restrict__ A,
                                                       float* __restrict__ G, int ldg) {
+    constexpr bool B16 = OUT != 0;
     const int lane = threadIdx.x & 63;
     const long rl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rl >= nrows) return;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
         for (int t = lane; t < (D >> 2); t += 64) {
             const float4 qv = q[t], kv = k[t], bv = b[t];
             const float4 v = make_float4(qv.x * kv.x, qv.y * kv.y, qv.z * kv.z, qv.w * kv.w);
-            if (B16) a16[t] = pack_bf16x4(v.x, v.y, v.z, v.w);
+            if (B16) a16[t] = pack_h16x4<OUT == 2>(v.x, v.y, v.z, v.w);
             else a[t] = v;
             c += v.x * bv.x + v.y * bv.y + v.z * bv.z + v.w * bv.w;
         }
@@ -322,31 +323,38 @@ int head_rows(const HeadRowsP& p, hipStream_t s) {
 }
 
 int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
-            int ldg, bool rows_bf16, hipStream_t s) {
+            int ldg, int rows_h16, hipStream_t s) {
     ProfScope prof("head_qk_rows", s);
-    if (rows_bf16)
-        hipLaunchKernelGGL(qk_rows_kernel<true>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
+    if (rows_h16 == 2)
+        hipLaunchKernelGGL(qk_rows_kernel<2>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
+                           A, G, ldg);
+    else if (rows_h16 == 1)
+        hipLaunchKernelGGL(qk_rows_kernel<1>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
                            A, G, ldg);
     else
-        hipLaunchKernelGGL(qk_rows_kernel<false>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
+        hipLaunchKernelGGL(qk_rows_kernel<0>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
                            A, G, ldg);
     return launch_status("qk_rows");
 }
 
-// out[n][k] (bf16, row stride K) = W[k][n] (fp32, row stride ld): the [N][K] operand of the bf16 NT GEMM
-__global__ void transpose_cast_bf16_kernel(const float* __restrict__ W, int ld, int K, int N, unsigned short* __restrict__ out) {
+// out[n][k] (bf16 or half, row stride K) = W[k][n] (fp32, row stride ld): the [N][K] operand of the 16-bit NT GEMM
+template <bool F16>
+__global__ void transpose_cast_h16_kernel(const float* __restrict__ W, int ld, int K, int N, unsigned short* __restrict__ out) {
     const long n_el = (long)K * N;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n_el; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i % K), n = (int)(i / K);
-        out[i] = to_bf16(W[(size_t)k * ld + n]);
+        out[i] = to_h16<F16>(W[(size_t)k * ld + n]);
     }
 }
 
-int transpose_cast_bf16(const float* W, int ld, int K, int N, unsigned short* out, hipStream_t s) {
-    ProfScope prof("transpose_cast_bf16", s);
+int transpose_cast_h16(const float* W, int ld, int K, int N, unsigned short* out, bool f16, hipStream_t s) {
+    ProfScope prof("transpose_cast_h16", s);
     const long n_el = (long)K * N;
-    hipLaunchKernelGGL(transpose_cast_bf16_kernel, dim3((int)((n_el + 255) / 256)), dim3(256), 0, s, W, ld, K, N, out);
-    return launch_status("transpose_cast_bf16");
+    if (f16)
+        hipLaunchKernelGGL(transpose_cast_h16_kernel<true>, dim3((int)((n_el + 255) / 256)), dim3(256), 0, s, W, ld, K, N, out);
+    else
+        hipLaunchKernelGGL(transpose_cast_h16_kernel<false>, dim3((int)((n_el + 255) / 256)), dim3(256), 0, s, W, ld, K, N, out);
+    return launch_status("transpose_cast_h16");
 }
 
 int local_attention(const LocalAttnP& p, hipStream_t s) {

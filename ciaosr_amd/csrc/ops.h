@@ -75,19 +75,14 @@ int downsample(const float* src, int Hp, int Wp, int C, int scale, float* dst, h
 int csa_gather_vprime(const float* Pc, int Hh, int Wh, int C, float* Vp, hipStream_t s);
 int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const float* Otl, const float* bd, int H, int W,
                    int Hp, int Wp, int C, float* out, int ld_out, long ld_main, long ld_top, long ld_left, hipStream_t s);
-int csa_gather_vprime_t_bf16(const float* Pc, int Hh, int Wh, int C, unsigned short* VpT, int ldt, hipStream_t s);
-// gemm_bf16.hip
-int gemm_bf16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,
-                 int K, float alpha, hipStream_t s, const char* tag);
-int cast_rows_bf16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s);
-int softmax_rows_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s);
+int csa_gather_vprime_t_h16(const float* Pc, int Hh, int Wh, int C, unsigned short* VpT, int ldt, bool f16, hipStream_t s);
 // head_ops.hip
 int head_indices(const float* coord, const float* cell, long q0, int nq, int chunk, int H, int W, int local_size,
                  int* q_idx, int* k_idx, float* rel, hipStream_t s);
 int head_rows(const HeadRowsP& p, hipStream_t s);
 int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
-            int ldg, bool rows_bf16, hipStream_t s);
-int transpose_cast_bf16(const float* W, int ld, int K, int N, unsigned short* out, hipStream_t s);
+            int ldg, int rows_h16 /* 0 fp32 rows, 1 bf16, 2 half */, hipStream_t s);
+int transpose_cast_h16(const float* W, int ld, int K, int N, unsigned short* out, bool f16, hipStream_t s);
 int local_attention(const LocalAttnP& p, hipStream_t s);
 int decode_residual(const DecodeP& p, hipStream_t s);
 
@@ -143,9 +138,44 @@ struct FusedQP {
     int rows_per_wg;   // fp32 kernel: 32 (0 = default) or 64
 };
 int head_kv_fused(const FusedKVP& p, hipStream_t s);
-int head_kv_fused_bf16(const FusedKVP& p, hipStream_t s);
-int head_decode_fused_bf16(const FusedQP& p, hipStream_t s);
 int head_decode_fused(const FusedQP& p, hipStream_t s);
+
+// The 16-bit translation units (head_fused_h16.hip, gemm_h16.hip, dense_h16.hip) are compiled once per element type
+// (h16_util.h): the same functions exist in ciaosr::b16 (bf16) and ciaosr::f16 (IEEE half).
+#define CIAOSR_H16_DECLS                                                                                                              \
+    int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,  \
+                    int K, float alpha, hipStream_t s, const char* tag);                                                              \
+    int cast_rows_h16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s);             \
+    int softmax_rows_h16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s);                        \
+    int head_kv_fused_h16(const FusedKVP& p, hipStream_t s);                                                                          \
+    int head_decode_fused_h16(const FusedQP& p, hipStream_t s);                                                                       \
+    int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual);                               \
+    int dense_h16_tiles(int H, int W);                                                                                                \
+    int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);                       \
+    int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,                     \
+                        const void* frag16_lo, const float* bias, hipStream_t s);
+namespace b16 { CIAOSR_H16_DECLS }
+namespace f16 { CIAOSR_H16_DECLS }
+#undef CIAOSR_H16_DECLS
+
+// precision of an entry point: the suffix of its name
+enum Prec { kF32 = 0, kBF16 = 1, kF16 = 2 };
+struct H16Ops {
+    decltype(&b16::gemm_h16_nt) gemm_nt;
+    decltype(&b16::cast_rows_h16) cast_rows;
+    decltype(&b16::softmax_rows_h16) softmax_rows;
+    decltype(&b16::head_kv_fused_h16) head_kv_fused;
+    decltype(&b16::head_decode_fused_h16) head_decode_fused;
+    decltype(&b16::cast_group_h16) cast_group;
+    decltype(&b16::dense_layer_h16) dense_layer;
+};
+inline const H16Ops& h16_ops(Prec prec) {
+    static const H16Ops kB = {b16::gemm_h16_nt, b16::cast_rows_h16, b16::softmax_rows_h16, b16::head_kv_fused_h16,
+                              b16::head_decode_fused_h16, b16::cast_group_h16, b16::dense_layer_h16};
+    static const H16Ops kH = {f16::gemm_h16_nt, f16::cast_rows_h16, f16::softmax_rows_h16, f16::head_kv_fused_h16,
+                              f16::head_decode_fused_h16, f16::cast_group_h16, f16::dense_layer_h16};
+    return prec == kF16 ? kH : kB;
+}
 
 // bump allocator over the caller-provided workspace (256-byte aligned carve-outs)
 struct Arena {

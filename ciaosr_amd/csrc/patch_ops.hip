@@ -2,7 +2,7 @@
 // row softmax, the gather-form fold of conv_transpose2d, restorer plumbing.
 // All accesses are float4 along the channel (innermost) dimension: one 3x3 / 6x6 tap of a
 // channels-last map is C contiguous floats.
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "common.h"
 #include "index_math.h"
 
@@ -208,15 +208,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S
 }
 
 // Single-pass variant for rows of up to 64 x SMV float4: the whole row lives in registers (one HBM read, one write).
-// OUT16: write bf16 probabilities to P (row stride ldp) instead of fp32 in place.
+// OUT: 0 = fp32 in place; 1 / 2 = write bf16 / half probabilities to P (row stride ldp) instead.
 constexpr int SMV = 36;          // 36 float4 per lane = rows of up to 9216 floats (the 192x192 tile's L)
-template <bool OUT16>
+template <int OUT>
 __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict__ S, long rows, int L, int ld,
                                                                unsigned short* __restrict__ P, int ldp) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     float4* s = reinterpret_cast<float4*>(S + (size_t)row * ld);
+    constexpr bool OUT16 = OUT != 0;
     const int n4 = (OUT16 ? ldp : ld) >> 2;
     float4 v[SMV];
 #pragma unroll
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(float* __restrict
         if (t >= n4) continue;
         const float4 o = make_float4(v[i].x / sum, v[i].y / sum, v[i].z / sum, v[i].w / sum);
         if (OUT16) {
-            reinterpret_cast<uint2*>(P + (size_t)row * ldp)[t] = pack_bf16x4(o.x, o.y, o.z, o.w);
+            reinterpret_cast<uint2*>(P + (size_t)row * ldp)[t] = pack_h16x4<OUT == 2>(o.x, o.y, o.z, o.w);
         } else {
             s[t] = o;
         }
@@ -340,9 +341,10 @@ __global__ void csa_gather_vprime_kernel(const float* __restrict__ Pc, int Hh, i
     }
 }
 
-// bf16 mode: the same matrix transposed, VpT[blk*C + co][l] (bf16, row stride ldt >= L, pad columns zeroed), the
-// [N][K] operand of the bf16 NT GEMM (gemm_bf16.hip)
-__global__ void csa_gather_vprime_t_bf16_kernel(const float* __restrict__ Pc, int Hh, int Wh, int C, unsigned short* __restrict__ VpT,
+// 16-bit modes: the same matrix transposed, VpT[blk*C + co][l] (bf16 or half, row stride ldt >= L, pad columns zeroed), the
+// [N][K] operand of the 16-bit NT GEMM (gemm_h16.hip)
+template <bool F16>
+__global__ void csa_gather_vprime_t_h16_kernel(const float* __restrict__ Pc, int Hh, int Wh, int C, unsigned short* __restrict__ VpT,
                                                 int ldt) {
     const long n = (long)25 * C * ldt;
     const int We = Wh + 3, L = Hh * Wh;
@@ -360,7 +362,7 @@ __global__ void csa_gather_vprime_t_bf16_kernel(const float* __restrict__ Pc, in
             else { dy = 0; dx = 0; r = 2; sct = 2; }
             v = Pc[((size_t)(ly - dy + 1) * We + (lx - dx + 1)) * (9 * C) + (size_t)(3 * r + sct) * C + co];
         }
-        VpT[idx] = to_bf16(v);
+        VpT[idx] = to_h16<F16>(v);
     }
 }
 
@@ -487,17 +489,19 @@ int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int 
 int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s) {
     ProfScope prof("softmax_rows", s);
     if ((ld >> 2) <= 64 * SMV && (ld >> 2) > 64 * 8)       // long rows that still fit the register file: one pass
-        hipLaunchKernelGGL(softmax_rows_reg_kernel<false>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, nullptr, 0);
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<0>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, nullptr, 0);
     else
         hipLaunchKernelGGL(softmax_rows_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld);
     return launch_status("softmax_rows");
 }
 
-// fp32 logits -> bf16 probabilities, single pass; false when the row does not fit the register file
-bool softmax_rows_reg_bf16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s) {
+// fp32 logits -> bf16 / half probabilities, single pass; false when the row does not fit the register file
+bool softmax_rows_reg_h16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, bool f16, hipStream_t s) {
     if ((ldp >> 2) > 64 * SMV) return false;
-    hipLaunchKernelGGL(softmax_rows_reg_kernel<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, const_cast<float*>(S), rows, L, ld,
-                       P, ldp);
+    if (f16)
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<2>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, const_cast<float*>(S), rows, L, ld, P, ldp);
+    else
+        hipLaunchKernelGGL(softmax_rows_reg_kernel<1>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, const_cast<float*>(S), rows, L, ld, P, ldp);
     return true;
 }
 
@@ -515,9 +519,12 @@ int csa_gather_out(const float* Op, const float* Otop, const float* Oleft, const
     return launch_status("csa_gather_out");
 }
 
-int csa_gather_vprime_t_bf16(const float* Pc, int Hh, int Wh, int C, unsigned short* VpT, int ldt, hipStream_t s) {
+int csa_gather_vprime_t_h16(const float* Pc, int Hh, int Wh, int C, unsigned short* VpT, int ldt, bool f16, hipStream_t s) {
     ProfScope prof("csa_gather_vprime", s);
-    hipLaunchKernelGGL(csa_gather_vprime_t_bf16_kernel, dim3(ew_grid((long)25 * C * ldt)), dim3(256), 0, s, Pc, Hh, Wh, C, VpT, ldt);
+    if (f16)
+        hipLaunchKernelGGL(csa_gather_vprime_t_h16_kernel<true>, dim3(ew_grid((long)25 * C * ldt)), dim3(256), 0, s, Pc, Hh, Wh, C, VpT, ldt);
+    else
+        hipLaunchKernelGGL(csa_gather_vprime_t_h16_kernel<false>, dim3(ew_grid((long)25 * C * ldt)), dim3(256), 0, s, Pc, Hh, Wh, C, VpT, ldt);
     return launch_status("csa_gather_vprime_t");
 }
 

@@ -71,7 +71,7 @@ int launch_status(const char* what) {
 
 using namespace ciaosr;
 
-extern "C" int ciaosr_version(void) { return 200; }
+extern "C" int ciaosr_version(void) { return 210; }
 
 // sizeof of every struct of the ABI, by name: lets a binding (ciaosr_amd/_lib.py's ctypes mirrors) verify its layout
 extern "C" size_t ciaosr_sizeof(const char* type_name) {

@@ -11,7 +11,7 @@
 // :247-250) is folded into the token index, the relative-position bias arrives pre-gathered per layer
 // [heads][N][N] and the shifted-window mask [nW][N][N] (calculate_mask :192-213) per map size, both built once on the
 // host.  Everything fp32 (exact-fp32 MFMA for q k^T and P v).
-#include "bf16_util.h"
+#include "h16_util.h"
 #include "ops.h"
 
 namespace ciaosr {

@@ -58,16 +58,43 @@ class PackedEncoder:
         self._key = None
         self._st = None
         self._keep = None
+        self._st_f16 = None       # RDN: copy of the struct whose dense-layer frag16 are IEEE half (packed on first use)
+        self._keep_f16 = None
 
     def _params(self):
         n = self.net
         mods = [n.sfe1, n.sfe2, n.rdbs, n.gff] if self.kind == 'rdn' else [n.conv_first, n.body, n.conv_after_body]
         return [p for m in mods for p in m.parameters()]
 
-    def struct(self):
+    def struct(self, half=None):
+        """The trunk's weight struct.  half='f16' (RDN): the copy whose dense layers carry IEEE-half fragments (the _f16 entry)."""
         key = tuple((p.data_ptr(), p._version) for p in self._params())
-        if self._st is not None and key == self._key:
+        if self._st is None or key != self._key:
+            self._build(key)
+            self._st_f16 = None
+        if half != 'f16' or self.kind != 'rdn':
             return self._st
+        if self._st_f16 is None:
+            base = self._st
+            st = _lib.RdnWeightsT()
+            C.memmove(C.byref(st), C.byref(base), C.sizeof(st))
+            nd = base.num_blocks * base.num_layers
+            dense = (_lib.ConvT * nd)()
+            keep = [dense]
+            for i in range(nd):
+                C.memmove(C.byref(dense[i]), C.byref(base.dense[i]), C.sizeof(_lib.ConvT))
+                c = dense[i]
+                n_, k_ = c.cout, c.ksize * c.ksize * c.cin
+                f = torch.empty(_lib.load().ciaosr_fragment_f16_bytes(n_, k_), dtype=torch.uint8, device=self._keep[0].device)
+                _lib.call('ciaosr_pack_fragments_f16', c.weight, k_, n_, k_, hip_ops.ptr(f), hip_ops.stream_ptr())
+                keep.append(f)
+                c.frag16 = f.data_ptr()
+                c.frag16_lo = None
+            st.dense = dense
+            self._st_f16, self._keep_f16 = st, keep
+        return self._st_f16
+
+    def _build(self, key):
         n, keep = self.net, []
         if self.kind == 'rdn':
             st = _lib.RdnWeightsT()
@@ -128,7 +155,6 @@ class PackedEncoder:
             st.conv1, st.conv2 = c1, c2
             keep += [c1, c2]
         self._st, self._keep, self._key = st, keep, key
-        return st
 
     def supported(self):
         n = self.net
@@ -146,11 +172,11 @@ class PackedEncoder:
         x_chw = x_chw.contiguous().float()
         hip_ops.require_gpu(x_chw)
         _, H, W = x_chw.shape
-        st = self.struct()
+        st = self.struct(opt.half)
         lib = _lib.load()
         if self.kind == 'rdn':
             nbytes = lib.ciaosr_rdn_workspace_bytes(H, W, C.byref(st))
-            fn = 'ciaosr_rdn_forward_bf16' if opt.bf16 else 'ciaosr_rdn_forward_f32'
+            fn = 'ciaosr_rdn_forward_' + opt.suffix
         else:
             nbytes = lib.ciaosr_edsr_workspace_bytes(H, W, C.byref(st))
             fn = 'ciaosr_edsr_forward_f32'

@@ -28,6 +28,8 @@ class PackedHead:
         self._key = None
         self._st = None
         self._keep = None
+        self._st_f16 = None       # copy of the struct whose frag16 hold IEEE-half fragments (packed on first use)
+        self._keep_f16 = None
 
     def _version_key(self):
         mods = [self.net.imnet_q, self.net.imnet_k, self.net.imnet_v]
@@ -41,6 +43,7 @@ class PackedHead:
         st.n_layers = len(lin)
         st.act = mlp.act_code() if hasattr(mlp, 'act_code') else _lib.ACT_RELU
         keep = []
+        srcs = []      # (layer, weight) of the layers with MFMA fragments
         for i, l in enumerate(lin):
             w = l.weight.detach().float()
             b = l.bias.detach().float()
@@ -64,6 +67,7 @@ class PackedHead:
             if i in frag_layers and w.shape[1] % 8 == 0:
                 # MFMA fragment order for the fused kernels, packed on the device by the library
                 n, k = w.shape
+                srcs.append((i, w))
                 frag = torch.empty(_lib.load().ciaosr_fragment_floats(n, k), dtype=torch.float32, device=w.device)
                 _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(frag),
                           hip_ops.stream_ptr())
@@ -80,12 +84,35 @@ class PackedHead:
                 keep.append(lo16)
                 st.frag16_lo[i] = lo16.data_ptr()
         st.in_dim = lin[0].weight.shape[1]
-        return st, keep
+        return st, keep, srcs
 
-    def struct(self):
+    def struct(self, half=None):
+        """The ciaosr_head_weights_t of the net.  half='f16': the copy whose 16-bit fragments are IEEE half (the _f16
+        entry); else the struct with bf16 hi + lo fragments (the _f32 / _bf16 entries)."""
         key = self._version_key()
-        if self._st is not None and self._key == key:
+        if self._st is None or self._key != key:
+            self._build()
+            self._st_f16 = None
+        if half != 'f16':
             return self._st
+        if self._st_f16 is None:
+            st = _lib.HeadWeightsT()
+            C.memmove(C.byref(st), C.byref(self._st), C.sizeof(st))
+            keep = []
+            for name in ('k', 'v', 'q'):
+                m = getattr(st, name)
+                for i, w in self._srcs[name]:
+                    n, k = w.shape
+                    f = torch.empty(_lib.load().ciaosr_fragment_f16_bytes(n, k), dtype=torch.uint8, device=w.device)
+                    _lib.call('ciaosr_pack_fragments_f16', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(f), hip_ops.stream_ptr())
+                    keep.append(f)
+                    m.frag16[i] = f.data_ptr()
+                    m.frag16_lo[i] = None
+            self._st_f16, self._keep_f16 = st, keep
+        return self._st_f16
+
+    def _build(self):
+        key = self._version_key()
         net = self.net
         Cc = net.imnet_dim
         Cn = Cc * len(net.multi_scale) if net.non_local_attn else 0
@@ -104,13 +131,13 @@ class PackedHead:
         st.no_unfold = 0 if unfold else 1
         keep = []
         nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
-        st.k, kk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
-        st.v, kv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
-        st.q, kq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
+        st.k, kk, sk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
+        st.v, kv, sv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
+        st.q, kq, sq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
         self._q_last = self._last_wb
         self._keep = kk + kv + kq
+        self._srcs = {'k': sk, 'v': sv, 'q': sq}
         self._st, self._key = st, key
-        return st
 
     @torch.no_grad()
     def forward(self, feature_chw, x_lr_chw, coord, cell, chunk, feature_hwc=None, options=None):
@@ -130,7 +157,7 @@ class PackedHead:
         hip_ops.require_gpu(feature_hwc if feature_hwc is not None else feature_chw, x_lr_chw, coord, cell)
         Cc, H, W = feature_chw.shape
         Q = coord.shape[0]
-        st = self.struct()
+        st = self.struct(opt.half)
         cs = None
         if net.non_local_attn:
             cs, _ = net.cs_attn.packed()
@@ -138,7 +165,7 @@ class PackedHead:
         nbytes = _lib.load().ciaosr_head_workspace_bytes(H, W, C.byref(st), Q)
         ws = hip_ops.workspace(nbytes, coord.device)
         rgb = torch.empty(Q, 3, dtype=torch.float32, device=coord.device)
-        _lib.call('ciaosr_head_forward_bf16' if opt.bf16 else 'ciaosr_head_forward_f32', hip_ops.ptr(feat_hwc), H, W,
+        _lib.call('ciaosr_head_forward_' + opt.suffix, hip_ops.ptr(feat_hwc), H, W,
                   C.byref(st), cs if cs is not None else None, hip_ops.ptr(x_lr_chw), hip_ops.ptr(coord),
                   hip_ops.ptr(cell), Q, int(chunk or 0), hip_ops.ptr(rgb), opt.c_arg(), hip_ops.ptr(ws), ws.numel(),
                   hip_ops.stream_ptr())

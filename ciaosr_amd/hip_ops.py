@@ -168,15 +168,16 @@ def tile_finalize(E, Wt):
 class Options:
     """Per-call evaluation options, passed explicitly down the call chain (no process-global switches).
 
-    precision  'fp32' (exact-fp32 MFMA, the contract precision) or 'bf16' (bf16 MFMA inputs, fp32 accumulation):
-               selects the _f32 / _bf16 entry point of the C ABI.
+    precision  'fp32' (exact-fp32 MFMA, the contract precision), 'bf16' (bf16 MFMA inputs, fp32 accumulation; weights as
+               hi + lo pairs unless bf16_single) or 'f16' (IEEE half MFMA inputs, one MFMA per product, saturating at 65504):
+               selects the _f32 / _bf16 / _f16 entry point of the C ABI.
     the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
     Immutable; `replace()` returns a modified copy."""
     _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single')
     __slots__ = ('precision',) + _C_FIELDS + ('_c',)
 
     def __init__(self, precision='fp32', **kw):
-        object.__setattr__(self, 'precision', {'fp32': 'fp32', 'f32': 'fp32', 'bf16': 'bf16'}[precision])
+        object.__setattr__(self, 'precision', {'fp32': 'fp32', 'f32': 'fp32', 'bf16': 'bf16', 'f16': 'f16', 'fp16': 'f16', 'half': 'f16'}[precision])
         for f in self._C_FIELDS:
             object.__setattr__(self, f, int(kw.pop(f, 0)))
         if kw:
@@ -200,6 +201,16 @@ class Options:
     def bf16(self):
         return self.precision == 'bf16'
 
+    @property
+    def half(self):
+        """None for the fp32 entries, else the 16-bit element type of the MFMA operands: 'bf16' | 'f16'."""
+        return None if self.precision == 'fp32' else self.precision
+
+    @property
+    def suffix(self):
+        """Entry-point suffix of the C ABI: 'f32' | 'bf16' | 'f16'."""
+        return 'f32' if self.precision == 'fp32' else self.precision
+
     def c_arg(self):
         """ctypes argument for `const ciaosr_options_t* opt` (NULL when every field is default)."""
         return C.byref(self._c) if self._c is not None else None
@@ -213,7 +224,7 @@ DEFAULT_OPTIONS = Options()
 
 
 def as_options(options):
-    """None -> defaults; 'fp32'/'bf16' -> Options(precision); Options -> itself; dict -> Options(**dict)."""
+    """None -> defaults; 'fp32'/'bf16'/'f16' -> Options(precision); Options -> itself; dict -> Options(**dict)."""
     if options is None:
         return DEFAULT_OPTIONS
     if isinstance(options, Options):

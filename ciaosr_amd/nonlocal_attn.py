@@ -111,7 +111,7 @@ class CrossScaleAttention(nn.Module):
             o = torch.empty(H, W, ns * Cc, dtype=torch.float32, device=x.device)
             for i in range(ns):           # scale i writes channels [i*C, (i+1)*C) of the channels-last rows
                 o_i = o.view(-1)[i * Cc:]
-                _lib.call('ciaosr_cs_attn_bf16' if opt.bf16 else 'ciaosr_cs_attn_f32', hip_ops.ptr(f), Cc, H, W, C.byref(sts[i]),
+                _lib.call('ciaosr_cs_attn_' + opt.suffix, hip_ops.ptr(f), Cc, H, W, C.byref(sts[i]),
                           hip_ops.ptr(o_i), ns * Cc, opt.c_arg(), hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
             out[b] = hip_ops.hwc_to_nchw(o)
         return out

@@ -59,7 +59,7 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
 
 /* ---- per-call options --------------------------------------------------------------------
  * The library keeps NO mutable state besides the opt-in profiler above: precision is selected by the entry point's
- * _f32 / _bf16 suffix, and every route choice is an argument.  `opt` may be NULL (all defaults); a zero field means
+ * _f32 / _bf16 / _f16 suffix, and every route choice is an argument.  `opt` may be NULL (all defaults); a zero field means
  * "default".  The struct only selects between result-equivalent evaluation routes (tests force each of them). */
 #define CIAOSR_HEAD_STAGED 1          /* head_route bit 0: per-layer GEMM path instead of the fused kernels */
 #define CIAOSR_HEAD_NO_LOGIT_TABLE 2  /* head_route bit 1: fused path, imnet_k output layer on the MFMA per (query, sample)
@@ -143,6 +143,11 @@ int ciaosr_cs_attn_f32(const float* feat_hwc, int ld_feat, int H, int W, const c
 int ciaosr_cs_attn_bf16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
                         float* out, int ld_out, const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* Same route with IEEE half operands (v_mfma_f32_32x32x16_f16: the bf16 MFMA's rate, 11 mantissa bits instead of 8;
+ * conversions saturate at +-65504 instead of producing inf). */
+int ciaosr_cs_attn_f16(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w,
+                       float* out, int ld_out, const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
+                       size_t workspace_bytes, void* stream);
 
 /* ---- head ---------------------------------------------------------------------------------- */
 typedef struct ciaosr_mlp {
@@ -158,10 +163,11 @@ typedef struct ciaosr_mlp {
      * packed).  With every hidden width 256, local_size 2 and fragments present the fused kernels run
      * (head_kv_fused / head_decode_fused); otherwise the staged per-layer GEMM path. */
     const float* frag[CIAOSR_MAX_LAYERS];
-    /* optional: the same layers packed as bf16 MFMA fragments by ciaosr_pack_fragments_bf16 (precision mode 1) */
+    /* optional: the same layers packed as 16-bit MFMA fragments: by ciaosr_pack_fragments_bf16 for the _bf16 entries, by
+     * ciaosr_pack_fragments_f16 for the _f16 entries (a struct serves ONE 16-bit element type; the caller keeps one per type) */
     const void* frag16[CIAOSR_MAX_LAYERS];
     /* optional: the rounding residual w - bf16(w) of the same layers, packed by ciaosr_pack_fragments_bf16_lo (NULL = the
-     * bf16 entries run with single-bf16 weights) */
+     * bf16 entries run with single-bf16 weights; ignored by the _f16 entries) */
     const void* frag16_lo[CIAOSR_MAX_LAYERS];
 } ciaosr_mlp_t;
 
@@ -176,6 +182,11 @@ size_t ciaosr_fragment_bf16_bytes(int N, int K);
 int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream);
 /* same layout, holding bf16(W - bf16(W)): the low half of the hi + lo weight pair */
 int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* out, void* stream);
+/* same layout and byte count with IEEE half elements (round-to-nearest-even, saturating at +-65504): the weights of the
+ * _f16 entries.  Half keeps 11 mantissa bits, so ONE MFMA per product passes the PSNR gate that single bf16 weights fail
+ * (DESIGN 4.3); the price is the range: activations and weights beyond 65504 are clamped, below 6e-8 flushed to 0. */
+size_t ciaosr_fragment_f16_bytes(int N, int K);
+int ciaosr_pack_fragments_f16(const float* W, int ld, int N, int K, void* out, void* stream);
 
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
@@ -259,14 +270,21 @@ int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_h
                              const float* coord, const float* cell, int Q, int chunk, float* rgb,
                              const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
                              size_t workspace_bytes, void* stream);
+/* Same with IEEE half MFMA inputs (ciaosr_mlp_t.frag16 packed by ciaosr_pack_fragments_f16; one MFMA per product,
+ * frag16_lo and opt->bf16_single ignored). */
+int ciaosr_head_forward_f16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
+                            const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
+                            const float* coord, const float* cell, int Q, int chunk, float* rgb,
+                            const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
+                            size_t workspace_bytes, void* stream);
 
 /* ---- encoder trunks: gen_feature (net:321-342 RDN, net:393-408 EDSR) -------------------------- */
 typedef struct ciaosr_conv {
     const float* weight; /* [cout][k*k*cin'] packed (a*k+b)*cin' + ci; cin' = cin (4 for the 3-channel first conv, zero padded) */
     const float* bias;   /* [cout] */
     int cin, cout, ksize;
-    const void* frag16;  /* optional: ciaosr_pack_fragments_bf16(weight, ld = k*k*cin, N = cout, K = k*k*cin); used by
-                          * ciaosr_rdn_forward_bf16 for the dense layers, NULL otherwise */
+    const void* frag16;  /* optional: ciaosr_pack_fragments_bf16 / _f16 (weight, ld = k*k*cin, N = cout, K = k*k*cin); used by
+                          * ciaosr_rdn_forward_bf16 / _f16 for the dense layers, NULL otherwise */
     const void* frag16_lo; /* optional: ciaosr_pack_fragments_bf16_lo of the same matrix (hi + lo weight pair of the bf16 trunk) */
     const float* frag;   /* optional: ciaosr_pack_fragments_f32 of the same matrix; lets ciaosr_rdn_forward_f32 run the
                           * dense layers of maps with >= 128 tiles of 12x12 pixels through the halo-resident kernel, and any
@@ -309,6 +327,10 @@ int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_w
 int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                             const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
                             void* stream);
+/* Same with IEEE half operands (ciaosr_conv_t.frag16 packed by ciaosr_pack_fragments_f16; frag16_lo ignored). */
+int ciaosr_rdn_forward_f16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                           const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
+                           void* stream);
 size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w);
 int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w, float* feat_hwc,
                             void* workspace, size_t workspace_bytes, void* stream);
