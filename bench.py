@@ -75,7 +75,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         # >= 64x64 maps run the composed fold+down tail (DESIGN 'cs_attn tail'): 16C value columns instead of 36C
         'csa_attn_v': (2.0 * HW * (HW / 4) * (16 if HW >= 4096 else 36) * C, 'flop'),
         'csa_scores_bf16': (2.0 * HW * (HW / 4) * 4.5 * C, 'flop16'),
-        'csa_attn_v_bf16': (2.0 * HW * (HW / 4) * 25 * C, 'flop16'),
+        'csa_attn_v_bf16': (2.0 * HW * (HW / 4) * 16 * C, 'flop16'),        # main 16C columns; the 9C edge variants run as csa_attn_v_edge
         'csa_attn_v_edge': (2.0 * (2 * side * 4 * C + C) * (HW / 4), 'flop'),
         'csa_down_partial': (2.0 * (side / 2 + 3) ** 2 * 9 * C * 9 * C, 'flop'),
         'csa_down': (2.0 * HW * 9 * C * C, 'flop'),

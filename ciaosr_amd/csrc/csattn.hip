@@ -137,10 +137,25 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
         RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
                      CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));
         RUN(csa_gather_vprime_t_h16(Pc, Hh, Wh, C, VpT, p.Lld8, f16, s));
-        // all 25C columns for every row (the 9C edge-variant columns are only read for row 0 / column 0 pixels)
-        RUN(h.gemm_nt(P16, p.Lld8, VpT, p.Lld8, O, 25 * C, false, HWp, 25 * C, p.Lld8, 1.f, s, f16 ? "csa_attn_v_f16" : "csa_attn_v_bf16"));
-        RUN(csa_gather_out(O, O + 16 * C, O + 20 * C, O + 24 * C, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 25L * C, 25L * C,
-                           (long)p.Wp * 25 * C, s));
+        // main 16C columns for every row on the 16-bit MFMA
+        RUN(h.gemm_nt(P16, p.Lld8, VpT, p.Lld8, O, 16 * C, false, HWp, 16 * C, p.Lld8, 1.f, s, f16 ? "csa_attn_v_f16" : "csa_attn_v_bf16"));
+        // the 9C edge-variant columns are read for row 0 / column 0 pixels only (Wp + Hp of the HWp rows): those rows' 16-bit
+        // probabilities go back to fp32 (exact) and through the fp32 path's three skinny split-K contractions
+        float* Otop = Ov;
+        float* Oleft = Ov + (size_t)p.Wp * 4 * C;
+        float* Otl = Oleft + (size_t)p.Hp * 4 * C;
+        float* Se = S;                                        // the logits are consumed: [Wp + Hp][Lld] fp32 rows fit
+        float* part = reinterpret_cast<float*>(Y);            // so are the 16-bit Q / K copies
+        RUN(csa_gather_vprime(Pc, Hh, Wh, C, Vp, s));
+        RUN(h.rows_to_f32(P16, p.Lld8, 0, 1, p.Wp, p.Lld, Se, p.Lld, s));                               // row 0: pixels 0 .. Wp-1
+        RUN(h.rows_to_f32(P16, p.Lld8, 0, p.Wp, p.Hp, p.Lld, Se + (size_t)p.Wp * p.Lld, p.Lld, s));     // column 0: pixels i * Wp
+        RUN(gemm_f32_splitk(Se, p.Lld, Vp + 16 * C, 25 * C, true, Otop, 4 * C, nullptr, p.Wp, 4 * C, p.L, 1.f, CIAOSR_ACT_NONE,
+                            0.f, part, p.n_Y, s, "csa_attn_v_edge"));
+        RUN(gemm_f32_splitk(Se + (size_t)p.Wp * p.Lld, p.Lld, Vp + 20 * C, 25 * C, true, Oleft, 4 * C, nullptr, p.Hp, 4 * C, p.L, 1.f,
+                            CIAOSR_ACT_NONE, 0.f, part, p.n_Y, s, "csa_attn_v_edge"));
+        RUN(gemm_f32_splitk(Se, p.Lld, Vp + 24 * C, 25 * C, true, Otl, C, nullptr, 1, C, p.L, 1.f, CIAOSR_ACT_NONE, 0.f, part,
+                            p.n_Y, s, "csa_attn_v_edge"));
+        RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 16L * C, 4L * C, 4L * C, s));
         return CIAOSR_OK;
     }
     RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,

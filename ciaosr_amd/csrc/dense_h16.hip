@@ -58,11 +58,19 @@ struct DenseH16P {
     const uint4* wf; int nks;                // ciaosr_pack_fragments_bf16 of the conv weight [64][9*cin]: [2][nks][64 lanes]
     const uint4* wf_lo;                      // ciaosr_pack_fragments_bf16_lo of the same matrix (hi + lo weight pair), or null
     const float* bias;                       // [64]
-    float* x; int ldx;                       // fp32 feature buffer (written at column col_out)
+    float* x; int ldx;                       // fp32 feature buffer (written at column col_out), or null
     unsigned short* xb_out;                  // == xb (written at column col_out)
     int col_out;
 };
 
+#ifndef CIAOSR_DENSE_PF
+#define CIAOSR_DENSE_PF 4
+#endif
+constexpr int DPF = CIAOSR_DENSE_PF;          // weight fragments are requested this many taps ahead (1..8)
+
+// LO: second MFMA per product with the low halves of the weight pairs (bf16 default); compiled out otherwise so that its
+// registers go to a deeper weight pipeline
+template <bool LO>
 __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     const uint4* wl = p.wf + lane;
     const int kpt = 4 * p.groups;            // k16-steps per tap (cin / 16)
     auto frag = [&](int nt, int g, int tap) -> uint4 { return wl[(size_t)(nt * p.nks + tap * kpt + 4 * phys(g) + w) * 64]; };
-    const bool has_lo = p.wf_lo != nullptr;                       // uniform: second MFMA per product with the weights' low halves
+    constexpr bool has_lo = LO;
     const uint4* wll = (has_lo ? p.wf_lo : p.wf) + lane;
     auto frag_lo = [&](int nt, int g, int tap) -> uint4 { return wll[(size_t)(nt * p.nks + tap * kpt + 4 * phys(g) + w) * 64]; };
 
@@ -122,14 +130,13 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
 
-    // prologue: the first two weight stages go out BEFORE the patch (vmcnt retires in order: a later wait on the
+    // prologue: the first DPF weight stages go out BEFORE the patch (vmcnt retires in order: a later wait on the
     // weights would otherwise also wait for the patch)
-    uint4 wq[3][2], wlq[3][2];               // weight fragments (hi, lo) of the current tap and the next two
-    wq[0][0] = frag(0, 0, 0); wq[0][1] = frag(1, 0, 0);
-    wq[1][0] = frag(0, 0, 1); wq[1][1] = frag(1, 0, 1);
-    if (has_lo) {
-        wlq[0][0] = frag_lo(0, 0, 0); wlq[0][1] = frag_lo(1, 0, 0);
-        wlq[1][0] = frag_lo(0, 0, 1); wlq[1][1] = frag_lo(1, 0, 1);
+    uint4 wq[9][2], wlq[9][2];               // weight fragments (hi, lo) by tap; DPF + 1 of them are live at a time
+#pragma unroll
+    for (int tp = 0; tp < DPF; ++tp) {
+        wq[tp][0] = frag(0, 0, tp); wq[tp][1] = frag(1, 0, tp);
+        if (has_lo) { wlq[tp][0] = frag_lo(0, 0, tp); wlq[tp][1] = frag_lo(1, 0, tp); }
     }
 #pragma unroll
     for (int s = 0; s < DLOADS; ++s) load_chunk(s, 0);
@@ -147,12 +154,12 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
             b[0][r] = *reinterpret_cast<const uint4*>(pb + poff[r] - DROW - DPS);      // tap 0
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            {   // weights two taps ahead
-                int ng = g, ntap = tap + 2;
+            {   // weights DPF taps ahead
+                int ng = g, ntap = tap + DPF;
                 if (ntap >= 9) { ntap -= 9; ng = g + 1; }
                 if (ng < G) {
-                    wq[(tap + 2) % 3][0] = frag(0, ng, ntap); wq[(tap + 2) % 3][1] = frag(1, ng, ntap);
-                    if (has_lo) { wlq[(tap + 2) % 3][0] = frag_lo(0, ng, ntap); wlq[(tap + 2) % 3][1] = frag_lo(1, ng, ntap); }
+                    wq[(tap + DPF) % 9][0] = frag(0, ng, ntap); wq[(tap + DPF) % 9][1] = frag(1, ng, ntap);
+                    if (has_lo) { wlq[(tap + DPF) % 9][0] = frag_lo(0, ng, ntap); wlq[(tap + DPF) % 9][1] = frag_lo(1, ng, ntap); }
                 }
             }
             // next group's whole patch right after the tap-3 weights left: the first wait that covers it is tap 4's
@@ -168,21 +175,21 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
             }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const uint4 a = wq[tap % 3][nt];
+                const uint4 a = wq[tap][nt];
 #pragma unroll
                 for (int r = 0; r < DMT; ++r) acc[nt][r] = mfma_h16<kF16>(a, b[tap & 1][r], acc[nt][r]);
             }
             if (has_lo) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const uint4 a = wlq[tap % 3][nt];
+                    const uint4 a = wlq[tap][nt];
 #pragma unroll
                     for (int r = 0; r < DMT; ++r) acc[nt][r] = mfma_h16<kF16>(a, b[tap & 1][r], acc[nt][r]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // 9 taps = 3 full rotations of the weight ring: stages 0 and 1 now hold taps 0 and 1 of the next group
+        // the ring is indexed by tap: stages 0 .. DPF-1 now hold the first taps of the next group
         if (more) store_patch((g + 1) & 1);
         __syncthreads();
     }
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
                 v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
                 v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
                 const size_t pix = (size_t)y * p.W + x;
-                *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
+                if (p.x) *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
                 *reinterpret_cast<uint2*>(p.xb_out + pix * p.ldxb + p.col_out + co) =
                     pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
             }
@@ -251,7 +258,7 @@ int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int co
 // dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb)
 int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
                      const float* bias, hipStream_t s) {
-    CIAOSR_CHECK_ARG(X && Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);
+    CIAOSR_CHECK_ARG(Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);      // X null: no fp32 copy of the output
     const size_t xb_bytes = (size_t)H * W * ldxb * 2;
     CIAOSR_CHECK_ARG(xb_bytes < 0xFFFFFF00ull);
     DenseH16P p;
@@ -262,9 +269,13 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
     p.wf_lo = reinterpret_cast<const uint4*>(frag16_lo);
     p.bias = bias;
     p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
-    CIAOSR_BIG_LDS(dense_h16_kernel, kDenseLds);
+    CIAOSR_BIG_LDS(dense_h16_kernel<true>, kDenseLds);
+    CIAOSR_BIG_LDS(dense_h16_kernel<false>, kDenseLds);
     ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
-    hipLaunchKernelGGL(dense_h16_kernel, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+    if (p.wf_lo)
+        hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+    else
+        hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     return launch_status("dense" CIAOSR_H16_SUFFIX);
 }
 

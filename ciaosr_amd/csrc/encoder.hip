@@ -67,8 +67,9 @@ extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weig
     const int C = w->mid_channels, G = w->growth, cb = C + G * w->num_layers;
     size_t n = HW * 4 + HW * 36 + HW * C /*sfe1*/ + 2 * HW * cb /*block buffers*/ +
                HW * (size_t)G * w->num_blocks /*global concat*/ + HW * C /*gff0*/ + HW * (size_t)G * w->num_layers /*scatter sums*/ +
-               16 * HW * (size_t)(C > G ? C : G) + HW * cb / 2 + 64 /*bf16 copy of one block buffer*/;
-    return n * sizeof(float) + 16 * 256;
+               16 * HW * (size_t)(C > G ? C : G) + HW * cb / 2 + 64 /*16-bit copy of one block buffer*/ +
+               (size_t)w->num_blocks * G * cb / 2 + 64 /*16-bit copies of the lff weights (f16 mode)*/;
+    return n * sizeof(float) + 17 * 256;
 }
 
 static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
@@ -99,6 +100,7 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     const size_t pf = 16 * HW * (size_t)(C > G ? C : G);
     float* part = ar.take<float>(pf);
     unsigned short* Xb = reinterpret_cast<unsigned short*>(ar.take<float>(HW * cb / 2 + 64));
+    unsigned short* Wl16 = reinterpret_cast<unsigned short*>(ar.take<float>((size_t)NB * G * cb / 2 + 64));
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
     // 16-bit modes: the dense layers (97 % of the trunk's MACs) run on the bf16 / f16 MFMA when the map is big enough to give
     // every CU a tile (dense_h16.hip); first/last convolutions, LFF/GFF 1x1 and all residual sums stay fp32
@@ -108,8 +110,23 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     // big maps, fp32: halo-resident gather-form dense layers (dense_f32.hip) instead of the scatter form
     bool dense32 = !dense16 && C == 64 && G == 64 && min_tiles > 0 && dense_f32_tiles(H, W) >= min_tiles;
     for (int i = 0; i < NB * NL && dense32; ++i) dense32 = w->dense[i].frag != nullptr;
+    // f16 mode: the local feature fusion (1x1 over the block's 576 channels) too reads the 16-bit copy of the block buffer, on the
+    // 16-bit GEMM with bias + residual in its epilogue; the dense layers then need no fp32 copy of their outputs, and the epilogue
+    // writes the next block's 16-bit input group.  (bf16 mode keeps the fp32 lff: its weights would need the hi + lo pair.)
+    const bool lff16 = dense16 && prec == kF16 && cb % 8 == 0 && G % 4 == 0 && G <= 128;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    if (lff16) {
+        const float* src[16];
+        for (int b0 = 0; b0 < NB; b0 += 16) {
+            const int n = NB - b0 < 16 ? NB - b0 : 16;
+            for (int i = 0; i < n; ++i) {
+                CIAOSR_CHECK_ARG(conv_ok(w->lff[b0 + i], cb, G, 1));
+                src[i] = w->lff[b0 + i].weight;
+            }
+            RUN(h16_ops(prec).cast_many(src, n, G, cb, Wl16 + (size_t)b0 * G * cb, s));
+        }
+    }
     RUN(first_conv(x_nchw, H, W, w->sfe1, img4, rows, sfe1, C, s));
     // sfe2 -> block 0 input (columns [0, C) of X[0])
     RUN(conv3(sfe1, C, H, W, w->sfe2, X[0], cb, nullptr, 0, CIAOSR_ACT_NONE, 1.f, part, pf, s));
@@ -117,11 +134,20 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
         float* x = X[b & 1];
         float* xn = X[(b + 1) & 1];
         if (dense16) {
-            RUN(h16_ops(prec).cast_group(x, cb, Xb, cb, 0, (long)HW, s));
+            if (!(lff16 && b > 0)) RUN(h16_ops(prec).cast_group(x, cb, Xb, cb, 0, (long)HW, s));     // else: written by the previous lff
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
-                RUN(h16_ops(prec).dense_layer(x, cb, Xb, cb, H, W, l, c.frag16, (prec == kF16 || (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, s));
+                RUN(h16_ops(prec).dense_layer(lff16 ? nullptr : x, cb, Xb, cb, H, W, l, c.frag16,
+                                              (prec == kF16 || (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, s));
+            }
+            if (lff16) {
+                // RDB output = x + lff(dense) from the 16-bit rows: fp32 to the global concat and the next block's input, 16-bit to the
+                // next block's input group (rows of Xb this workgroup alone reads and writes: N = G is one column tile)
+                const bool more = b + 1 < NB;
+                RUN(h16_ops(prec).conv1x1(Xb, cb, Wl16 + (size_t)b * G * cb, cb, w->lff[b].bias, x, cb, Gc + (size_t)b * G, G * NB,
+                                          more ? xn : nullptr, cb, more ? Xb : nullptr, cb, (int)HW, G, cb, s, "enc_conv1x1_f16"));
+                continue;
             }
         } else if (dense32) {
             for (int l = 0; l < NL; ++l) {

@@ -49,6 +49,12 @@ struct Gemm16P {
     int M, N, K;
     float alpha;
     int tiles_n, n_wg;
+    // optional epilogue (full-width quads only use these; all null for the plain GEMM): v = acc * alpha + bias[n] + res[m][n],
+    // written to C and, when given, to a second fp32 matrix C2 and a 16-bit matrix C16
+    const float* bias;
+    const float* res; int ldres;
+    float* C2; int ldc2;
+    unsigned short* C16; int ldc16;
 };
 
 __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
@@ -159,8 +165,18 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
             for (int q = 0; q < 4; ++q) {
                 const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
                 if (n >= p.N) continue;
-                const float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
-                const float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
+                float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
+                float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
+                if (p.bias) {                                              // fused epilogue (host checks N % 4 == 0: whole quads)
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                    v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                    if (p.res) {
+                        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
+                        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                    }
+                    if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)m * p.ldc2 + n) = make_float4(v0, v1, v2, v3);
+                    if (p.C16) *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
+                }
                 if (n + 3 >= p.N) {                                        // ragged last columns
                     const float v[4] = {v0, v1, v2, v3};
                     for (int e = 0; e < 4 && n + e < p.N; ++e) {
@@ -246,6 +262,7 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     Gemm16P p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.c_bf16 = c_bf16 ? 1 : 0;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha;
+    p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.C2 = nullptr; p.ldc2 = 0; p.C16 = nullptr; p.ldc16 = 0;
     const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldb + K) * 2;
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
@@ -272,6 +289,77 @@ int softmax_rows_h16(const float* S, long rows, int L, int ld, unsigned short* P
     if (softmax_rows_reg_h16(S, rows, L, ld, P, ldp, kF16, s)) return launch_status("softmax_rows_reg" CIAOSR_H16_SUFFIX);
     hipLaunchKernelGGL(softmax_rows_h16_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, P, ldp);
     return launch_status("softmax_rows" CIAOSR_H16_SUFFIX);
+}
+
+// 1x1 convolution of a 16-bit channels-last map (the RDB's local feature fusion, mmedit RDB.lff called from
+// ciaosr_net.py:337): out[m][n] = sum_k A[m][k] W16[n][k] + bias[n] + res[m][n], N % 4 == 0, written as fp32 to `out` (and `out2`
+// when given) and as 16-bit to `out16` when given (the next block's input group, which makes its cast launch unnecessary).
+int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int ldw, const float* bias, const float* res, int ldres,
+                float* out, int ldo, float* out2, int ldo2, unsigned short* out16, int ldo16, int M, int N, int K, hipStream_t s,
+                const char* tag) {
+    CIAOSR_CHECK_ARG(A && W16 && bias && out && M > 0 && N > 0 && (N & 3) == 0 && K > 0 && (K & 7) == 0);
+    CIAOSR_CHECK_ARG((lda & 7) == 0 && (ldw & 7) == 0 && (ldo & 3) == 0 && (ldo2 & 3) == 0 && (ldo16 & 3) == 0 && (ldres & 3) == 0);
+    CIAOSR_CHECK_ARG(aligned16(A) && aligned16(W16) && aligned16(out) && aligned16(bias) && (!res || aligned16(res)) &&
+                     (!out2 || aligned16(out2)) && (!out16 || aligned16(out16)));
+    Gemm16P p;
+    p.A = A; p.lda = lda; p.B = W16; p.ldb = ldw; p.C = out; p.ldc = ldo; p.c_bf16 = 0;
+    p.M = M; p.N = N; p.K = K; p.alpha = 1.f;
+    p.bias = bias; p.res = res; p.ldres = ldres; p.C2 = out2; p.ldc2 = ldo2; p.C16 = out16; p.ldc16 = ldo16;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldw + K) * 2;
+    CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    p.tiles_n = ceil_div(N, GN);
+    p.n_wg = ceil_div(M, GM) * p.tiles_n;
+    CIAOSR_BIG_LDS(gemm_h16_kernel, kGemm16Lds);
+    ProfScope prof(tag, s);
+    hipLaunchKernelGGL(gemm_h16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    return launch_status("conv1x1" CIAOSR_H16_SUFFIX);
+}
+
+// rows row0 + r * row_stride (r < nrows) of a 16-bit matrix back to fp32 (exact): dst[r][0 .. cols), cols % 4 == 0
+__global__ void rows_to_f32_h16_kernel(const unsigned short* __restrict__ src, long ld_src, long row0, long row_stride, int nrows, int cols,
+                                       float* __restrict__ dst, int ld_dst) {
+    const int c4n = cols >> 2;
+    const long n = (long)nrows * c4n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int r = (int)(i / c4n), c = (int)(i - (long)r * c4n) * 4;
+        const uint2 v = *reinterpret_cast<const uint2*>(src + (row0 + r * row_stride) * ld_src + c);
+        *reinterpret_cast<float4*>(dst + (size_t)r * ld_dst + c) =
+            make_float4(h16_lo<kF16>(v.x), h16_hi<kF16>(v.x), h16_lo<kF16>(v.y), h16_hi<kF16>(v.y));
+    }
+}
+int rows_to_f32_h16(const unsigned short* src, long ld_src, long row0, long row_stride, int nrows, int cols, float* dst, int ld_dst,
+                    hipStream_t s) {
+    CIAOSR_CHECK_ARG(src && dst && nrows > 0 && cols > 0 && (cols & 3) == 0 && (ld_src & 3) == 0 && (ld_dst & 3) == 0 && cols <= ld_dst);
+    ProfScope prof("rows_to_f32" CIAOSR_H16_SUFFIX, s);
+    const long n = (long)nrows * (cols >> 2);
+    int grid = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(rows_to_f32_h16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, src, ld_src, row0, row_stride, nrows, cols,
+                       dst, ld_dst);
+    return launch_status("rows_to_f32" CIAOSR_H16_SUFFIX);
+}
+
+// up to 16 fp32 matrices [rows][cols] (row stride cols) -> one 16-bit array [n][rows][cols], one launch
+struct CastManyP { const float* src[16]; int n; long each; };
+__global__ void cast_many_h16_kernel(CastManyP p, unsigned short* __restrict__ dst) {
+    const long total = (long)p.n * p.each / 4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int m = (int)(e / p.each);
+        const float4 v = *reinterpret_cast<const float4*>(p.src[m] + (e - (long)m * p.each));
+        *reinterpret_cast<uint2*>(dst + e) = pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
+    }
+}
+int cast_many_h16(const float* const* src, int n, int rows, int cols, unsigned short* dst, hipStream_t s) {
+    CIAOSR_CHECK_ARG(src && dst && n >= 1 && n <= 16 && ((long)rows * cols) % 4 == 0);
+    CastManyP p;
+    for (int i = 0; i < 16; ++i) p.src[i] = i < n ? src[i] : nullptr;
+    for (int i = 0; i < n; ++i) CIAOSR_CHECK_ARG(src[i] && aligned16(src[i]));
+    p.n = n; p.each = (long)rows * cols;
+    ProfScope prof("cast_weights" CIAOSR_H16_SUFFIX, s);
+    const long total = (long)n * p.each / 4;
+    hipLaunchKernelGGL(cast_many_h16_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, p, dst);
+    return launch_status("cast_weights" CIAOSR_H16_SUFFIX);
 }
 
 }  // namespace CIAOSR_H16_NS

@@ -153,7 +153,13 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
     int dense_h16_tiles(int H, int W);                                                                                                \
     int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);                       \
     int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,                     \
-                        const void* frag16_lo, const float* bias, hipStream_t s);
+                        const void* frag16_lo, const float* bias, hipStream_t s);                                                     \
+    int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int ldw, const float* bias, const float* res,        \
+                    int ldres, float* out, int ldo, float* out2, int ldo2, unsigned short* out16, int ldo16, int M, int N, int K,     \
+                    hipStream_t s, const char* tag);                                                                                  \
+    int cast_many_h16(const float* const* src, int n, int rows, int cols, unsigned short* dst, hipStream_t s);                       \
+    int rows_to_f32_h16(const unsigned short* src, long ld_src, long row0, long row_stride, int nrows, int cols, float* dst,          \
+                        int ld_dst, hipStream_t s);
 namespace b16 { CIAOSR_H16_DECLS }
 namespace f16 { CIAOSR_H16_DECLS }
 #undef CIAOSR_H16_DECLS
@@ -168,12 +174,17 @@ struct H16Ops {
     decltype(&b16::head_decode_fused_h16) head_decode_fused;
     decltype(&b16::cast_group_h16) cast_group;
     decltype(&b16::dense_layer_h16) dense_layer;
+    decltype(&b16::conv1x1_h16) conv1x1;
+    decltype(&b16::cast_many_h16) cast_many;
+    decltype(&b16::rows_to_f32_h16) rows_to_f32;
 };
 inline const H16Ops& h16_ops(Prec prec) {
     static const H16Ops kB = {b16::gemm_h16_nt, b16::cast_rows_h16, b16::softmax_rows_h16, b16::head_kv_fused_h16,
-                              b16::head_decode_fused_h16, b16::cast_group_h16, b16::dense_layer_h16};
+                              b16::head_decode_fused_h16, b16::cast_group_h16, b16::dense_layer_h16, b16::conv1x1_h16,
+                              b16::cast_many_h16, b16::rows_to_f32_h16};
     static const H16Ops kH = {f16::gemm_h16_nt, f16::cast_rows_h16, f16::softmax_rows_h16, f16::head_kv_fused_h16,
-                              f16::head_decode_fused_h16, f16::cast_group_h16, f16::dense_layer_h16};
+                              f16::head_decode_fused_h16, f16::cast_group_h16, f16::dense_layer_h16, f16::conv1x1_h16,
+                              f16::cast_many_h16, f16::rows_to_f32_h16};
     return prec == kF16 ? kH : kB;
 }
 

@@ -517,8 +517,8 @@ def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw):
 
 def _rdn_trunk_bf16_emulation(x, P, nb, nl, single=False, f16=False):
     """torch-CPU RDN trunk with the 16-bit modes' rounding points: dense-layer inputs rounded to bf16, weights as the
-    bf16 pair hi + lo (or hi alone when `single`) -- or inputs and weights rounded to IEEE half when `f16`; products are
-    then exact in fp32; fp32 accumulation, everything else fp32."""
+    bf16 pair hi + lo (or hi alone when `single`) -- or inputs and weights rounded to IEEE half when `f16`, where the 1x1
+    local feature fusion runs on the 16-bit rows too; products are then exact in fp32; fp32 accumulation, everything else fp32."""
     F = torch.nn.functional
     bf = (lambda t: t.half().float()) if f16 else (lambda t: t.bfloat16().float())
     bw = bf if (single or f16) else (lambda t: bf(t) + bf(t - bf(t)))
@@ -530,7 +530,10 @@ def _rdn_trunk_bf16_emulation(x, P, nb, nl, single=False, f16=False):
         for l in range(nl):
             inp = torch.cat([bf(f) for f in feats], 1)
             feats.append(F.relu(F.conv2d(inp, bw(P[f'rdbs.{b}.layers.{l}.conv.weight']), P[f'rdbs.{b}.layers.{l}.conv.bias'], padding=1)))
-        cur = cur + F.conv2d(torch.cat(feats, 1), P[f'rdbs.{b}.lff.weight'], P[f'rdbs.{b}.lff.bias'])
+        if f16:     # f16 mode: the 1x1 local feature fusion reads the same 16-bit rows, weights rounded to half; fp32 residual
+            cur = cur + F.conv2d(torch.cat([bf(f) for f in feats], 1), bf(P[f'rdbs.{b}.lff.weight']), P[f'rdbs.{b}.lff.bias'])
+        else:
+            cur = cur + F.conv2d(torch.cat(feats, 1), P[f'rdbs.{b}.lff.weight'], P[f'rdbs.{b}.lff.bias'])
         outs.append(cur)
     g = F.conv2d(torch.cat(outs, 1), P['gff.0.weight'], P['gff.0.bias'])
     return F.conv2d(g, P['gff.1.weight'], P['gff.1.bias'], padding=1) + sfe1

@@ -1,5 +1,6 @@
 """Developer lab: per-kernel time of one C3 tile (192x192 LR -> 768x768) under option variants, one process, one GPU.
-   python tools/kernel_lab.py [variant ...]     variants: name=precision[,field=value...]"""
+   python tools/kernel_lab.py [--quick] [variant ...]     variants: name=precision[,field=value...]
+   --quick skips the tile-stream timings; CIAOSR_HIP_LIB=<path> selects another build of the library (A/B of kernel variants)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +13,8 @@ model = rdn_ciaosr(dict(scale=4, tile=192, tile_overlap=32))
 seeded_init_(model, seed=0, gain=1.0)
 model = model.to(dev)
 lq = synthetic_pair(192, 192, 4)[0].to(dev)
-variants = sys.argv[1:] or ['fp32=fp32', 'bf16=bf16', 'bf16_single=bf16,bf16_single=1']
+quick = '--quick' in sys.argv
+variants = [a for a in sys.argv[1:] if a != '--quick'] or ['fp32=fp32', 'bf16=bf16', 'bf16_single=bf16,bf16_single=1']
 ref = None
 for v in variants:
     name, spec = v.split('=', 1)
@@ -31,9 +33,11 @@ for v in variants:
     print(f'{name:12s} {ms:8.3f} ms/tile  max|d vs first| {d.max().item():.2e} rms {d.pow(2).mean().sqrt().item():.2e}  ' +
           ' '.join(f'{k}={x["total_ms"]:.2f}' for k, x in top), flush=True)
 
+if quick:
+    sys.exit(0)
 # tile-stream concurrency on the 6-tile image
 lq6 = synthetic_pair(339, 510, 4)[0].to(dev)
-for prec in ('fp32', 'bf16'):
+for prec in ('fp32', 'bf16', 'f16'):
     for ns in (1, 2, 3):
         model.test_cfg['tile_streams'] = ns
         model.restore(lq6, options=prec)
