@@ -131,8 +131,15 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
         unsigned short* VpT = reinterpret_cast<unsigned short*>(V);
         RUN(h.cast_rows(Qp, Kq, Qb, Kq, HWp, Kq, s));
         RUN(h.cast_rows(Kn, Kq, Kb, Kq, p.L, Kq, s));
-        RUN(h.gemm_nt(Qb, Kq, Kb, Kq, S, p.Lld, false, HWp, p.L, Kq, w->softmax_scale, s, f16 ? "csa_scores_f16" : "csa_scores_bf16"));
-        RUN(h.softmax_rows(S, HWp, p.L, p.Lld, P16, p.Lld8, s));
+        // probabilities straight from the contraction (two passes over the short-K GEMM, no fp32 logit matrix, no softmax kernel);
+        // the logits buffer serves as the statistics scratch
+        if (h.softmax_gemm_scratch(HWp, p.L) <= p.n_S) {
+            RUN(h.softmax_gemm_nt(Qb, Kq, Kb, Kq, P16, p.Lld8, HWp, p.L, Kq, w->softmax_scale, S, p.n_S, s,
+                                  f16 ? "csa_scores_f16" : "csa_scores_bf16"));
+        } else {
+            RUN(h.gemm_nt(Qb, Kq, Kb, Kq, S, p.Lld, false, HWp, p.L, Kq, w->softmax_scale, s, f16 ? "csa_scores_f16" : "csa_scores_bf16"));
+            RUN(h.softmax_rows(S, HWp, p.L, p.Lld, P16, p.Lld8, s));
+        }
         RUN(patch_rows(E, C, p.Hp, p.Wp, C, 3, 2, 3, Hh + 3, Wh + 3, PE, 9 * C, 0, 0.f, s, "csa_patch_down"));
         RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
                      CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));

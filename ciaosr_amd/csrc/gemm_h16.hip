@@ -49,25 +49,37 @@ struct Gemm16P {
     int M, N, K;
     float alpha;
     int tiles_n, n_wg;
+    int tn_per_wg, groups_n;   // column tiles per workgroup (consecutive, one software pipeline) and groups of them per row tile
     // optional epilogue (full-width quads only use these; all null for the plain GEMM): v = acc * alpha + bias[n] + res[m][n],
     // written to C and, when given, to a second fp32 matrix C2 and a 16-bit matrix C16
     const float* bias;
     const float* res; int ldres;
     float* C2; int ldc2;
     unsigned short* C16; int ldc16;
+    // row-softmax epilogues (EPI 1 / 2): the logits alpha * A.B^T never go to memory.
+    //   EPI 1: per (row, 64-column wave strip) partial (max, sum of exp(v - max)) -> part[row][2 * tile_n + wn]
+    //   EPI 2: stats[row] = (row max, 1 / row sum) -> probabilities exp(v - max) / sum as 16-bit into C16 (columns [N, npad) zeroed)
+    float2* part; int n_part;
+    const float2* stats; int npad;
 };
 
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
     unsigned char* As = lds16;                    // [2][GM][GRS]
     unsigned char* Bs = lds16 + 2 * GA_T;         // [2][GN][GRS]
 
-    // XCD-aware remap (as gemm_f32.hip): each XCD walks a contiguous run of tiles sharing A row panels
+    // XCD-aware remap (as gemm_f32.hip): each XCD walks a contiguous run of work items sharing A row panels.
+    // A work item = tn_per_wg consecutive column tiles of one row tile: their k-loops run as ONE software pipeline (the loads
+    // of the next tile's first stages are in flight under the current tile's epilogue), which is what a short-K contraction
+    // (K = a few k-tiles) needs -- with one tile per workgroup it is all prologue and epilogue.
     const int bid = blockIdx.x;
     const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int m0 = (lid / p.tiles_n) * GM, n0 = (lid % p.tiles_n) * GN;
+    const int m0 = (lid / p.groups_n) * GM;
+    const int tile0 = (lid % p.groups_n) * p.tn_per_wg;
+    const int ntl = p.tiles_n - tile0 < p.tn_per_wg ? p.tiles_n - tile0 : p.tn_per_wg;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1, li = lane & 31, lh = lane >> 5;
@@ -77,28 +89,29 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
     // staging: 16-byte chunk c = t + 256 s -> row c / GCH, k-part c % GCH
     constexpr int RS = 256 / GCH;                 // rows covered per staging step
     const int part = t % GCH, row0 = t / GCH;     // rows row0 + RS s
-    unsigned a_off[GSA], b_off[GSB];
+    unsigned a_off[GSA];
 #pragma unroll
     for (int s = 0; s < GSA; ++s) {
         const int gm = m0 + row0 + RS * s;
         a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 2u + (unsigned)part * 16u : kOob16;
     }
-#pragma unroll
-    for (int s = 0; s < GSB; ++s) {
-        const int gn = n0 + row0 + RS * s;
-        b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u : kOob16;
-    }
     i32x4 ra[2][GSA], rb[2][GSB];            // two k-tiles in flight
     const int swz = (row0 >> 2) & 3;              // RS is a multiple of 16: the swizzle key of rows row0 + RS s is that of row0
-    auto load_stage = [&](int kt, int set) {
-        const int k0 = kt * GK;
+    const int nk = (p.K + GK - 1) / GK;
+    int ld_tile = tile0, ld_k = 0;                // load pointer: next (column tile, k-tile) to request
+    auto load_next = [&](int set) {
+        const int k0 = ld_k * GK;
         const bool kok = k0 + part * 8 < p.K;     // K % 8 == 0: a chunk is entirely in or out
 #pragma unroll
         for (int s = 0; s < GSA; ++s)
             ra[set][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (kok && a_off[s] != kOob16) ? (int)(a_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
 #pragma unroll
-        for (int s = 0; s < GSB; ++s)
-            rb[set][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, (kok && b_off[s] != kOob16) ? (int)(b_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+        for (int s = 0; s < GSB; ++s) {
+            const int gn = ld_tile * GN + row0 + RS * s;
+            rb[set][s] = __builtin_amdgcn_raw_buffer_load_b128(
+                rs_b, (kok && gn < p.N) ? (int)((unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+        }
+        if (++ld_k == nk) { ld_k = 0; ++ld_tile; }
     };
     auto store_stage = [&](int buf, int set) {
 #pragma unroll
@@ -108,30 +121,121 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
     };
 
     f32x16 acc[4][2];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+    };
+    zero_acc();
 
-    const int nk = (p.K + GK - 1) / GK;
-    load_stage(0, 0);
-    if (nk > 1) load_stage(1, 1);
-    store_stage(0, 0);                            // waits for k-tile 0 only (vmcnt retires in order)
+    // epilogue of the column tile at n0: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li,
+    // columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
+    auto epilogue = [&](int n0) {
+        if constexpr (EPI == 1) {
+            // partial softmax statistics of this wave's 64-column strip: a row's 32 values sit in two lanes (li, li + 32)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + 128 * wm + 32 * mt + li;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) mx = fmaxf(mx, acc[mt][nt][4 * q + e] * p.alpha);
+                float sum = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) sum += __expf(acc[mt][nt][4 * q + e] * p.alpha - mx);
+                const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sum, 32, 64);
+                const float mm = fmaxf(mx, mo);
+                // a strip with no valid column on either lane keeps (-inf, 0): exp(-inf - -inf) is avoided
+                const float tot = (mx == -INFINITY ? 0.f : sum * __expf(mx - mm)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mm));
+                if (lh == 0 && m < p.M) p.part[(size_t)m * p.n_part + 2 * (n0 / GN) + wn] = make_float2(mm, tot);
+            }
+        } else if constexpr (EPI == 2) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + 128 * wm + 32 * mt + li;
+                if (m >= p.M) continue;
+                const float2 st = p.stats[m];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
+                        if (n >= p.npad) continue;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = n + e < p.N ? __expf(acc[mt][nt][4 * q + e] * p.alpha - st.x) * st.y : 0.f;
+                        *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v[0], v[1], v[2], v[3]);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + 128 * wm + 32 * mt + li;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
+                        if (n >= p.N) continue;
+                        float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
+                        float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
+                        if (p.bias) {                                              // fused epilogue (host checks N % 4 == 0: whole quads)
+                            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                            if (p.res) {
+                                const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
+                                v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                            }
+                            if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)m * p.ldc2 + n) = make_float4(v0, v1, v2, v3);
+                            if (p.C16) *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
+                        }
+                        if (n + 3 >= p.N) {                                        // ragged last columns
+                            const float v[4] = {v0, v1, v2, v3};
+                            for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                                if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = to_h16<kF16>(v[e]);
+                                else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = v[e];
+                            }
+                        } else if (p.c_bf16)
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
+                                pack_h16x4<kF16>(v0, v1, v2, v3);
+                        else
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
+                    }
+            }
+        }
+    };
+
+    const int total = ntl * nk;                   // flattened (column tile, k-tile) iterations of this workgroup
+    load_next(0);
+    if (total > 1) load_next(1);
+    store_stage(0, 0);                            // waits for the first k-tile only (vmcnt retires in order)
     __syncthreads();
     const int lswz = (li >> 2) & 3;               // swizzle key of the lane's rows (row = multiple of 32 + li)
     const unsigned char* a_base = As + (128 * wm + li) * GRS;
     const unsigned char* b_base = Bs + (64 * wn + li) * GRS;
-    // k-tile kt is computed from LDS buffer kt & 1 while k-tile kt + 1 sits in register set (kt + 1) & 1 (loaded one
-    // iteration ago) and k-tile kt + 2 is requested into set kt & 1; kt + 1 goes to LDS at the END of the iteration
+    int c_tile = tile0, c_k = 0;                  // compute pointer
+    // iteration i is computed from LDS buffer i & 1 while iteration i + 1 sits in register set (i + 1) & 1 (loaded one
+    // iteration ago) and iteration i + 2 is requested into set i & 1; i + 1 goes to LDS at the END of the iteration
 #pragma unroll 1
-    for (int kt = 0; kt < nk; kt += 2) {
+    for (int it = 0; it < total; it += 2) {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {    // unrolled by 2 so that the register-set indices are compile-time
-            const int k = kt + half;
-            if (k < nk) {
-                if (k + 2 < nk) load_stage(k + 2, half);
+            const int i = it + half;
+            if (i < total) {
+                if (i + 2 < total) load_next(half);
                 const unsigned char* a = a_base + half * GA_T;
                 const unsigned char* b = b_base + half * GB_T;
 #pragma unroll
@@ -148,48 +252,19 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
                         for (int mt = 0; mt < 4; ++mt)
                             acc[mt][nt] = mfma_h16<kF16>(fb[nt], fa[mt], acc[mt][nt]);
                 }
-                if (k + 1 < nk) store_stage(half ^ 1, half ^ 1);       // k-tile k + 1: requested one iteration ago
+                if (i + 1 < total) store_stage(half ^ 1, half ^ 1);       // iteration i + 1: requested one iteration ago
+                if constexpr (EPI != 0) {         // the store epilogue (EPI 0) is fat and runs once: after the loop, one tile per workgroup
+                    if (++c_k == nk) {            // last k-tile of a column tile: its epilogue runs while the next loads fly
+                        epilogue(c_tile * GN);
+                        zero_acc();
+                        c_k = 0; ++c_tile;
+                    }
+                }
                 __syncthreads();
             }
         }
     }
-
-    // epilogue: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li, columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + 128 * wm + 32 * mt + li;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
-                if (n >= p.N) continue;
-                float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
-                float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
-                if (p.bias) {                                              // fused epilogue (host checks N % 4 == 0: whole quads)
-                    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                    v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
-                    if (p.res) {
-                        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
-                        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
-                    }
-                    if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)m * p.ldc2 + n) = make_float4(v0, v1, v2, v3);
-                    if (p.C16) *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
-                }
-                if (n + 3 >= p.N) {                                        // ragged last columns
-                    const float v[4] = {v0, v1, v2, v3};
-                    for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                        if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = to_h16<kF16>(v[e]);
-                        else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = v[e];
-                    }
-                } else if (p.c_bf16)
-                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
-                        pack_h16x4<kF16>(v0, v1, v2, v3);
-                else
-                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
-            }
-    }
+    if constexpr (EPI == 0) epilogue(tile0 * GN);     // host: tn_per_wg == 1
 }
 
 // fp32 rows -> bf16 rows (first `cols` columns, cols % 4 == 0); pad columns [cols, ld_dst) are zeroed
@@ -263,14 +338,16 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.c_bf16 = c_bf16 ? 1 : 0;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha;
     p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.C2 = nullptr; p.ldc2 = 0; p.C16 = nullptr; p.ldc16 = 0;
+    p.part = nullptr; p.n_part = 0; p.stats = nullptr; p.npad = 0;
     const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldb + K) * 2;
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    p.n_wg = ceil_div(M, GM) * p.tiles_n;
-    CIAOSR_BIG_LDS(gemm_h16_kernel, kGemm16Lds);
+    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
+    p.n_wg = ceil_div(M, GM) * p.groups_n;
+    CIAOSR_BIG_LDS(gemm_h16_kernel<0>, kGemm16Lds);
     ProfScope prof(tag ? tag : "gemm" CIAOSR_H16_SUFFIX, s);
-    hipLaunchKernelGGL(gemm_h16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    hipLaunchKernelGGL(gemm_h16_kernel<0>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
     return launch_status("gemm" CIAOSR_H16_SUFFIX);
 }
 
@@ -305,15 +382,76 @@ int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int
     p.A = A; p.lda = lda; p.B = W16; p.ldb = ldw; p.C = out; p.ldc = ldo; p.c_bf16 = 0;
     p.M = M; p.N = N; p.K = K; p.alpha = 1.f;
     p.bias = bias; p.res = res; p.ldres = ldres; p.C2 = out2; p.ldc2 = ldo2; p.C16 = out16; p.ldc16 = ldo16;
+    p.part = nullptr; p.n_part = 0; p.stats = nullptr; p.npad = 0;
     const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldw + K) * 2;
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    p.n_wg = ceil_div(M, GM) * p.tiles_n;
-    CIAOSR_BIG_LDS(gemm_h16_kernel, kGemm16Lds);
+    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
+    p.n_wg = ceil_div(M, GM) * p.groups_n;
+    CIAOSR_BIG_LDS(gemm_h16_kernel<0>, kGemm16Lds);
     ProfScope prof(tag, s);
-    hipLaunchKernelGGL(gemm_h16_kernel, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    hipLaunchKernelGGL(gemm_h16_kernel<0>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
     return launch_status("conv1x1" CIAOSR_H16_SUFFIX);
+}
+
+// P = row_softmax(alpha * A . B^T) as 16-bit rows [M][ldp] (pad columns [N, ldp) zeroed) WITHOUT materialising the logits:
+// the contraction runs twice (K is short: the correlation scores of CrossScaleAttention have K = 9C/2 against N = L columns) --
+// pass 1 leaves per-strip (max, sum) partials, a merge kernel turns them into (row max, 1 / row sum), pass 2 recomputes the same
+// logits (same code, same order: bit-identical) and writes exp(v - max) / sum.  Replaces an fp32 logit matrix written once and
+// read once plus a separate row-softmax kernel.  scratch: M * (2 * ceil(N / 128) + 1) float2.
+__global__ void softmax_stats_merge_kernel(const float2* __restrict__ part, int n_part, long M, float2* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float2* pr = part + (size_t)row * n_part;
+    float mx = -INFINITY;
+    for (int i = lane; i < n_part; i += 64) mx = fmaxf(mx, pr[i].x);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int i = lane; i < n_part; i += 64) {
+        const float2 v = pr[i];
+        if (v.x != -INFINITY) sum += v.y * __expf(v.x - mx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) stats[row] = make_float2(mx, 1.f / sum);
+}
+
+size_t softmax_gemm_scratch_floats(long M, int N) { return (size_t)M * (2 * (size_t)ceil_div(N, GN) + 1) * 2 + 64; }
+
+int softmax_gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, unsigned short* P, int ldp, int M, int N, int K,
+                        float alpha, float* scratch, size_t scratch_floats, hipStream_t s, const char* tag) {
+    if (M <= 0 || N <= 0) return CIAOSR_OK;
+    CIAOSR_CHECK_ARG(A && B && P && scratch && K > 0 && (K & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && (ldp & 7) == 0 && ldp >= N);
+    CIAOSR_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(P) && aligned16(scratch) && scratch_floats >= softmax_gemm_scratch_floats(M, N));
+    Gemm16P p;
+    p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = nullptr; p.ldc = 0; p.c_bf16 = 0;
+    p.M = M; p.N = N; p.K = K; p.alpha = alpha;
+    p.bias = nullptr; p.res = nullptr; p.ldres = 0; p.C2 = nullptr; p.ldc2 = 0; p.C16 = P; p.ldc16 = ldp;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldb + K) * 2;
+    CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    p.tiles_n = ceil_div(N, GN);
+    // One column tile per workgroup.  Several consecutive tiles in one software pipeline (tn_per_wg = 2 .. 8: the kernel supports it)
+    // measured the same 0.75 ms on the 192x192 tile's scores (M = 36864, N = 9216, K = 288): each 256 x 128 tile pulls 221 KB
+    // through L2 for 18.9 MFLOP, 2.3 GB per pass at ~6.5 TB/s -- the contraction is bound by L2 -> CU bandwidth, not by its
+    // prologue / epilogue latency.
+    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
+    p.n_wg = ceil_div(M, GM) * p.groups_n;
+    p.n_part = 2 * p.tiles_n;
+    p.part = reinterpret_cast<float2*>(scratch);
+    float2* stats = p.part + (size_t)M * p.n_part;
+    p.stats = stats;
+    p.npad = (int)round_up((size_t)N, 8) <= ldp ? (int)round_up((size_t)N, 8) : ldp;
+    CIAOSR_BIG_LDS(gemm_h16_kernel<1>, kGemm16Lds);
+    CIAOSR_BIG_LDS(gemm_h16_kernel<2>, kGemm16Lds);
+    ProfScope prof(tag, s);
+    hipLaunchKernelGGL(gemm_h16_kernel<1>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    hipLaunchKernelGGL(softmax_stats_merge_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, p.part, p.n_part, (long)M, stats);
+    hipLaunchKernelGGL(gemm_h16_kernel<2>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    return launch_status("softmax_gemm" CIAOSR_H16_SUFFIX);
 }
 
 // rows row0 + r * row_stride (r < nrows) of a 16-bit matrix back to fp32 (exact): dst[r][0 .. cols), cols % 4 == 0

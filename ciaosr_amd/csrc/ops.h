@@ -158,6 +158,9 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
                     int ldres, float* out, int ldo, float* out2, int ldo2, unsigned short* out16, int ldo16, int M, int N, int K,     \
                     hipStream_t s, const char* tag);                                                                                  \
     int cast_many_h16(const float* const* src, int n, int rows, int cols, unsigned short* dst, hipStream_t s);                       \
+    size_t softmax_gemm_scratch_floats(long M, int N);                                                                                \
+    int softmax_gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, unsigned short* P, int ldp, int M,    \
+                            int N, int K, float alpha, float* scratch, size_t scratch_floats, hipStream_t s, const char* tag);        \
     int rows_to_f32_h16(const unsigned short* src, long ld_src, long row0, long row_stride, int nrows, int cols, float* dst,          \
                         int ld_dst, hipStream_t s);
 namespace b16 { CIAOSR_H16_DECLS }
@@ -177,14 +180,18 @@ struct H16Ops {
     decltype(&b16::conv1x1_h16) conv1x1;
     decltype(&b16::cast_many_h16) cast_many;
     decltype(&b16::rows_to_f32_h16) rows_to_f32;
+    decltype(&b16::softmax_gemm_h16_nt) softmax_gemm_nt;
+    decltype(&b16::softmax_gemm_scratch_floats) softmax_gemm_scratch;
 };
 inline const H16Ops& h16_ops(Prec prec) {
     static const H16Ops kB = {b16::gemm_h16_nt, b16::cast_rows_h16, b16::softmax_rows_h16, b16::head_kv_fused_h16,
                               b16::head_decode_fused_h16, b16::cast_group_h16, b16::dense_layer_h16, b16::conv1x1_h16,
-                              b16::cast_many_h16, b16::rows_to_f32_h16};
+                              b16::cast_many_h16, b16::rows_to_f32_h16, b16::softmax_gemm_h16_nt,
+                              b16::softmax_gemm_scratch_floats};
     static const H16Ops kH = {f16::gemm_h16_nt, f16::cast_rows_h16, f16::softmax_rows_h16, f16::head_kv_fused_h16,
                               f16::head_decode_fused_h16, f16::cast_group_h16, f16::dense_layer_h16, f16::conv1x1_h16,
-                              f16::cast_many_h16, f16::rows_to_f32_h16};
+                              f16::cast_many_h16, f16::rows_to_f32_h16, f16::softmax_gemm_h16_nt,
+                              f16::softmax_gemm_scratch_floats};
     return prec == kF16 ? kH : kB;
 }
 
