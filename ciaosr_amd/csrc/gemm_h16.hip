@@ -368,6 +368,79 @@ int softmax_rows_h16(const float* S, long rows, int L, int ld, unsigned short* P
     return launch_status("softmax_rows" CIAOSR_H16_SUFFIX);
 }
 
+// ---- skinny 1x1 convolution: N = 64 output channels, K <= 576 -------------------------------------------------------------------
+// The 256 x 128 GEMM tile above is latency-bound on this shape (M = 36864, N = 64, K = 576: 144 workgroups, two 24-KB k-tiles in
+// flight each: 37 us against ~15 us of memory time).  Here the WEIGHTS are the resident operand -- [64][K] 16-bit in LDS (74 KB,
+// two workgroups per CU) -- and every wave streams one 32-row tile of A straight from memory into MFMA operand registers: all
+// K / 16 fragment loads of the tile (16 B per lane each) are issued before anything waits, so a wave has 36 loads in flight instead
+// of 6.  Epilogue as conv1x1_h16 (bias, fp32 residual, fp32 + fp32 + 16-bit outputs).
+constexpr int SK_KS = 36;                      // k16-steps held in registers (K <= 576)
+constexpr int SK_N = 64;
+struct Skinny16P {
+    const unsigned short* A; int lda; unsigned a_bytes;
+    const unsigned short* W; int ldw;          // [64][ldw]
+    const float* bias;
+    const float* res; int ldres;
+    float* out; int ldo;
+    float* out2; int ldo2;
+    unsigned short* out16; int ldo16;
+    int M, K, nks, wpitch;                     // wpitch: LDS row pitch in bytes
+};
+
+__global__ __launch_bounds__(256, 2) void conv1x1_skinny_h16_kernel(Skinny16P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];      // [64][wpitch]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int rt = blockIdx.x * 4 + w;                                      // 32-row tile of this wave
+    const int row = rt * 32 + li;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, p.a_bytes, 0x00020000);
+    // the wave's whole A tile: fragment ks of lane (li, lh) = A[row][16 ks + 8 lh .. + 7]
+    i32x4 af[SK_KS];
+    const unsigned abase = row < p.M ? (unsigned)row * (unsigned)p.lda * 2u + (unsigned)lh * 16u : kOob16;
+#pragma unroll
+    for (int ks = 0; ks < SK_KS; ++ks)
+        af[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (abase != kOob16 && ks < p.nks) ? (int)(abase + (unsigned)ks * 32u) : (int)kOob16, 0, 0);
+    // weights -> LDS (16-byte chunks; row pitch K * 2 + 16 B keeps the 32 rows of a ds_read_b128 on distinct bank quads)
+    const int cpr = p.K >> 3;                                               // chunks per row
+    for (int c = t; c < SK_N * cpr; c += 256) {
+        const int r = c / cpr, k8 = c - r * cpr;
+        *reinterpret_cast<uint4*>(wl + r * p.wpitch + k8 * 16) = *reinterpret_cast<const uint4*>(p.W + (size_t)r * p.ldw + k8 * 8);
+    }
+    __syncthreads();
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    const unsigned char* wrow = wl + li * p.wpitch + lh * 16;
+#pragma unroll
+    for (int ks = 0; ks < SK_KS; ++ks) {
+        if (ks < p.nks) {
+            const uint4 a = make_uint4((unsigned)af[ks].x, (unsigned)af[ks].y, (unsigned)af[ks].z, (unsigned)af[ks].w);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const uint4 wf = *reinterpret_cast<const uint4*>(wrow + nt * 32 * p.wpitch + ks * 32);
+                acc[nt] = mfma_h16<kF16>(wf, a, acc[nt]);
+            }
+        }
+    }
+    if (row >= p.M) return;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 32 * nt + 8 * q + 4 * lh;
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            float v0 = acc[nt][4 * q] + b.x, v1 = acc[nt][4 * q + 1] + b.y, v2 = acc[nt][4 * q + 2] + b.z, v3 = acc[nt][4 * q + 3] + b.w;
+            if (p.res) {
+                const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldres + n);
+                v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+            }
+            *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldo + n) = make_float4(v0, v1, v2, v3);
+            if (p.out2) *reinterpret_cast<float4*>(p.out2 + (size_t)row * p.ldo2 + n) = make_float4(v0, v1, v2, v3);
+            if (p.out16) *reinterpret_cast<uint2*>(p.out16 + (size_t)row * p.ldo16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
+        }
+}
+
 // 1x1 convolution of a 16-bit channels-last map (the RDB's local feature fusion, mmedit RDB.lff called from
 // ciaosr_net.py:337): out[m][n] = sum_k A[m][k] W16[n][k] + bias[n] + res[m][n], N % 4 == 0, written as fp32 to `out` (and `out2`
 // when given) and as 16-bit to `out16` when given (the next block's input group, which makes its cast launch unnecessary).
@@ -378,6 +451,18 @@ int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int
     CIAOSR_CHECK_ARG((lda & 7) == 0 && (ldw & 7) == 0 && (ldo & 3) == 0 && (ldo2 & 3) == 0 && (ldo16 & 3) == 0 && (ldres & 3) == 0);
     CIAOSR_CHECK_ARG(aligned16(A) && aligned16(W16) && aligned16(out) && aligned16(bias) && (!res || aligned16(res)) &&
                      (!out2 || aligned16(out2)) && (!out16 || aligned16(out16)));
+    if (N == SK_N && (K & 15) == 0 && K <= SK_KS * 16 && ((size_t)(M - 1) * lda + K) * 2 < 0xFFFFFF00ull) {
+        Skinny16P q;
+        q.A = A; q.lda = lda; q.a_bytes = (unsigned)(((size_t)(M - 1) * lda + K) * 2);
+        q.W = W16; q.ldw = ldw; q.bias = bias; q.res = res; q.ldres = ldres;
+        q.out = out; q.ldo = ldo; q.out2 = out2; q.ldo2 = ldo2; q.out16 = out16; q.ldo16 = ldo16;
+        q.M = M; q.K = K; q.nks = K >> 4; q.wpitch = K * 2 + 16;
+        const size_t lds = (size_t)SK_N * q.wpitch;
+        CIAOSR_BIG_LDS(conv1x1_skinny_h16_kernel, lds);
+        ProfScope prof(tag, s);
+        hipLaunchKernelGGL(conv1x1_skinny_h16_kernel, dim3(ceil_div(M, 128)), dim3(256), lds, s, q);
+        return launch_status("conv1x1_skinny" CIAOSR_H16_SUFFIX);
+    }
     Gemm16P p;
     p.A = A; p.lda = lda; p.B = W16; p.ldb = ldw; p.C = out; p.ldc = ldo; p.c_bf16 = 0;
     p.M = M; p.N = N; p.K = K; p.alpha = 1.f;

@@ -184,8 +184,24 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     for (int i = 0; i < n_scales; ++i)     // one C-column slice per scale, in the order of multi_scale (csa:528 torch.cat(res_y, dim=1))
         RUN((prec == kF16 ? ciaosr_cs_attn_f16 : prec == kBF16 ? ciaosr_cs_attn_bf16 : ciaosr_cs_attn_f32)(feat_hwc, p.C, H, W, csattn + i, U + p.D + (size_t)i * p.C, p.Dv, opt, csa_ws,
                                                               p.csa_bytes, stream_));
+    const bool fused = !(route & CIAOSR_HEAD_STAGED) && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
+                       chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
+    if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the 16-bit modes exist for the fused kernels only
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
-    if (gemm_small_ok(p.HW, p.wk0, p.D, p.Dv, w->k.ld[0]) && gemm_small_ok(p.HW, p.wv0, p.Dv, p.Dv, w->v.ld[0]) && p.HW <= 4096) {
+    // f16 mode: on the 16-bit GEMM from a half copy of U (the staged route's activation buffers are free on the fused route)
+    const size_t u16_bytes = (size_t)p.HW * p.Dv * 2 + 256, w16_bytes = (size_t)(p.wk0 + p.wv0) * p.Dv * 2 + 512;
+    if (prec == kF16 && (p.D & 7) == 0 && (p.Dv & 7) == 0 && u16_bytes + w16_bytes <= R * p.wmax * sizeof(float) &&
+        (size_t)p.HW * p.Dv * 2 < 0xFFFFFF00ull) {
+        const H16Ops& h = h16_ops(prec);
+        unsigned short* U16 = reinterpret_cast<unsigned short*>(bufA);
+        unsigned short* Wk16 = U16 + round_up((size_t)p.HW * p.Dv, 128);
+        unsigned short* Wv16 = Wk16 + round_up((size_t)p.wk0 * p.D, 128);
+        RUN(h.cast_rows(U, p.Dv, U16, p.Dv, p.HW, p.Dv, s));
+        RUN(h.cast_rows(w->k.weight[0], w->k.ld[0], Wk16, p.D, p.wk0, p.D, s));
+        RUN(h.cast_rows(w->v.weight[0], w->v.ld[0], Wv16, p.Dv, p.wv0, p.Dv, s));
+        RUN(h.conv1x1(U16, p.Dv, Wk16, p.D, w->k.bias[0], nullptr, 0, Tk, p.wk0, nullptr, 0, nullptr, 0, p.HW, p.wk0, p.D, s, "head_table_f16"));
+        RUN(h.conv1x1(U16, p.Dv, Wv16, p.Dv, w->v.bias[0], nullptr, 0, Tv, p.wv0, nullptr, 0, nullptr, 0, p.HW, p.wv0, p.Dv, s, "head_table_f16"));
+    } else if (gemm_small_ok(p.HW, p.wk0, p.D, p.Dv, w->k.ld[0]) && gemm_small_ok(p.HW, p.wv0, p.Dv, p.Dv, w->v.ld[0]) && p.HW <= 4096) {
         RUN(gemm_small_f32(U, p.Dv, w->k.weight[0], w->k.ld[0], w->k.bias[0], Tk, p.wk0, nullptr, 0, nullptr, 0, p.HW, p.wk0, p.D,
                            CIAOSR_ACT_NONE, 0.f, 1.f, s, "head_table"));
         RUN(gemm_small_f32(U, p.Dv, w->v.weight[0], w->v.ld[0], w->v.bias[0], Tv, p.wv0, nullptr, 0, nullptr, 0, p.HW, p.wv0, p.Dv,
@@ -197,9 +213,6 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                      CIAOSR_ACT_NONE, 0.f, s, "head_table"));
     }
 
-    const bool fused = !(route & CIAOSR_HEAD_STAGED) && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
-                       chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
-    if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the bf16 mode exists for the fused kernels only
     // logit table of imnet_k's output layer (exact fold, head_ops.hip): pays off when queries outnumber LR pixels
     const bool use_table = fused && !(route & CIAOSR_HEAD_NO_LOGIT_TABLE) && w->k.width[w->k.n_layers - 1] == p.D && w->k.width[w->k.n_layers - 2] == 256 &&
                            (long)Q * p.J > (long)p.HW * 9 && (size_t)p.HW * 9 * kLdG * sizeof(float) < 0xFFFFFF00ull;
