@@ -71,6 +71,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'mlp_in_q': (2.0 * Q * Dv * hidden, 'flop'),
         'mlp_hidden_q': (3 * 2.0 * Q * hidden * hidden, 'flop'),
         'head_table': (2.0 * HW * hidden * (D + Dv), 'flop'),
+        'head_table_bf16': (2.0 * HW * hidden * (D + Dv), 'flop16'),
         'csa_scores': (2.0 * HW * (HW / 4) * 4.5 * C, 'flop'),
         # >= 64x64 maps run the composed fold+down tail (DESIGN 'cs_attn tail'): 16C value columns instead of 36C
         'csa_attn_v': (2.0 * HW * (HW / 4) * (16 if HW >= 4096 else 36) * C, 'flop'),
@@ -84,6 +85,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'enc_dense_bf16': (dense, 'flop16'),
         'enc_dense_gather': (dense, 'flop'),
         'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),
+        # the blocks' local feature fusion in f16 mode: memory-bound (16-bit rows in, fp32 residual in, two fp32 + one 16-bit rows out)
+        'enc_conv1x1_bf16': (blocks * HW * ((C + C * layers) * 2.0 + C * 4.0 + 2 * C * 4.0 + C * 2.0), 'byte'),
         'local_attention': (Q * (4.0 * J * D + 4.0 * J * Dv + 4.0 * Dv + 16) + 2.0 * C * 4 * HW, 'byte'),
         'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),
     }
@@ -424,7 +427,8 @@ def main():
                 tag2fn = {'enc_dense_scatter': 'dense_scatter_small_kernel', 'enc_rdb_fused': 'rdb_fused_kernel',
                           'head_kv_fused': 'head_kv_fused_kernel', 'head_fused': 'head_fused_kernel',
                           'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_h16_kernel',
-                          'head_kv_fused_f16': 'head_kv_fused_h16_kernel'}
+                          'head_kv_fused_f16': 'head_kv_fused_h16_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
+                          'enc_dense_gather': 'dense_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
                 pmc_path = os.path.join(REPO, 'profiles', f'r2_{unit}_pmc_hbm_traffic.json')
                 live_traffic = None

@@ -1,5 +1,5 @@
 // fp32 dense-block convolution for big maps (exact-fp32 MFMA, v_mfma_f32_32x32x2_f32): the halo-resident,
-// K-sliced design of dense_bf16.hip in the contract precision.
+// K-sliced design of dense_h16.hip in the contract precision.
 //
 // One 3x3 dense layer l of a residual dense block (mmedit RDB.layers[l].conv over cat(x, d_0 .. d_{l-1}), called from
 // ciaosr_net.py:330-337) in GATHER form: K = 9 * 64 (l+1), N = 64.  The tap-major implicit GEMM of conv_f32.hip

@@ -187,12 +187,15 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
             RUN(conv2d_hwc(x, cb, H, W, cb, f.weight, cb, f.bias, G, 1, Gc + (size_t)b * G, G * NB,
                            b + 1 < NB ? xn : nullptr, cb, x, cb, CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
     }
+    // global feature fusion; its own profiler tag when the blocks' 1x1 convolutions ran on the 16-bit path (the "enc_conv1x1" work
+    // figure of bench.py counts both)
+    const char* gff_tag = lff16 ? "enc_gff1x1" : "enc_conv1x1";
     if (gemm_small_ok((int)HW, C, G * NB, G * NB, G * NB))
         RUN(gemm_small_f32(Gc, G * NB, w->gff0.weight, G * NB, w->gff0.bias, g0, C, nullptr, 0, nullptr, 0, (int)HW, C, G * NB,
-                           CIAOSR_ACT_NONE, 0.f, 1.f, s, "enc_conv1x1"));
+                           CIAOSR_ACT_NONE, 0.f, 1.f, s, gff_tag));
     else
         RUN(conv2d_hwc(Gc, G * NB, H, W, G * NB, w->gff0.weight, G * NB, w->gff0.bias, C, 1, g0, C, nullptr, 0, nullptr, 0,
-                       CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
+                       CIAOSR_ACT_NONE, 1.f, part, pf, s, gff_tag));
     RUN(conv3(g0, C, H, W, w->gff1, feat_hwc, C, sfe1, C, CIAOSR_ACT_NONE, 1.f, part, pf, s));
 #undef RUN
     return CIAOSR_OK;

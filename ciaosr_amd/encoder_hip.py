@@ -25,7 +25,7 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False):
     st.frag16_lo = None
     st.frag = None
     if frag16:
-        # bf16 MFMA fragments of the [cout][k*k*cin] matrix for the bf16 trunk mode (dense_bf16.hip)
+        # bf16 MFMA fragments of the [cout][k*k*cin] matrix for the bf16 trunk mode (dense_h16.hip)
         n_, k_ = w.shape
         f16 = torch.empty(_lib.load().ciaosr_fragment_bf16_bytes(n_, k_), dtype=torch.uint8, device=w.device)
         _lib.call('ciaosr_pack_fragments_bf16', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f16), hip_ops.stream_ptr())

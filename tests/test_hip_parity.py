@@ -449,7 +449,7 @@ def test_e2e_bf16_precision_mode_psnr(dev):
 
 
 def test_cs_attn_bf16_mode_vs_fp32(dev):
-    """ciaosr_cs_attn_bf16 (scores and P.V' on the bf16 MFMA, gemm_bf16.hip; odd map size -> reflect pad, ragged GEMM
+    """ciaosr_cs_attn_bf16 (scores and P.V' on the bf16 MFMA, gemm_h16.hip; odd map size -> reflect pad, ragged GEMM
     tiles) against the fp32 path on the same input; PSNR-gated like the other bf16 kernels."""
     import math
     from ciaosr_amd import hip_ops
