@@ -131,6 +131,10 @@ SIGNATURES = {
     'ciaosr_rdn_forward_f32': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
     'ciaosr_rdn_forward_bf16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
     'ciaosr_rdn_forward_f16': (_I, [_P, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
+    'ciaosr_rdn_workspace_bytes_batch': (_S, [_I, _I, _I, C.POINTER(RdnWeightsT)]),
+    'ciaosr_rdn_forward_batch_f32': (_I, [_P, _I, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
+    'ciaosr_rdn_forward_batch_bf16': (_I, [_P, _I, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
+    'ciaosr_rdn_forward_batch_f16': (_I, [_P, _I, _I, _I, C.POINTER(RdnWeightsT), _P, _O, _P, _S, _P]),
     'ciaosr_edsr_workspace_bytes': (_S, [_I, _I, C.POINTER(EdsrWeightsT)]),
     'ciaosr_edsr_forward_f32': (_I, [_P, _I, _I, C.POINTER(EdsrWeightsT), _P, _P, _S, _P]),
     'ciaosr_swinir_workspace_bytes': (_S, [_I, _I, C.POINTER(SwinirWeightsT)]),

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsf[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int ty0 = (blockIdx.x / p.tiles_x) * FT, tx0 = (blockIdx.x % p.tiles_x) * FT;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
+    float* const xi = p.x + (size_t)blockIdx.y * p.H * p.W * p.ldx;        // image blockIdx.y of the batch (same weights, own rows)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xi, 0, p.x_bytes, 0x00020000);
 
     // patch staging: thread -> 16-byte chunks t + 256 s  (pixel = chunk / 16, 16 chunks = 64 channels)
     unsigned goff[FLOADS];
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
                 const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
                 v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
                 v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
-                *reinterpret_cast<float4*>(p.x + ((size_t)y * p.W + x) * p.ldx + p.col_out + co) = v;
+                *reinterpret_cast<float4*>(xi + ((size_t)y * p.W + x) * p.ldx + p.col_out + co) = v;
             }
         }
         __syncthreads();
@@ -190,8 +191,8 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
 
 int dense_f32_tiles(int H, int W) { return ceil_div(H, FT) * ceil_div(W, FT); }
 
-// dense layer l of a block: input groups 0..l of X, output group l+1
-int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, hipStream_t s) {
+// dense layer l of a block: input groups 0..l of X, output group l+1; X holds n_img images of H x W rows back to back
+int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, int n_img, hipStream_t s) {
     CIAOSR_CHECK_ARG(X && frag && bias && (ldx & 3) == 0 && aligned16(X) && aligned16(frag) && aligned16(bias));
     const size_t x_bytes = (size_t)H * W * ldx * 4;
     CIAOSR_CHECK_ARG(x_bytes < 0xFFFFFF00ull);
@@ -204,7 +205,7 @@ int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, c
     p.col_out = 64 * (l + 1);
     CIAOSR_BIG_LDS(dense_f32_kernel, kDenseF32Lds);
     ProfScope prof("enc_dense_gather", s);
-    hipLaunchKernelGGL(dense_f32_kernel, dim3(dense_f32_tiles(H, W)), dim3(256), kDenseF32Lds, s, p);
+    hipLaunchKernelGGL(dense_f32_kernel, dim3(dense_f32_tiles(H, W), n_img), dim3(256), kDenseF32Lds, s, p);
     return launch_status("dense_f32");
 }
 

@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int ty0 = (blockIdx.x / p.tiles_x) * DT, tx0 = (blockIdx.x % p.tiles_x) * DT;
+    const size_t ipix = (size_t)blockIdx.y * p.H * p.W;                    // image blockIdx.y of the batch (same weights, own rows)
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xb), 0, p.xb_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xb + ipix * p.ldxb), 0, p.xb_bytes, 0x00020000);
 
     // patch staging: thread -> 16-byte chunks t + 256 s  (pixel = chunk / 8, 8 chunks = 64 channels)
     unsigned goff[DLOADS];
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
                 const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
                 v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
                 v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
-                const size_t pix = (size_t)y * p.W + x;
+                const size_t pix = ipix + (size_t)y * p.W + x;
                 if (p.x) *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
                 *reinterpret_cast<uint2*>(p.xb_out + pix * p.ldxb + p.col_out + co) =
                     pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
@@ -255,9 +256,9 @@ int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int co
     return launch_status("cast_group" CIAOSR_H16_SUFFIX);
 }
 
-// dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb)
+// dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb); n_img images back to back
 int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
-                     const float* bias, hipStream_t s) {
+                     const float* bias, int n_img, hipStream_t s) {
     CIAOSR_CHECK_ARG(Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);      // X null: no fp32 copy of the output
     const size_t xb_bytes = (size_t)H * W * ldxb * 2;
     CIAOSR_CHECK_ARG(xb_bytes < 0xFFFFFF00ull);
@@ -273,9 +274,9 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
     CIAOSR_BIG_LDS(dense_h16_kernel<false>, kDenseLds);
     ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
     if (p.wf_lo)
-        hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+        hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W), n_img), dim3(256), kDenseLds, s, p);
     else
-        hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+        hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W), n_img), dim3(256), kDenseLds, s, p);
     return launch_status("dense" CIAOSR_H16_SUFFIX);
 }
 

@@ -18,7 +18,7 @@ int dense_scatter_small(float* X, int ldx, int H, int W, int step, int num_layer
                         float* acc_buf, hipStream_t s);
 // dense_f32.hip
 int dense_f32_tiles(int H, int W);
-int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, hipStream_t s);
+int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, int n_img, hipStream_t s);
 
 __global__ void image_to_hwc4_kernel(const float* __restrict__ x, float* __restrict__ out, long HW) {
     // [3][H][W] -> [H*W][4] with a zero 4th channel (so the first conv moves float4 taps)
@@ -61,45 +61,54 @@ static int conv3(const float* src, int ld_src, int H, int W, const ciaosr_conv_t
 
 using namespace ciaosr;
 
-extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weights_t* w) {
-    if (!w || H <= 0 || W <= 0) return 0;
-    const size_t HW = (size_t)H * W;
+extern "C" size_t ciaosr_rdn_workspace_bytes_batch(int B, int H, int W, const ciaosr_rdn_weights_t* w) {
+    if (!w || B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t HW = (size_t)H * W, BHW = (size_t)B * HW;
     const int C = w->mid_channels, G = w->growth, cb = C + G * w->num_layers;
-    size_t n = HW * 4 + HW * 36 + HW * C /*sfe1*/ + 2 * HW * cb /*block buffers*/ +
-               HW * (size_t)G * w->num_blocks /*global concat*/ + HW * C /*gff0*/ + HW * (size_t)G * w->num_layers /*scatter sums*/ +
-               16 * HW * (size_t)(C > G ? C : G) + HW * cb / 2 + 64 /*16-bit copy of one block buffer*/ +
+    size_t n = HW * 4 + HW * 36 /*first-conv temporaries, one image at a time*/ + BHW * C /*sfe1*/ + 2 * BHW * cb /*block buffers*/ +
+               BHW * (size_t)G * w->num_blocks /*global concat*/ + BHW * C /*gff0*/ + HW * (size_t)G * w->num_layers /*scatter sums*/ +
+               16 * HW * (size_t)(C > G ? C : G) + BHW * cb / 2 + 64 /*16-bit copy of one block buffer*/ +
                (size_t)w->num_blocks * G * cb / 2 + 64 /*16-bit copies of the lff weights (f16 mode)*/;
     return n * sizeof(float) + 17 * 256;
 }
 
-static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weights_t* w) {
+    return ciaosr_rdn_workspace_bytes_batch(1, H, W, w);
+}
+
+// B images of the same size through the trunk.  On the big-map routes (halo-resident dense layers) the B images share every dense-layer
+// launch (grid.y = image: the 128 strictly dependent launches per image pay their ~8.5 us ramp / first-load / K-slice-reduction / drain
+// once per batch instead of once per image) and the row-wise 1x1 kernels of the f16 route; the few 3x3 convolutions outside the
+// blocks run per image.  Each image is computed by exactly the workgroups, in exactly the order, of a single-image call: bitwise equal.
+static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                        const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, Prec prec) {
     const bool bf16 = prec != kF32;      // a 16-bit MFMA mode (bf16 or f16 entry)
     // route thresholds (per-call options; defaults: halo-resident dense layers from 128 tiles of 12x12 pixels on, small-map
     // kernels up to 18432 pixels = 128 such tiles)
     const int min_tiles = opt && opt->dense_min_tiles ? opt->dense_min_tiles : 128;
     const int small_max = opt && opt->scatter_small_max ? opt->scatter_small_max : 18432;
-    CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && H > 0 && W > 0);
+    CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && B >= 1 && H > 0 && W > 0);
     const int C = w->mid_channels, G = w->growth, NB = w->num_blocks, NL = w->num_layers;
     CIAOSR_CHECK_ARG(C % 32 == 0 && G % 32 == 0 && NB >= 1 && NL >= 1 && w->dense && w->lff);
     CIAOSR_CHECK_ARG(C == G);   // mmedit's RDN feeds rdbs[b>0] with channel_growth channels and adds sfe1 (mid) at the end
     CIAOSR_CHECK_ARG(conv_ok(w->sfe1, 3, C, 3) && conv_ok(w->sfe2, C, C, 3));
     CIAOSR_CHECK_ARG(conv_ok(w->gff0, G * NB, C, 1) && conv_ok(w->gff1, C, C, 3));
-    if (workspace_bytes < ciaosr_rdn_workspace_bytes(H, W, w)) return CIAOSR_ERR_WORKSPACE;
+    if (workspace_bytes < ciaosr_rdn_workspace_bytes_batch(B, H, W, w)) return CIAOSR_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream_;
-    const size_t HW = (size_t)H * W;
+    const size_t HW = (size_t)H * W, BHW = (size_t)B * HW;
     const int cb = C + G * NL;
+    CIAOSR_CHECK_ARG(BHW * cb * sizeof(float) < 0xFFFFFF00ull);
     Arena ar(workspace, workspace_bytes);
     float* img4 = ar.take<float>(HW * 4);
     float* rows = ar.take<float>(HW * 36);
-    float* sfe1 = ar.take<float>(HW * C);
-    float* X[2] = {ar.take<float>(HW * cb), ar.take<float>(HW * cb)};
-    float* Gc = ar.take<float>(HW * (size_t)G * NB);
-    float* g0 = ar.take<float>(HW * C);
+    float* sfe1 = ar.take<float>(BHW * C);
+    float* X[2] = {ar.take<float>(BHW * cb), ar.take<float>(BHW * cb)};
+    float* Gc = ar.take<float>(BHW * (size_t)G * NB);
+    float* g0 = ar.take<float>(BHW * C);
     float* accb = ar.take<float>(HW * (size_t)G * NL);
     const size_t pf = 16 * HW * (size_t)(C > G ? C : G);
     float* part = ar.take<float>(pf);
-    unsigned short* Xb = reinterpret_cast<unsigned short*>(ar.take<float>(HW * cb / 2 + 64));
+    unsigned short* Xb = reinterpret_cast<unsigned short*>(ar.take<float>(BHW * cb / 2 + 64));
     unsigned short* Wl16 = reinterpret_cast<unsigned short*>(ar.take<float>((size_t)NB * G * cb / 2 + 64));
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
     // 16-bit modes: the dense layers (97 % of the trunk's MACs) run on the bf16 / f16 MFMA when the map is big enough to give
@@ -116,6 +125,11 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
     const bool lff16 = dense16 && prec == kF16 && cb % 8 == 0 && G % 4 == 0 && G <= 128;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
+    if (B > 1 && !(dense16 || dense32)) {       // small maps: one image after the other through the single-image routes
+        for (int i = 0; i < B; ++i)
+            RUN(rdn_forward(x_nchw + (size_t)i * 3 * HW, 1, H, W, w, feat_hwc + (size_t)i * HW * C, opt, workspace, workspace_bytes, stream_, prec));
+        return CIAOSR_OK;
+    }
     if (lff16) {
         const float* src[16];
         for (int b0 = 0; b0 < NB; b0 += 16) {
@@ -127,33 +141,35 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
             RUN(h16_ops(prec).cast_many(src, n, G, cb, Wl16 + (size_t)b0 * G * cb, s));
         }
     }
-    RUN(first_conv(x_nchw, H, W, w->sfe1, img4, rows, sfe1, C, s));
-    // sfe2 -> block 0 input (columns [0, C) of X[0])
-    RUN(conv3(sfe1, C, H, W, w->sfe2, X[0], cb, nullptr, 0, CIAOSR_ACT_NONE, 1.f, part, pf, s));
+    for (int i = 0; i < B; ++i) {
+        RUN(first_conv(x_nchw + (size_t)i * 3 * HW, H, W, w->sfe1, img4, rows, sfe1 + (size_t)i * HW * C, C, s));
+        // sfe2 -> block 0 input (columns [0, C) of X[0])
+        RUN(conv3(sfe1 + (size_t)i * HW * C, C, H, W, w->sfe2, X[0] + (size_t)i * HW * cb, cb, nullptr, 0, CIAOSR_ACT_NONE, 1.f, part, pf, s));
+    }
     for (int b = 0; b < NB; ++b) {
         float* x = X[b & 1];
         float* xn = X[(b + 1) & 1];
         if (dense16) {
-            if (!(lff16 && b > 0)) RUN(h16_ops(prec).cast_group(x, cb, Xb, cb, 0, (long)HW, s));     // else: written by the previous lff
+            if (!(lff16 && b > 0)) RUN(h16_ops(prec).cast_group(x, cb, Xb, cb, 0, (long)BHW, s));     // else: written by the previous lff
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
                 RUN(h16_ops(prec).dense_layer(lff16 ? nullptr : x, cb, Xb, cb, H, W, l, c.frag16,
-                                              (prec == kF16 || (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, s));
+                                              (prec == kF16 || (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, B, s));
             }
             if (lff16) {
                 // RDB output = x + lff(dense) from the 16-bit rows: fp32 to the global concat and the next block's input, 16-bit to the
                 // next block's input group (rows of Xb this workgroup alone reads and writes: N = G is one column tile)
                 const bool more = b + 1 < NB;
                 RUN(h16_ops(prec).conv1x1(Xb, cb, Wl16 + (size_t)b * G * cb, cb, w->lff[b].bias, x, cb, Gc + (size_t)b * G, G * NB,
-                                          more ? xn : nullptr, cb, more ? Xb : nullptr, cb, (int)HW, G, cb, s, "enc_conv1x1_f16"));
+                                          more ? xn : nullptr, cb, more ? Xb : nullptr, cb, (int)BHW, G, cb, s, "enc_conv1x1_f16"));
                 continue;
             }
         } else if (dense32) {
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
-                RUN(dense_layer_f32(x, cb, H, W, l, c.frag, c.bias, s));
+                RUN(dense_layer_f32(x, cb, H, W, l, c.frag, c.bias, B, s));
             }
         } else if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {
             // scatter form: input group s (64 channels) feeds every later dense layer in ONE convolution with
@@ -180,23 +196,32 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
         const ciaosr_conv_t& f = w->lff[b];
         CIAOSR_CHECK_ARG(conv_ok(f, cb, G, 1));
         // RDB output = x + lff(dense): goes to the global concat and is the next block's input
-        if (gemm_small_ok((int)HW, G, cb, cb, cb))
-            RUN(gemm_small_f32(x, cb, f.weight, cb, f.bias, Gc + (size_t)b * G, G * NB, b + 1 < NB ? xn : nullptr, cb, x, cb, (int)HW, G,
-                               cb, CIAOSR_ACT_NONE, 0.f, 1.f, s, "enc_conv1x1"));
-        else
-            RUN(conv2d_hwc(x, cb, H, W, cb, f.weight, cb, f.bias, G, 1, Gc + (size_t)b * G, G * NB,
-                           b + 1 < NB ? xn : nullptr, cb, x, cb, CIAOSR_ACT_NONE, 1.f, part, pf, s, "enc_conv1x1"));
+        for (int i = 0; i < B; ++i) {
+            float* xi = x + (size_t)i * HW * cb;
+            float* xni = b + 1 < NB ? xn + (size_t)i * HW * cb : nullptr;
+            float* gi = Gc + (size_t)i * HW * G * NB + (size_t)b * G;
+            if (gemm_small_ok((int)HW, G, cb, cb, cb))
+                RUN(gemm_small_f32(xi, cb, f.weight, cb, f.bias, gi, G * NB, xni, cb, xi, cb, (int)HW, G, cb, CIAOSR_ACT_NONE, 0.f, 1.f, s,
+                                   "enc_conv1x1"));
+            else
+                RUN(conv2d_hwc(xi, cb, H, W, cb, f.weight, cb, f.bias, G, 1, gi, G * NB, xni, cb, xi, cb, CIAOSR_ACT_NONE, 1.f, part, pf, s,
+                               "enc_conv1x1"));
+        }
     }
     // global feature fusion; its own profiler tag when the blocks' 1x1 convolutions ran on the 16-bit path (the "enc_conv1x1" work
     // figure of bench.py counts both)
     const char* gff_tag = lff16 ? "enc_gff1x1" : "enc_conv1x1";
-    if (gemm_small_ok((int)HW, C, G * NB, G * NB, G * NB))
-        RUN(gemm_small_f32(Gc, G * NB, w->gff0.weight, G * NB, w->gff0.bias, g0, C, nullptr, 0, nullptr, 0, (int)HW, C, G * NB,
-                           CIAOSR_ACT_NONE, 0.f, 1.f, s, gff_tag));
-    else
-        RUN(conv2d_hwc(Gc, G * NB, H, W, G * NB, w->gff0.weight, G * NB, w->gff0.bias, C, 1, g0, C, nullptr, 0, nullptr, 0,
-                       CIAOSR_ACT_NONE, 1.f, part, pf, s, gff_tag));
-    RUN(conv3(g0, C, H, W, w->gff1, feat_hwc, C, sfe1, C, CIAOSR_ACT_NONE, 1.f, part, pf, s));
+    for (int i = 0; i < B; ++i) {
+        const float* gci = Gc + (size_t)i * HW * G * NB;
+        float* g0i = g0 + (size_t)i * HW * C;
+        if (gemm_small_ok((int)HW, C, G * NB, G * NB, G * NB))
+            RUN(gemm_small_f32(gci, G * NB, w->gff0.weight, G * NB, w->gff0.bias, g0i, C, nullptr, 0, nullptr, 0, (int)HW, C, G * NB,
+                               CIAOSR_ACT_NONE, 0.f, 1.f, s, gff_tag));
+        else
+            RUN(conv2d_hwc(gci, G * NB, H, W, G * NB, w->gff0.weight, G * NB, w->gff0.bias, C, 1, g0i, C, nullptr, 0, nullptr, 0,
+                           CIAOSR_ACT_NONE, 1.f, part, pf, s, gff_tag));
+        RUN(conv3(g0i, C, H, W, w->gff1, feat_hwc + (size_t)i * HW * C, C, sfe1 + (size_t)i * HW * C, C, CIAOSR_ACT_NONE, 1.f, part, pf, s));
+    }
 #undef RUN
     return CIAOSR_OK;
 }
@@ -204,19 +229,37 @@ static int rdn_forward(const float* x_nchw, int H, int W, const ciaosr_rdn_weigh
 extern "C" int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
                                       float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
                                       size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF32);
+    return rdn_forward(x_nchw, 1, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF32);
+}
+
+extern "C" int ciaosr_rdn_forward_batch_f32(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w,
+                                              float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, B, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF32);
 }
 
 extern "C" int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
                                        float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
                                        size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kBF16);
+    return rdn_forward(x_nchw, 1, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kBF16);
+}
+
+extern "C" int ciaosr_rdn_forward_batch_bf16(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w,
+                                              float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, B, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kBF16);
 }
 
 extern "C" int ciaosr_rdn_forward_f16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w,
                                       float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
                                       size_t workspace_bytes, void* stream) {
-    return rdn_forward(x_nchw, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF16);
+    return rdn_forward(x_nchw, 1, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF16);
+}
+
+extern "C" int ciaosr_rdn_forward_batch_f16(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w,
+                                              float* feat_hwc, const ciaosr_options_t* opt, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+    return rdn_forward(x_nchw, B, H, W, w, feat_hwc, opt, workspace, workspace_bytes, stream, kF16);
 }
 
 extern "C" size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w) {

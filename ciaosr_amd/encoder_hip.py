@@ -166,6 +166,25 @@ class PackedEncoder:
         return n.conv_first.in_channels == 3
 
     @torch.no_grad()
+    def forward_hwc_batch(self, x_bchw, options=None):
+        """x [B,3,H,W] normalised LR crops of one size (GPU) -> features [B,H,W,C] channels-last, the B images sharing the
+        trunk's dense-layer launches (ciaosr_rdn_forward_batch_*; each image bitwise equal to a forward_hwc call)."""
+        B = x_bchw.shape[0]
+        if self.kind != 'rdn' or B == 1:
+            return torch.stack([self.forward_hwc(x_bchw[i], options) for i in range(B)])
+        opt = hip_ops.as_options(options)
+        x_bchw = x_bchw.contiguous().float()
+        hip_ops.require_gpu(x_bchw)
+        _, _, H, W = x_bchw.shape
+        st = self.struct(opt.half)
+        nbytes = _lib.load().ciaosr_rdn_workspace_bytes_batch(B, H, W, C.byref(st))
+        ws = hip_ops.workspace(nbytes, x_bchw.device, slot='encoder')
+        out = torch.empty(B, H, W, st.mid_channels, dtype=torch.float32, device=x_bchw.device)
+        _lib.call('ciaosr_rdn_forward_batch_' + opt.suffix, hip_ops.ptr(x_bchw), B, H, W, C.byref(st), hip_ops.ptr(out), opt.c_arg(),
+                  hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
+        return out
+
+    @torch.no_grad()
     def forward_hwc(self, x_chw, options=None):
         """x [3,H,W] normalised LR (GPU) -> feature [H,W,C] channels-last.  `options`: hip_ops.Options."""
         opt = hip_ops.as_options(options)

@@ -71,8 +71,9 @@ class LocalImplicitSRNet(nn.Module):
         if enc is not None and x.is_cuda and enc.supported():
             # HIP trunk: channels-last feature map goes straight into the head (no NCHW round trip)
             x = x.contiguous().float()
-            outs = [self._head.forward(None, x[b], coord[b], cell[b], chunk, feature_hwc=enc.forward_hwc(x[b], options),
-                                       options=options) for b in range(x.shape[0])]
+            feats = enc.forward_hwc_batch(x, options)        # the batch shares the trunk's dense-layer launches
+            outs = [self._head.forward(None, x[b], coord[b], cell[b], chunk, feature_hwc=feats[b], options=options)
+                    for b in range(x.shape[0])]
             return torch.stack(outs, 0)
         features = self.gen_feature(x, options)
         return self._predict(features, coord, cell, chunk, x, options)

@@ -110,6 +110,18 @@ class CiaoSR(BasicRestorer):
         cell = cell.unsqueeze(0).expand(b, -1, 2)
         return self.generator(patch, coord, cell, test_mode=True, options=self.options(options)), (th, tw)
 
+    def run_tiles(self, x_norm, origins, tile, sf, options=None):
+        """Several equally sized tiles of ONE image (batch 1) through one generator call: the crops are stacked into a batch, so
+        the encoder's dense-layer launches are shared (encoder_hip.forward_hwc_batch); the head then runs per tile.  Returns
+        ([n, th*tw, 3], (th, tw)); row i is bitwise the run_tile result of origins[i]."""
+        patch = torch.cat([x_norm[..., hi:hi + tile, wi:wi + tile] for (hi, wi) in origins], 0).contiguous()
+        n = patch.shape[0]
+        th, tw = round(patch.shape[-2] * sf), round(patch.shape[-1] * sf)
+        coord, cell = hip_ops.make_coord_cell(th, tw, patch.device)
+        coord = coord.unsqueeze(0).expand(n, -1, 2)
+        cell = cell.unsqueeze(0).expand(n, -1, 2)
+        return self.generator(patch, coord, cell, test_mode=True, options=self.options(options)), (th, tw)
+
     def prepare(self, device=None):
         """Pack every weight for the HIP kernels NOW, on the current stream (idempotent; re-packs only what changed).
         The tile loop runs tiles on several streams: nothing a tile reads may be first built on another tile's stream."""
@@ -140,6 +152,17 @@ class CiaoSR(BasicRestorer):
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
         n_streams = int(self.test_cfg.get('tile_streams', 1) or 1)
+        n_batch = int(self.test_cfg.get('tile_batch', 4) or 1)
+        if (tile_fn is None and n_streams <= 1 and n_batch > 1 and b == 1 and len(origins) > 1 and img_lq.is_cuda and
+                hasattr(getattr(self.generator, '_encoder_hip', None), 'forward_hwc_batch')):
+            # `test_cfg.tile_batch` (an extension; default 4) consecutive tiles share the encoder's dense-layer launches; every tile
+            # is bitwise the one-at-a-time result and the blend order is the reference's
+            for i0 in range(0, len(origins), n_batch):
+                group = origins[i0:i0 + n_batch]
+                outs, (th, tw) = self.run_tiles(img_lq, group, tile, sf, options)
+                for (hi, wi), out in zip(group, outs):
+                    hip_ops.tile_blend(E[0], Wt[0], out.contiguous(), hi * sf, wi * sf, th, tw)
+            return torch.stack([hip_ops.tile_finalize(E[0], Wt[0])])
         if tile_fn is not None or n_streams <= 1 or len(origins) < 2 or not img_lq.is_cuda:
             for (hi, wi) in origins:
                 out, (th, tw) = self.run_tile(img_lq, hi, wi, tile, sf, options) if tile_fn is None else tile_fn(hi, wi)

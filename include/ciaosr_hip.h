@@ -331,6 +331,21 @@ int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_
 int ciaosr_rdn_forward_f16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                            const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
                            void* stream);
+/* B images of one size through the trunk in one call: x_nchw [B][3][H][W] -> feat_hwc [B][H][W][mid_channels].  On maps big
+ * enough for the halo-resident dense-layer kernels the B images share every dense-layer launch (and the f16 route's row-wise 1x1
+ * kernels), so the per-launch floor of the 128 dependent launches is paid once per batch; each image's result is bitwise the
+ * single-image result.  Smaller maps: the images run one after the other.  This is how clip_test's tiles (ciaosr.py:233-254,
+ * independent crops of one image) are fed: `test_cfg.tile_batch` tiles per call. */
+size_t ciaosr_rdn_workspace_bytes_batch(int B, int H, int W, const ciaosr_rdn_weights_t* w);
+int ciaosr_rdn_forward_batch_f32(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                                 const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+int ciaosr_rdn_forward_batch_bf16(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                                  const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int ciaosr_rdn_forward_batch_f16(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
+                                 const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
+                                 void* stream);
 size_t ciaosr_edsr_workspace_bytes(int H, int W, const ciaosr_edsr_weights_t* w);
 int ciaosr_edsr_forward_f32(const float* x_nchw, int H, int W, const ciaosr_edsr_weights_t* w, float* feat_hwc,
                             void* workspace, size_t workspace_bytes, void* stream);

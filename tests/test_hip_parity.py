@@ -753,6 +753,24 @@ def test_tile_streams_are_bitwise_the_single_stream_result(dev):
         assert torch.equal(model.restore(lq), one)
 
 
+def test_tile_batch_is_bitwise_the_one_tile_result(dev):
+    """clip_test feeds `test_cfg.tile_batch` consecutive tiles through ONE encoder call (grid.y = image in the dense-layer
+    kernels, row-wise 1x1 kernels over all rows; ciaosr_rdn_forward_batch_*): the 6-tile image must come out bitwise equal to the
+    one-tile-at-a-time loop for batch 2, 4 (default; ragged last group 4 + 2) and 6, in every precision."""
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    lq, _ = synthetic_pair(339, 510, 4)
+    lq = lq.to(dev)
+    for precision in ('fp32', 'bf16', 'f16'):
+        model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32, tile_batch=1, precision=precision))
+        seeded_init_(model, seed=0, gain=1.5, head_gain=SQRT6)
+        model = model.to(dev)
+        one = model.restore(lq)
+        for nb in (2, 4, 6):
+            model.test_cfg['tile_batch'] = nb
+            got = model.restore(lq)
+            assert torch.equal(one, got), (precision, nb, (one - got).abs().max().item())
+
+
 def test_c3_full_image_tiled_restore_properties(dev):
     """C3 itself: the 1356x2040 LR image through restore() (117 tiles of 192, overlap 32 -> 5424x8160).  No CPU
     reference finishes at this size (11 h), so: (1) where a tile's interior is covered by that tile alone (the
