@@ -266,28 +266,27 @@ __device__ __forceinline__ void hidden_layer16v2(unsigned short* X, const void* 
         }
 }
 
-// layer-0 rows from the hoisted tables: 32 rows per thread, 16 table gathers in flight at a time (no accumulator is live here)
+// layer-0 rows from the hoisted tables: 32 rows per thread, all 32 table gathers in flight at once (no accumulator is live here:
+// the registers are free, and the phase is bound by the gathers' latency, not by their bytes)
 __device__ __forceinline__ void build_rows16v2(unsigned short* X, const FusedChain& c, const int* s_kpix, const float* s_t4, int t) {
     const int n4 = t & 63;
     float4 tw[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
+    constexpr int NR = HBM_ / 4;       // rows per thread
+    float4 tv[NR];
 #pragma unroll
-    for (int b = 0; b < HBM_ / 64; ++b) {
-        float4 tv[16];
+    for (int i = 0; i < NR; ++i) tv[i] = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[(t >> 6) + 4 * i] * HH)[n4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) tv[i] = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[(t >> 6) + 4 * (16 * b + i)] * HH)[n4];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = (t >> 6) + 4 * (16 * b + i);
-            const float4 q = *reinterpret_cast<const float4*>(s_t4 + 4 * r);       // rel_y rel_x scale_y scale_x
-            uint2 o;
-            o.x = pack_relu2(tv[i].x + tw[0].x * q.x + tw[0].y * q.y + tw[0].z * q.z + tw[0].w * q.w,
-                             tv[i].y + tw[1].x * q.x + tw[1].y * q.y + tw[1].z * q.z + tw[1].w * q.w);
-            o.y = pack_relu2(tv[i].z + tw[2].x * q.x + tw[2].y * q.y + tw[2].z * q.z + tw[2].w * q.w,
-                             tv[i].w + tw[3].x * q.x + tw[3].y * q.y + tw[3].z * q.z + tw[3].w * q.w);
-            *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
-        }
+    for (int i = 0; i < NR; ++i) {
+        const int r = (t >> 6) + 4 * i;
+        const float4 q = *reinterpret_cast<const float4*>(s_t4 + 4 * r);       // rel_y rel_x scale_y scale_x
+        uint2 o;
+        o.x = pack_relu2(tv[i].x + tw[0].x * q.x + tw[0].y * q.y + tw[0].z * q.z + tw[0].w * q.w,
+                         tv[i].y + tw[1].x * q.x + tw[1].y * q.y + tw[1].z * q.z + tw[1].w * q.w);
+        o.y = pack_relu2(tv[i].z + tw[2].x * q.x + tw[2].y * q.y + tw[2].z * q.z + tw[2].w * q.w,
+                         tv[i].w + tw[3].x * q.x + tw[3].y * q.y + tw[3].z * q.z + tw[3].w * q.w);
+        *reinterpret_cast<uint2*>(X + r * HLD + 4 * n4) = o;
     }
 }
 
