@@ -71,7 +71,10 @@ class LocalImplicitSRNet(nn.Module):
         if enc is not None and x.is_cuda and enc.supported():
             # HIP trunk: channels-last feature map goes straight into the head (no NCHW round trip)
             x = x.contiguous().float()
-            feats = enc.forward_hwc_batch(x, options)        # the batch shares the trunk's dense-layer launches
+            if hasattr(enc, 'forward_hwc_batch'):            # RDN: the batch shares the trunk's dense-layer launches
+                feats = enc.forward_hwc_batch(x, options)
+            else:
+                feats = [enc.forward_hwc(x[b], options) for b in range(x.shape[0])]
             outs = [self._head.forward(None, x[b], coord[b], cell[b], chunk, feature_hwc=feats[b], options=options)
                     for b in range(x.shape[0])]
             return torch.stack(outs, 0)
