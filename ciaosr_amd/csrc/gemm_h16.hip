@@ -6,16 +6,16 @@
 //
 // v_mfma_f32_32x32x16_bf16 is 16x the fp32 MFMA rate, so the tile is sized for the operand streams instead:
 // workgroup tile 256 x 128 x 32, 4 waves in a 2 x 2 grid, each wave a 128 x 64 sub-tile = 4 x 2 MFMA tiles (128
-// accumulator registers): per 16-deep k-step a wave reads 6 KB from LDS for 8 MFMAs (24 B/clk/SIMD, under the
-// 128 B/clk/CU LDS limit) and the workgroup fetches 24 KB from L2/HBM per 2.1 MFLOP stage (12 B/clk at the full MFMA
-// rate).  The k-tile is 32 deep (not 64) so that the double-buffered stages take 60 KB and TWO workgroups share a CU:
-// with one wave per SIMD (round 1: 108 KB, one workgroup per CU) every barrier, LDS store and late global load stalled
-// the matrix pipe directly (SQ: 45 % of wave cycles in issue stalls, MFMA pipe 27 % busy); with two, one workgroup's
-// staging runs under the other's MFMAs.  LDS rows are 64 B, unpadded, with the 16-byte chunk index XOR-swizzled by
-// (row >> 2) & 3: the 16 rows a ds_read_b128 lane group touches ({0-3,12-15,20-27} / {4-11,16-19,28-31}) land on 16
-// distinct bank quads, and so do the 2 rows x 4 chunks of every 8-lane ds_write_b128 group (the 80-B padded rows of the
-// first GK = 32 version read conflict-free but wrapped one write per group: SQ_LDS_BANK_CONFLICT 33 % of LDS cycles).
-// Global loads run TWO k-tiles ahead in two register sets (one k-tile is only ~512 MFMA cycles: less than an HBM round trip).
+// accumulator registers); the k-tile is 32 deep so that TWO workgroups share a CU (with one wave per SIMD -- round 1: 108 KB,
+// one workgroup per CU -- every barrier and late load stalled the matrix pipe directly: MFMA pipe 27 % busy).
+// LDS rows are 64 B, unpadded, with the 16-byte chunk index XOR-swizzled by (row >> 2) & 3: the 16 rows a ds_read_b128 lane
+// group touches ({0-3,12-15,20-27} / {4-11,16-19,28-31}) land on 16 distinct bank quads.
+// Staging (round 2, second half): LDS-DMA.  The register-staged version (global -> VGPR two k-tiles ahead -> ds_write_b128) paid
+// 311 LDS cycles per 24-KB k-tile for the VGPR -> LDS transfer (~79 B/clk per CU, MI355X_MICROARCH.md LDS table) on top of 192 for
+// the fragment reads, against 512 MFMA cycles per SIMD: with two workgroups per CU the LDS pipe was as busy as the matrix pipe.
+// Because the LDS image is lane-linear per wave (unpadded rows, swizzle), each wave's 1-KB slice of a stage now comes straight from
+// memory (`buffer_load_dwordx4 ... lds`), the swizzle applied to the SOURCE address; three stage buffers (72 KB), two k-tiles in
+// flight across every barrier (counted s_waitcnt vmcnt + raw s_barrier), 48 VGPRs fewer.  P.V' of the 192x192 tile: 0.90 -> 0.79 ms.
 // Swapped MFMA operands (B rows = A operand, A rows = B operand): a lane owns one output row and 4 consecutive
 // columns per accumulator quad, so the epilogue stores 16 B (fp32) / 8 B (bf16) pieces.
 // Out-of-range rows / k-chunks are buffer loads with an out-of-range offset (return 0, no branches).
@@ -38,7 +38,7 @@ constexpr int GRS = GK * 2;                               // LDS row stride in b
 constexpr int GCH = GK / 8;                               // 16-byte chunks per row
 constexpr int GSA = GM * GCH / 256, GSB = GN * GCH / 256; // staging chunks per thread (A: 4, B: 2)
 constexpr int GA_T = GM * GRS, GB_T = GN * GRS;           // bytes per stage
-constexpr size_t kGemm16Lds = 2 * (size_t)(GA_T + GB_T);  // 49 152 B: two workgroups per CU (register-limited)
+constexpr size_t kGemm16Lds = 3 * (size_t)(GA_T + GB_T);  // three stages, 73 728 B: two workgroups per CU
 constexpr unsigned kOob16 = 0xFFFFFFF0u;
 
 struct Gemm16P {
@@ -49,7 +49,6 @@ struct Gemm16P {
     int M, N, K;
     float alpha;
     int tiles_n, n_wg;
-    int tn_per_wg, groups_n;   // column tiles per workgroup (consecutive, one software pipeline) and groups of them per row tile
     // optional epilogue (full-width quads only use these; all null for the plain GEMM): v = acc * alpha + bias[n] + res[m][n],
     // written to C and, when given, to a second fp32 matrix C2 and a 16-bit matrix C16
     const float* bias;
@@ -63,208 +62,198 @@ struct Gemm16P {
     const float2* stats; int npad;
 };
 
+// store epilogue of one 256 x 128 tile: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li, columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
+__device__ __forceinline__ void store_tile(const Gemm16P& p, const f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int li, int lh) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 128 * wm + 32 * mt + li;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
+                if (n >= p.N) continue;
+                float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
+                float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
+                if (p.bias) {                                              // fused epilogue (host checks N % 4 == 0: whole quads)
+                    const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                    v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
+                    if (p.res) {
+                        const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
+                        v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+                    }
+                    if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)m * p.ldc2 + n) = make_float4(v0, v1, v2, v3);
+                    if (p.C16) *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
+                }
+                if (n + 3 >= p.N) {                                        // ragged last columns
+                    const float v[4] = {v0, v1, v2, v3};
+                    for (int e = 0; e < 4 && n + e < p.N; ++e) {
+                        if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = to_h16<kF16>(v[e]);
+                        else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = v[e];
+                    }
+                } else if (p.c_bf16)
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
+                        pack_h16x4<kF16>(v0, v1, v2, v3);
+                else
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
+            }
+    }
+}
+
+// softmax pass 1: partial (max, sum of exp) of this wave's 64-column strip
+__device__ __forceinline__ void stats_tile(const Gemm16P& p, const f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int li, int lh) {
+    // partial softmax statistics of this wave's 64-column strip: a row's 32 values sit in two lanes (li, li + 32)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 128 * wm + 32 * mt + li;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) mx = fmaxf(mx, acc[mt][nt][4 * q + e] * p.alpha);
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) sum += __expf(acc[mt][nt][4 * q + e] * p.alpha - mx);
+        const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sum, 32, 64);
+        const float mm = fmaxf(mx, mo);
+        // a strip with no valid column on either lane keeps (-inf, 0): exp(-inf - -inf) is avoided
+        const float tot = (mx == -INFINITY ? 0.f : sum * __expf(mx - mm)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mm));
+        if (lh == 0 && m < p.M) p.part[(size_t)m * p.n_part + 2 * (n0 / GN) + wn] = make_float2(mm, tot);
+    }
+}
+
+// softmax pass 2: probabilities exp(v - row max) / row sum as 16-bit, pad columns zeroed
+__device__ __forceinline__ void softmax_tile(const Gemm16P& p, const f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int li, int lh) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + 128 * wm + 32 * mt + li;
+        if (m >= p.M) continue;
+        const float2 st = p.stats[m];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
+                if (n >= p.npad) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = n + e < p.N ? __expf(acc[mt][nt][4 * q + e] * p.alpha - st.x) * st.y : 0.f;
+                *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v[0], v[1], v[2], v[3]);
+            }
+    }
+}
+
+// ---- the kernel: one 256 x 128 tile per workgroup, operands staged by LDS-DMA, epilogue by EPI -------------------------------
+// lane i of a wave's 1-KB slice writes LDS chunk i and fetches the logical chunk (i % 4) ^ key(row); hipcc's __syncthreads() would
+// drain the DMAs, hence the raw barrier and the counted waits.
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];
-    unsigned char* As = lds16;                    // [2][GM][GRS]
-    unsigned char* Bs = lds16 + 2 * GA_T;         // [2][GN][GRS]
-
-    // XCD-aware remap (as gemm_f32.hip): each XCD walks a contiguous run of work items sharing A row panels.
-    // A work item = tn_per_wg consecutive column tiles of one row tile: their k-loops run as ONE software pipeline (the loads
-    // of the next tile's first stages are in flight under the current tile's epilogue), which is what a short-K contraction
-    // (K = a few k-tiles) needs -- with one tile per workgroup it is all prologue and epilogue.
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];      // [3] x { A [GM][GRS], B [GN][GRS] }
+    constexpr int STG = GA_T + GB_T;
     const int bid = blockIdx.x;
     const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int m0 = (lid / p.groups_n) * GM;
-    const int tile0 = (lid % p.groups_n) * p.tn_per_wg;
-    const int ntl = p.tiles_n - tile0 < p.tn_per_wg ? p.tiles_n - tile0 : p.tn_per_wg;
+    const int m0 = (lid / p.tiles_n) * GM, n0 = (lid % p.tiles_n) * GN;
 
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1, li = lane & 31, lh = lane >> 5;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.B), 0, p.b_bytes, 0x00020000);
 
-    // staging: 16-byte chunk c = t + 256 s -> row c / GCH, k-part c % GCH
-    constexpr int RS = 256 / GCH;                 // rows covered per staging step
-    const int part = t % GCH, row0 = t / GCH;     // rows row0 + RS s
-    unsigned a_off[GSA];
+    // DMA slices: wave w, step s covers rows 16 w + 64 s .. + 15 (1 KB of LDS); lane -> row +lane / 4, LDS chunk lane % 4,
+    // logical (source) chunk (lane % 4) ^ ((row >> 2) & 3)
+    const int rl = lane >> 2, pc = lane & 3;
+    unsigned a_off[GSA], b_off[GSB];
 #pragma unroll
     for (int s = 0; s < GSA; ++s) {
-        const int gm = m0 + row0 + RS * s;
+        const int row = 16 * w + 64 * s + rl, gm = m0 + row;
+        const int part = pc ^ ((row >> 2) & 3);
         a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 2u + (unsigned)part * 16u : kOob16;
     }
-    i32x4 ra[2][GSA], rb[2][GSB];            // two k-tiles in flight
-    const int swz = (row0 >> 2) & 3;              // RS is a multiple of 16: the swizzle key of rows row0 + RS s is that of row0
-    const int nk = (p.K + GK - 1) / GK;
-    int ld_tile = tile0, ld_k = 0;                // load pointer: next (column tile, k-tile) to request
-    auto load_next = [&](int set) {
-        const int k0 = ld_k * GK;
-        const bool kok = k0 + part * 8 < p.K;     // K % 8 == 0: a chunk is entirely in or out
 #pragma unroll
-        for (int s = 0; s < GSA; ++s)
-            ra[set][s] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, (kok && a_off[s] != kOob16) ? (int)(a_off[s] + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+    for (int s = 0; s < GSB; ++s) {
+        const int row = 16 * w + 64 * s + rl, gn = n0 + row;
+        const int part = pc ^ ((row >> 2) & 3);
+        b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u : kOob16;
+    }
+    const int nk = (p.K + GK - 1) / GK;
+    // The DMAs are issued from inline asm: a `__builtin_amdgcn_raw_ptr_buffer_load_lds` is counted by hipcc, which then waits
+    // vmcnt(0) in front of the first ds_read of every k-tile (it cannot tell the stage being read from the stages in flight) and the
+    // pipeline collapses to depth 0.  Hidden from the compiler, the DMAs are waited for by the counted s_waitcnt below.  M0 (the
+    // LDS destination base of the wave's 1-KB slice) is written in the same statement that uses it and restored after.
+    const i32x4 da = {(int)(unsigned)(size_t)p.A, (int)(((size_t)p.A >> 32) & 0xFFFFu), (int)p.a_bytes, 0x00020000};
+    const i32x4 db = {(int)(unsigned)(size_t)p.B, (int)(((size_t)p.B >> 32) & 0xFFFFu), (int)p.b_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds16;
+    auto dma = [&](const i32x4& desc, unsigned lds_dst, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(desc) : "memory");
+    };
+    auto issue = [&](int kt, int buf) {
+        const int k0 = kt * GK;
+        const unsigned st = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * STG) + (unsigned)(16 * w) * GRS);
+#pragma unroll
+        for (int s = 0; s < GSA; ++s) {
+            const int part = pc ^ (((16 * w + 64 * s + rl) >> 2) & 3);
+            const bool ok = a_off[s] != kOob16 && k0 + part * 8 < p.K;
+            dma(da, st + (unsigned)(64 * s * GRS), ok ? a_off[s] + (unsigned)k0 * 2u : kOob16);
+        }
 #pragma unroll
         for (int s = 0; s < GSB; ++s) {
-            const int gn = ld_tile * GN + row0 + RS * s;
-            rb[set][s] = __builtin_amdgcn_raw_buffer_load_b128(
-                rs_b, (kok && gn < p.N) ? (int)((unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u + (unsigned)k0 * 2u) : (int)kOob16, 0, 0);
+            const int part = pc ^ (((16 * w + 64 * s + rl) >> 2) & 3);
+            const bool ok = b_off[s] != kOob16 && k0 + part * 8 < p.K;
+            dma(db, st + (unsigned)(GA_T + 64 * s * GRS), ok ? b_off[s] + (unsigned)k0 * 2u : kOob16);
         }
-        if (++ld_k == nk) { ld_k = 0; ++ld_tile; }
-    };
-    auto store_stage = [&](int buf, int set) {
-#pragma unroll
-        for (int s = 0; s < GSA; ++s) *reinterpret_cast<i32x4*>(As + buf * GA_T + (row0 + RS * s) * GRS + ((part ^ swz) * 16)) = ra[set][s];
-#pragma unroll
-        for (int s = 0; s < GSB; ++s) *reinterpret_cast<i32x4*>(Bs + buf * GB_T + (row0 + RS * s) * GRS + ((part ^ swz) * 16)) = rb[set][s];
     };
 
     f32x16 acc[4][2];
-    auto zero_acc = [&]() {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    const int lswz = (li >> 2) & 3;
+    const int a_row = (128 * wm + li) * GRS, b_row = GA_T + (64 * wn + li) * GRS;
+    int buf = 0;
+#pragma unroll 1
+    for (int k = 0; k < nk; ++k) {
+        // stage k has landed once at most the next stage's GSA + GSB DMAs of this wave are still outstanding
+        if (k + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(GSA + GSB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // every wave's slices of stage k are in LDS; everyone is done reading stage k - 1
+        if (k + 2 < nk) issue(k + 2, buf == 0 ? 2 : buf - 1);       // (k + 2) % 3: the buffer stage k - 1 used
+        const unsigned char* st = lds16 + buf * STG;
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            const int co = ((2 * ks + lh) ^ lswz) * 16;
+            uint4 fb[2], fa[4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) fb[nt] = *reinterpret_cast<const uint4*>(st + b_row + nt * 32 * GRS + co);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(st + a_row + mt * 32 * GRS + co);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
-    };
-    zero_acc();
-
-    // epilogue of the column tile at n0: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li,
-    // columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
-    auto epilogue = [&](int n0) {
-        if constexpr (EPI == 1) {
-            // partial softmax statistics of this wave's 64-column strip: a row's 32 values sit in two lanes (li, li + 32)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + 128 * wm + 32 * mt + li;
-                float mx = -INFINITY;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) mx = fmaxf(mx, acc[mt][nt][4 * q + e] * p.alpha);
-                float sum = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) sum += __expf(acc[mt][nt][4 * q + e] * p.alpha - mx);
-                const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sum, 32, 64);
-                const float mm = fmaxf(mx, mo);
-                // a strip with no valid column on either lane keeps (-inf, 0): exp(-inf - -inf) is avoided
-                const float tot = (mx == -INFINITY ? 0.f : sum * __expf(mx - mm)) + (mo == -INFINITY ? 0.f : so * __expf(mo - mm));
-                if (lh == 0 && m < p.M) p.part[(size_t)m * p.n_part + 2 * (n0 / GN) + wn] = make_float2(mm, tot);
-            }
-        } else if constexpr (EPI == 2) {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + 128 * wm + 32 * mt + li;
-                if (m >= p.M) continue;
-                const float2 st = p.stats[m];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
-                        if (n >= p.npad) continue;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = n + e < p.N ? __expf(acc[mt][nt][4 * q + e] * p.alpha - st.x) * st.y : 0.f;
-                        *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v[0], v[1], v[2], v[3]);
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + 128 * wm + 32 * mt + li;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
-                        if (n >= p.N) continue;
-                        float v0 = acc[mt][nt][4 * q] * p.alpha, v1 = acc[mt][nt][4 * q + 1] * p.alpha;
-                        float v2 = acc[mt][nt][4 * q + 2] * p.alpha, v3 = acc[mt][nt][4 * q + 3] * p.alpha;
-                        if (p.bias) {                                              // fused epilogue (host checks N % 4 == 0: whole quads)
-                            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                            v0 += b.x; v1 += b.y; v2 += b.z; v3 += b.w;
-                            if (p.res) {
-                                const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
-                                v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
-                            }
-                            if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)m * p.ldc2 + n) = make_float4(v0, v1, v2, v3);
-                            if (p.C16) *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
-                        }
-                        if (n + 3 >= p.N) {                                        // ragged last columns
-                            const float v[4] = {v0, v1, v2, v3};
-                            for (int e = 0; e < 4 && n + e < p.N; ++e) {
-                                if (p.c_bf16) reinterpret_cast<unsigned short*>(p.C)[(size_t)m * p.ldc + n + e] = to_h16<kF16>(v[e]);
-                                else reinterpret_cast<float*>(p.C)[(size_t)m * p.ldc + n + e] = v[e];
-                            }
-                        } else if (p.c_bf16)
-                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.C) + (size_t)m * p.ldc + n) =
-                                pack_h16x4<kF16>(v0, v1, v2, v3);
-                        else
-                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = make_float4(v0, v1, v2, v3);
-                    }
-            }
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt][nt] = mfma_h16<kF16>(fb[nt], fa[mt], acc[mt][nt]);
         }
-    };
-
-    const int total = ntl * nk;                   // flattened (column tile, k-tile) iterations of this workgroup
-    load_next(0);
-    if (total > 1) load_next(1);
-    store_stage(0, 0);                            // waits for the first k-tile only (vmcnt retires in order)
-    __syncthreads();
-    const int lswz = (li >> 2) & 3;               // swizzle key of the lane's rows (row = multiple of 32 + li)
-    const unsigned char* a_base = As + (128 * wm + li) * GRS;
-    const unsigned char* b_base = Bs + (64 * wn + li) * GRS;
-    int c_tile = tile0, c_k = 0;                  // compute pointer
-    // iteration i is computed from LDS buffer i & 1 while iteration i + 1 sits in register set (i + 1) & 1 (loaded one
-    // iteration ago) and iteration i + 2 is requested into set i & 1; i + 1 goes to LDS at the END of the iteration
-#pragma unroll 1
-    for (int it = 0; it < total; it += 2) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {    // unrolled by 2 so that the register-set indices are compile-time
-            const int i = it + half;
-            if (i < total) {
-                if (i + 2 < total) load_next(half);
-                const unsigned char* a = a_base + half * GA_T;
-                const unsigned char* b = b_base + half * GB_T;
-#pragma unroll
-                for (int ks = 0; ks < GK / 16; ++ks) {
-                    const int co = ((2 * ks + lh) ^ lswz) * 16;
-                    uint4 fb[2], fa[4];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) fb[nt] = *reinterpret_cast<const uint4*>(b + nt * 32 * GRS + co);
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(a + mt * 32 * GRS + co);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[mt][nt] = mfma_h16<kF16>(fb[nt], fa[mt], acc[mt][nt]);
-                }
-                if (i + 1 < total) store_stage(half ^ 1, half ^ 1);       // iteration i + 1: requested one iteration ago
-                if constexpr (EPI != 0) {         // the store epilogue (EPI 0) is fat and runs once: after the loop, one tile per workgroup
-                    if (++c_k == nk) {            // last k-tile of a column tile: its epilogue runs while the next loads fly
-                        epilogue(c_tile * GN);
-                        zero_acc();
-                        c_k = 0; ++c_tile;
-                    }
-                }
-                __syncthreads();
-            }
-        }
+        buf = buf == 2 ? 0 : buf + 1;
     }
-    if constexpr (EPI == 0) epilogue(tile0 * GN);     // host: tn_per_wg == 1
+    if constexpr (EPI == 1) stats_tile(p, acc, m0, n0, wm, wn, li, lh);
+    else if constexpr (EPI == 2) softmax_tile(p, acc, m0, n0, wm, wn, li, lh);
+    else store_tile(p, acc, m0, n0, wm, wn, li, lh);
 }
 
 // fp32 rows -> bf16 rows (first `cols` columns, cols % 4 == 0); pad columns [cols, ld_dst) are zeroed
@@ -343,8 +332,7 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
-    p.n_wg = ceil_div(M, GM) * p.groups_n;
+    p.n_wg = ceil_div(M, GM) * p.tiles_n;
     CIAOSR_BIG_LDS(gemm_h16_kernel<0>, kGemm16Lds);
     ProfScope prof(tag ? tag : "gemm" CIAOSR_H16_SUFFIX, s);
     hipLaunchKernelGGL(gemm_h16_kernel<0>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
@@ -472,8 +460,7 @@ int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
-    p.n_wg = ceil_div(M, GM) * p.groups_n;
+    p.n_wg = ceil_div(M, GM) * p.tiles_n;
     CIAOSR_BIG_LDS(gemm_h16_kernel<0>, kGemm16Lds);
     ProfScope prof(tag, s);
     hipLaunchKernelGGL(gemm_h16_kernel<0>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
@@ -519,12 +506,9 @@ int softmax_gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* 
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    // One column tile per workgroup.  Several consecutive tiles in one software pipeline (tn_per_wg = 2 .. 8: the kernel supports it)
-    // measured the same 0.75 ms on the 192x192 tile's scores (M = 36864, N = 9216, K = 288): each 256 x 128 tile pulls 221 KB
-    // through L2 for 18.9 MFLOP, 2.3 GB per pass at ~6.5 TB/s -- the contraction is bound by L2 -> CU bandwidth, not by its
-    // prologue / epilogue latency.
-    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
-    p.n_wg = ceil_div(M, GM) * p.groups_n;
+    // (Several consecutive column tiles per workgroup as one software pipeline measured the same time on the 192x192 tile's scores
+    // -- M = 36864, N = 9216, K = 288: each 256 x 128 tile pulls 221 KB through L2 for 18.9 MFLOP -- and was dropped.)
+    p.n_wg = ceil_div(M, GM) * p.tiles_n;
     p.n_part = 2 * p.tiles_n;
     p.part = reinterpret_cast<float2*>(scratch);
     float2* stats = p.part + (size_t)M * p.n_part;
