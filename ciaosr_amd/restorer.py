@@ -152,10 +152,10 @@ class CiaoSR(BasicRestorer):
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
         n_streams = int(self.test_cfg.get('tile_streams', 1) or 1)
-        n_batch = int(self.test_cfg.get('tile_batch', 4) or 1)
+        n_batch = int(self.test_cfg.get('tile_batch', 8) or 1)
         if (tile_fn is None and n_streams <= 1 and n_batch > 1 and b == 1 and len(origins) > 1 and img_lq.is_cuda and
                 hasattr(getattr(self.generator, '_encoder_hip', None), 'forward_hwc_batch')):
-            # `test_cfg.tile_batch` (an extension; default 4) consecutive tiles share the encoder's dense-layer launches; every tile
+            # `test_cfg.tile_batch` (an extension; default 8) consecutive tiles share the encoder's dense-layer launches; every tile
             # is bitwise the one-at-a-time result and the blend order is the reference's
             for i0 in range(0, len(origins), n_batch):
                 group = origins[i0:i0 + n_batch]

@@ -756,7 +756,7 @@ def test_tile_streams_are_bitwise_the_single_stream_result(dev):
 def test_tile_batch_is_bitwise_the_one_tile_result(dev):
     """clip_test feeds `test_cfg.tile_batch` consecutive tiles through ONE encoder call (grid.y = image in the dense-layer
     kernels, row-wise 1x1 kernels over all rows; ciaosr_rdn_forward_batch_*): the 6-tile image must come out bitwise equal to the
-    one-tile-at-a-time loop for batch 2, 4 (default; ragged last group 4 + 2) and 6, in every precision."""
+    one-tile-at-a-time loop for batch 2, 4 (ragged last group 4 + 2) and 6 (the default 8 covers the whole image), in every precision."""
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     lq, _ = synthetic_pair(339, 510, 4)
     lq = lq.to(dev)
