@@ -499,6 +499,12 @@ def main():
                 model.restore(tl, options=oh)
                 extras['c3_tile_f16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=oh), 3, dev), 3)
                 extras['c3_tile_fp32_ms'] = round(time_steps(lambda: model.restore(tl), 3, dev), 3)
+                if args.workload == 'c3':        # the whole C3 image in the two opt-in 16-bit modes (PSNR-gated extensions; not the headline)
+                    for nm, o in (('f16', oh), ('bf16', o16)):
+                        model.restore(lq, options=o)
+                        t_ = time_steps(lambda: model.restore(lq, options=o), 1, dev)
+                        extras[f'c3_{nm}_mode_ms'] = round(t_, 1)
+                        extras[f'c3_{nm}_mode_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
                 c2 = synthetic_pair(48, 48, scale)[0].to(dev)
                 for _ in range(3):
                     model.restore(c2)
