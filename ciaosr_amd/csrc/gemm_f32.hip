@@ -16,6 +16,9 @@ namespace ciaosr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CIAOSR_GEMM32_TNK
+#define CIAOSR_GEMM32_TNK 24
+#endif
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_A = BK + 4;   // 36 floats / row (NT layouts)
 constexpr int LDS_BKN = BN + 4; // 132 floats / row for the [k][n] image
@@ -34,6 +37,8 @@ struct GemmP {
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents (< 4 GiB)
     int splitk, kt_per_split;    // skinny problems: the K loop is split over blockIdx.y into partial slabs
     float* partial;              // [splitk][M][N]
+    int tn_per_wg, groups_n;     // short K: a workgroup walks tn_per_wg consecutive column tiles of one row tile as ONE software
+                                 // pipeline (the first k-tile of the next column tile is prefetched under the last of the current)
 };
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -54,7 +59,8 @@ __device__ __forceinline__ float4 mask4(float4 v, int first, int limit) {
     return v;
 }
 
-template <bool B_KN>
+// MULTI: several column tiles per workgroup in one pipeline; plain epilogue only ((acc + bias) * alpha, no activation, no split-K)
+template <bool B_KN, bool MULTI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][A_TILE]
@@ -66,8 +72,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int m0 = (lid / p.tiles_n) * BM;
-    const int n0 = (lid % p.tiles_n) * BN;
+    const int m0 = (lid / p.groups_n) * BM;
+    const int tile0 = (lid % p.groups_n) * p.tn_per_wg;
+    const int ntl = min(p.tn_per_wg, p.tiles_n - tile0);          // column tiles of this workgroup
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
 
-    auto load_tiles = [&](int kt) {
+    auto load_tiles = [&](int kt, int n0) {
         const int k0 = kt * BK;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             }
         }
     };
-    auto store_tiles = [&](int buf, int kt) {
+    auto store_tiles = [&](int buf, int kt, int n0) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
         const int k0 = kt * BK;
@@ -143,13 +150,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tiles(kt0);
-    store_tiles(0, kt0);
+    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    auto epilogue = [&](int n0) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + li;
+            if (col >= p.N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row >= p.M) continue;
+                    if constexpr (!MULTI) {
+                        if (p.splitk > 1) {
+                            p.partial[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[mi][ni][r];
+                            continue;
+                        }
+                    }
+                    float v = (acc[mi][ni][r] + bv) * p.alpha;
+                    if constexpr (!MULTI) {
+                        if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
+                        else if (p.act == CIAOSR_ACT_SIN) v = sinf(v);
+                        else if (p.act == CIAOSR_ACT_COS) v = cosf(v);
+                    }
+                    p.C[(size_t)row * p.ldc + col] = v;
+                }
+            }
+        }
+    };
+
+    // flattened (column tile, k-tile) iterations; with tn_per_wg == 1 (and for split-K) this is the plain k-loop
+    const int nkl = kt1 - kt0;
+    const int total = ntl * nkl;
+    load_tiles(kt0, tile0 * BN);
+    store_tiles(0, kt0, tile0 * BN);
     __syncthreads();
 
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        if (kt + 1 < kt1) load_tiles(kt + 1);
+    int c_tile = tile0, c_kt = kt0;
+    for (int i = 0; i < total; ++i) {
+        const int cur = i & 1;
+        int n_tile = c_tile, n_kt = c_kt + 1;                      // next iteration
+        if (n_kt == kt1) { n_kt = kt0; ++n_tile; }
+        if (i + 1 < total) load_tiles(n_kt, n_tile * BN);
         const float* a = As + cur * A_TILE + (wm * 64 + li) * LDS_A + 4 * lh;
         const float* b = B_KN ? (Bs + cur * B_TILE + (4 * lh) * LDS_BKN + wn * 64 + li)
                               : (Bs + cur * B_TILE + (wn * 64 + li) * LDS_A + 4 * lh);
@@ -180,35 +225,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (kt + 1 < kt1) store_tiles(cur ^ 1, kt + 1);
-        __syncthreads();
-    }
-
-    // epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (i + 1 < total) store_tiles(cur ^ 1, n_kt, n_tile * BN);
+        if constexpr (MULTI) {
+            if (c_kt + 1 == kt1) {                                 // last k-tile of a column tile: its epilogue, then a fresh accumulator
+                epilogue(c_tile * BN);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int col = n0 + wn * 64 + ni * 32 + li;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+                    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= p.M) continue;
-                if (p.splitk > 1) {
-                    p.partial[((size_t)blockIdx.y * p.M + row) * p.N + col] = acc[mi][ni][r];
-                    continue;
-                }
-                float v = (acc[mi][ni][r] + bv) * p.alpha;
-                if (p.act == CIAOSR_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == CIAOSR_ACT_PRELU) v = v > 0.f ? v : v * p.slope;
-                else if (p.act == CIAOSR_ACT_SIN) v = sinf(v);
-                else if (p.act == CIAOSR_ACT_COS) v = cosf(v);
-                p.C[(size_t)row * p.ldc + col] = v;
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
             }
         }
+        c_tile = n_tile; c_kt = n_kt;
+        __syncthreads();
     }
+    if constexpr (!MULTI) epilogue(tile0 * BN);                    // one column tile per workgroup
 }
 
 __global__ void gemm_reduce_kernel(GemmP p) {
@@ -251,23 +283,40 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
         p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     }
     p.tiles_n = ceil_div(N, BN);
-    p.n_wg = ceil_div(M, BM) * p.tiles_n;
     p.splitk = 1;
     p.kt_per_split = (K + BK - 1) / BK;
     p.partial = nullptr;
+    // short K (the correlation scores: K = 288 = 9 k-tiles against 72 column tiles): a few consecutive column tiles per workgroup as one
+    // software pipeline, as long as the grid still fills the chip several times over.  192x192 tile: 2.50 -> 1.84 ms with 3 tiles per
+    // workgroup (0.50 -> 0.68 of the fp32 MFMA peak; 6 tiles 1.88, 12 tiles 2.03: the epilogue of a tile is serial work of its wave)
+    int tn = 1;
+#ifndef CIAOSR_GEMM32_TN1
+    if (p.kt_per_split <= 24 && act == CIAOSR_ACT_NONE) {
+        tn = ceil_div(CIAOSR_GEMM32_TNK, p.kt_per_split);
+        while (tn > 1 && (long)ceil_div(M, BM) * ceil_div(p.tiles_n, tn) < 2048) --tn;
+    }
+#endif
+    p.tn_per_wg = tn; p.groups_n = ceil_div(p.tiles_n, tn);
+    p.n_wg = ceil_div(M, BM) * p.groups_n;
     return gemm_launch(p, b_kn, stream, tag);
 }
 
 static int gemm_launch(GemmP& p, bool b_kn, hipStream_t stream, const char* tag) {
     const size_t smem = (size_t)(2 * A_TILE + 2 * B_TILE) * sizeof(float);
-    CIAOSR_BIG_LDS(gemm_f32_kernel<true>, smem);
-    CIAOSR_BIG_LDS(gemm_f32_kernel<false>, smem);
+    CIAOSR_BIG_LDS((gemm_f32_kernel<true, false>), smem);
+    CIAOSR_BIG_LDS((gemm_f32_kernel<false, false>), smem);
+    CIAOSR_BIG_LDS((gemm_f32_kernel<true, true>), smem);
+    CIAOSR_BIG_LDS((gemm_f32_kernel<false, true>), smem);
     {
         ProfScope prof(tag ? tag : (b_kn ? "gemm_f32_nn" : "gemm_f32_nt"), stream);
-        if (b_kn)
-            hipLaunchKernelGGL(gemm_f32_kernel<true>, dim3(p.n_wg, p.splitk), dim3(256), smem, stream, p);
-        else
-            hipLaunchKernelGGL(gemm_f32_kernel<false>, dim3(p.n_wg, p.splitk), dim3(256), smem, stream, p);
+        const dim3 grid(p.n_wg, p.splitk);
+        if (p.tn_per_wg > 1) {
+            if (b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), smem, stream, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), smem, stream, p);
+        } else {
+            if (b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), smem, stream, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), smem, stream, p);
+        }
     }
     int rc = launch_status("gemm_f32");
     if (rc != CIAOSR_OK || p.splitk == 1) return rc;
@@ -293,6 +342,7 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, BN);
+    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
     p.n_wg = ceil_div(M, BM) * p.tiles_n;
     const int nk = (K + BK - 1) / BK;
     int splits = ceil_div(512, p.n_wg);
