@@ -54,6 +54,7 @@ struct DenseH16P {
     const unsigned short* xb; int ldxb;      // bf16 feature buffer [HW][ldxb], 64-channel groups
     unsigned xb_bytes;
     int H, W, tiles_x;
+    int n_img;                               // images in the buffer (back to back); one workgroup walks its tile of every image
     int groups;                              // input groups of this layer (l + 1)
     const uint4* wf; int nks;                // ciaosr_pack_fragments_bf16 of the conv weight [64][9*cin]: [2][nks][64 lanes]
     const uint4* wf_lo;                      // ciaosr_pack_fragments_bf16_lo of the same matrix (hi + lo weight pair), or null
@@ -75,9 +76,12 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int ty0 = (blockIdx.x / p.tiles_x) * DT, tx0 = (blockIdx.x % p.tiles_x) * DT;
-    const size_t ipix = (size_t)blockIdx.y * p.H * p.W;                    // image blockIdx.y of the batch (same weights, own rows)
+    // The workgroup walks its 12x12 tile of EVERY image of the batch (same weights, own rows) as one software pipeline: the first
+    // weights and the halo patch of image i + 1 are requested during the last input group of image i, so only the first image pays the
+    // cold start.  Per image the work, its order and hence the result are those of a single-image launch.
+    const unsigned img_bytes = (unsigned)((size_t)p.H * p.W * p.ldxb * 2);
     const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xb + ipix * p.ldxb), 0, p.xb_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.xb), 0, p.xb_bytes, 0x00020000);
 
     // patch staging: thread -> 16-byte chunks t + 256 s  (pixel = chunk / 8, 8 chunks = 64 channels)
     unsigned goff[DLOADS];
@@ -98,8 +102,9 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
     auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
     i32x4 P[DLOADS];
-    auto load_chunk = [&](int s, int g) {
-        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobD ? (int)kOobD : (int)(goff[s] + (unsigned)phys(g) * 128u), 0, 0);
+    auto load_chunk = [&](int s, int g, int img) {
+        P[s] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs, goff[s] == kOobD ? (int)kOobD : (int)(goff[s] + (unsigned)phys(g) * 128u + (unsigned)img * img_bytes), 0, 0);
     };
     auto store_patch = [&](int buf) {
 #pragma unroll
@@ -124,12 +129,15 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     auto frag_lo = [&](int nt, int g, int tap) -> uint4 { return wll[(size_t)(nt * p.nks + tap * kpt + 4 * phys(g) + w) * 64]; };
 
     f32x16 acc[2][DMT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < DMT; ++r)
+            for (int r = 0; r < DMT; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+    };
+    zero_acc();
 
     // prologue: the first DPF weight stages go out BEFORE the patch (vmcnt retires in order: a later wait on the
     // weights would otherwise also wait for the patch)
@@ -140,16 +148,21 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
         if (has_lo) { wlq[tp][0] = frag_lo(0, 0, tp); wlq[tp][1] = frag_lo(1, 0, tp); }
     }
 #pragma unroll
-    for (int s = 0; s < DLOADS; ++s) load_chunk(s, 0);
+    for (int s = 0; s < DLOADS; ++s) load_chunk(s, 0, 0);
     store_patch(0);
     __syncthreads();
 
     const int G = p.groups;
     uint4 b[2][DMT];                         // activation fragments of the current tap and the next one
+    int pbuf = 0;                            // LDS patch buffer of the current (image, group)
+#pragma unroll 1
+    for (int img = 0; img < p.n_img; ++img) {
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
-        const bool more = g + 1 < G;
-        const unsigned char* pb = lds + (g & 1) * DPATCH;
+        const bool last_g = g + 1 == G;
+        const bool more = !last_g || img + 1 < p.n_img;          // another (image, group) follows: prefetch it
+        const int ng_next = last_g ? 0 : g + 1, nimg_next = last_g ? img + 1 : img;
+        const unsigned char* pb = lds + pbuf * DPATCH;
 #pragma unroll
         for (int r = 0; r < DMT; ++r)
             b[0][r] = *reinterpret_cast<const uint4*>(pb + poff[r] - DROW - DPS);      // tap 0
@@ -157,8 +170,9 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
         for (int tap = 0; tap < 9; ++tap) {
             {   // weights DPF taps ahead
                 int ng = g, ntap = tap + DPF;
-                if (ntap >= 9) { ntap -= 9; ng = g + 1; }
-                if (ng < G) {
+                bool have = true;
+                if (ntap >= 9) { ntap -= 9; ng = ng_next; have = more; }      // the next group -- of this image or the first of the next
+                if (have) {
                     wq[(tap + DPF) % 9][0] = frag(0, ng, ntap); wq[(tap + DPF) % 9][1] = frag(1, ng, ntap);
                     if (has_lo) { wlq[(tap + DPF) % 9][0] = frag_lo(0, ng, ntap); wlq[(tap + DPF) % 9][1] = frag_lo(1, ng, ntap); }
                 }
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
             // next group's whole patch right after the tap-3 weights left: the first wait that covers it is tap 4's
             if (more && tap == 1) {
 #pragma unroll
-                for (int s = 0; s < DLOADS; ++s) load_chunk(s, g + 1);
+                for (int s = 0; s < DLOADS; ++s) load_chunk(s, ng_next, nimg_next);
             }
             if (tap + 1 < 9) {               // LDS reads one tap ahead: their latency runs under this tap's 10 MFMAs
                 const int toff = (((tap + 1) / 3 - 1) * DROW) + (((tap + 1) % 3 - 1) * DPS);
@@ -191,12 +205,17 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // the ring is indexed by tap: stages 0 .. DPF-1 now hold the first taps of the next group
-        if (more) store_patch((g + 1) & 1);
+        if (!last_g) {
+            store_patch(pbuf ^ 1);
+            pbuf ^= 1;
+        }
         __syncthreads();
     }
 
-    // K-slice reduction + epilogue, one 32-channel half at a time through LDS:
+    // K-slice reduction + epilogue of this image, one 32-channel half at a time through LDS (the scratch overlays both patch buffers:
+    // the next image's patch stays in registers until it is done):
     // red[w][r][q][lane] = float4 of accumulator registers 4q..4q+3 (= channels 8q + 4lh .. +3 of pixel li of tile r)
+    const size_t ipix = (size_t)img * p.H * p.W;
     float4* red = reinterpret_cast<float4*>(lds);
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -231,6 +250,13 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
         }
         __syncthreads();
     }
+    if (img + 1 < p.n_img) {                 // next image: its first patch (requested during the last group) goes to LDS now
+        zero_acc();
+        pbuf = 0;
+        store_patch(0);
+        __syncthreads();
+    }
+    }
 }
 
 // fp32 columns [col, col+64) of X -> the same columns of the bf16 copy
@@ -260,11 +286,12 @@ int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int co
 int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
                      const float* bias, int n_img, hipStream_t s) {
     CIAOSR_CHECK_ARG(Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);      // X null: no fp32 copy of the output
-    const size_t xb_bytes = (size_t)H * W * ldxb * 2;
-    CIAOSR_CHECK_ARG(xb_bytes < 0xFFFFFF00ull);
+    const size_t xb_bytes = (size_t)n_img * H * W * ldxb * 2;
+    CIAOSR_CHECK_ARG(n_img >= 1 && xb_bytes < 0xFFFFFF00ull);
     DenseH16P p;
     p.xb = Xb; p.ldxb = ldxb; p.xb_bytes = (unsigned)xb_bytes;
     p.H = H; p.W = W; p.tiles_x = ceil_div(W, DT);
+    p.n_img = n_img;
     p.groups = l + 1;
     p.wf = reinterpret_cast<const uint4*>(frag16); p.nks = 9 * 64 * (l + 1) / 16;
     p.wf_lo = reinterpret_cast<const uint4*>(frag16_lo);
@@ -274,9 +301,9 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
     CIAOSR_BIG_LDS(dense_h16_kernel<false>, kDenseLds);
     ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
     if (p.wf_lo)
-        hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W), n_img), dim3(256), kDenseLds, s, p);
+        hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     else
-        hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W), n_img), dim3(256), kDenseLds, s, p);
+        hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     return launch_status("dense" CIAOSR_H16_SUFFIX);
 }
 
