@@ -36,6 +36,7 @@ struct DenseF32P {
     float* x; int ldx;                       // fp32 feature buffer [HW][ldx], 64-channel groups; read and written
     unsigned x_bytes;
     int H, W, tiles_x;
+    int n_img;                               // images in the buffer (back to back); one workgroup walks its tile of every image
     int groups;                              // input groups of this layer (l + 1)
     const float4* wf; int nj;                // fragments [2][nj][64 lanes] float4, nj = 9*cin/8
     const float* bias;                       // [64]
@@ -46,8 +47,11 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsf[];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
     const int ty0 = (blockIdx.x / p.tiles_x) * FT, tx0 = (blockIdx.x % p.tiles_x) * FT;
-    float* const xi = p.x + (size_t)blockIdx.y * p.H * p.W * p.ldx;        // image blockIdx.y of the batch (same weights, own rows)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xi, 0, p.x_bytes, 0x00020000);
+    // The workgroup walks its 12x12 tile of EVERY image of the batch (same weights, own rows) as one software pipeline: the first
+    // weights and the halo patch of image i + 1 are requested during the last input group of image i, so only the first image pays
+    // the cold start.  Per image the work, its order and hence the result are those of a single-image launch.
+    const unsigned img_bytes = (unsigned)((size_t)p.H * p.W * p.ldx * 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
 
     // patch staging: thread -> 16-byte chunks t + 256 s  (pixel = chunk / 16, 16 chunks = 64 channels)
     unsigned goff[FLOADS];
@@ -63,8 +67,9 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
         loff[s] = c < FCHUNKS ? px * FPS + part * 16 : -1;
     }
     i32x4 P[FLOADS];
-    auto load_chunk = [&](int s, int g) {
-        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobDF ? (int)kOobDF : (int)(goff[s] + (unsigned)g * 256u), 0, 0);
+    auto load_chunk = [&](int s, int g, int img) {
+        P[s] = __builtin_amdgcn_raw_buffer_load_b128(
+            rs, goff[s] == kOobDF ? (int)kOobDF : (int)(goff[s] + (unsigned)g * 256u + (unsigned)img * img_bytes), 0, 0);
     };
     auto store_patch = [&](int buf) {
 #pragma unroll
@@ -89,15 +94,18 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
     auto frag = [&](int nt, int g, int tap, int c) -> float4 { return wl[(size_t)(nt * p.nj + tap * jpt + 8 * g + 2 * w + c) * 64]; };
 
     f32x16 acc[2][FMT];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int r = 0; r < FMT; ++r)
+            for (int r = 0; r < FMT; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+    };
+    zero_acc();
 
 #pragma unroll
-    for (int s = 0; s < FLOADS; ++s) load_chunk(s, 0);
+    for (int s = 0; s < FLOADS; ++s) load_chunk(s, 0, 0);
     store_patch(0);
     float4 w0[2][2], w1[2][2];                // [chunk c][nt]: current tap and the next
 #pragma unroll
@@ -107,16 +115,22 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
     __syncthreads();
 
     const int G = p.groups;
+    int pbuf = 0;                             // LDS patch buffer of the current (image, group)
+#pragma unroll 1
+    for (int img = 0; img < p.n_img; ++img) {
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
-        const bool more = g + 1 < G;
-        const unsigned char* pb = ldsf + (g & 1) * FPATCH;
+        const bool last_g = g + 1 == G;
+        const bool more = !last_g || img + 1 < p.n_img;           // another (image, group) follows: prefetch it
+        const int ng_next = last_g ? 0 : g + 1, nimg_next = last_g ? img + 1 : img;
+        const unsigned char* pb = ldsf + pbuf * FPATCH;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             {   // weights of the next tap (a tap is 5120 MFMA cycles: one tap of lookahead covers any L2 latency)
                 int ng = g, ntap = tap + 1;
-                if (ntap == 9) { ntap = 0; ng = g + 1; }
-                if (ng < G) {
+                bool have = true;
+                if (ntap == 9) { ntap = 0; ng = ng_next; have = more; }       // the next group -- of this image or the first of the next
+                if (have) {
 #pragma unroll
                     for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -124,8 +138,8 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
                 }
             }
             if (more) {                                              // next group's patch, spread over the taps
-                if (tap < FLOADS) load_chunk(tap, g + 1);
-                if (tap + 9 < FLOADS) load_chunk(tap + 9, g + 1);
+                if (tap < FLOADS) load_chunk(tap, ng_next, nimg_next);
+                if (tap + 9 < FLOADS) load_chunk(tap + 9, ng_next, nimg_next);
             }
             const int toff = ((tap / 3 - 1) * FP + (tap % 3 - 1)) * FPS - kTapMin;
 #pragma unroll
@@ -150,12 +164,17 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) w0[c][nt] = w1[c][nt];
         }
-        if (more) store_patch((g + 1) & 1);
+        if (!last_g) {
+            store_patch(pbuf ^ 1);
+            pbuf ^= 1;
+        }
         __syncthreads();
     }
 
-    // K-slice reduction + epilogue, one 32-channel half at a time through LDS:
+    // K-slice reduction + epilogue of this image, one 32-channel half at a time through LDS (the scratch overlays both patch buffers:
+    // the next image's patch stays in registers until it is done):
     // red[w][r][q][lane] = float4 of accumulator registers 4q..4q+3 (= channels 8q + 4lh .. +3 of pixel li of tile r)
+    float* const xi = p.x + (size_t)img * p.H * p.W * p.ldx;
     float4* red = reinterpret_cast<float4*>(ldsf);
     for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
@@ -187,6 +206,13 @@ __global__ __launch_bounds__(256) void dense_f32_kernel(DenseF32P p) {
         }
         __syncthreads();
     }
+    if (img + 1 < p.n_img) {                  // next image: its first patch (requested during the last group) goes to LDS now
+        zero_acc();
+        pbuf = 0;
+        store_patch(0);
+        __syncthreads();
+    }
+    }
 }
 
 int dense_f32_tiles(int H, int W) { return ceil_div(H, FT) * ceil_div(W, FT); }
@@ -194,18 +220,19 @@ int dense_f32_tiles(int H, int W) { return ceil_div(H, FT) * ceil_div(W, FT); }
 // dense layer l of a block: input groups 0..l of X, output group l+1; X holds n_img images of H x W rows back to back
 int dense_layer_f32(float* X, int ldx, int H, int W, int l, const float* frag, const float* bias, int n_img, hipStream_t s) {
     CIAOSR_CHECK_ARG(X && frag && bias && (ldx & 3) == 0 && aligned16(X) && aligned16(frag) && aligned16(bias));
-    const size_t x_bytes = (size_t)H * W * ldx * 4;
-    CIAOSR_CHECK_ARG(x_bytes < 0xFFFFFF00ull);
+    const size_t x_bytes = (size_t)n_img * H * W * ldx * 4;
+    CIAOSR_CHECK_ARG(n_img >= 1 && x_bytes < 0xFFFFFF00ull);
     DenseF32P p;
     p.x = X; p.ldx = ldx; p.x_bytes = (unsigned)x_bytes;
     p.H = H; p.W = W; p.tiles_x = ceil_div(W, FT);
+    p.n_img = n_img;
     p.groups = l + 1;
     p.wf = reinterpret_cast<const float4*>(frag); p.nj = 9 * 64 * (l + 1) / 8;
     p.bias = bias;
     p.col_out = 64 * (l + 1);
     CIAOSR_BIG_LDS(dense_f32_kernel, kDenseF32Lds);
     ProfScope prof("enc_dense_gather", s);
-    hipLaunchKernelGGL(dense_f32_kernel, dim3(dense_f32_tiles(H, W), n_img), dim3(256), kDenseF32Lds, s, p);
+    hipLaunchKernelGGL(dense_f32_kernel, dim3(dense_f32_tiles(H, W)), dim3(256), kDenseF32Lds, s, p);
     return launch_status("dense_f32");
 }
 

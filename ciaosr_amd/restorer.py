@@ -152,7 +152,7 @@ class CiaoSR(BasicRestorer):
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
         n_streams = int(self.test_cfg.get('tile_streams', 1) or 1)
-        n_batch = int(self.test_cfg.get('tile_batch', 8) or 1)
+        n_batch = min(int(self.test_cfg.get('tile_batch', 8) or 1), 16)      # 32-bit buffer offsets into the batched block buffer
         if (tile_fn is None and n_streams <= 1 and n_batch > 1 and b == 1 and len(origins) > 1 and img_lq.is_cuda and
                 hasattr(getattr(self.generator, '_encoder_hip', None), 'forward_hwc_batch')):
             # `test_cfg.tile_batch` (an extension; default 8) consecutive tiles share the encoder's dense-layer launches; every tile
