@@ -245,7 +245,10 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     build_rows<MT>(X, p.k, s_kpix, s_t4, t);
     __syncthreads();
     HPROBE(2);
-    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer<MT>(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.k.n_hidden; ++l) {
+        hidden_layer<MT>(X, p.k.frag_hidden[l], p.k.bias_hidden[l], w, lane);
+        if (l < 3) HPROBE(10 + l);
+    }
     HPROBE(3);
 
     if (table) {
@@ -350,7 +353,10 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     build_rows<MT>(X, p.v, s_kpix, s_t4, t);   // all waves are past their last read of X (barrier above)
     __syncthreads();
     HPROBE(5);
-    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer<MT>(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+    for (int l = 0; l < p.v.n_hidden; ++l) {
+        hidden_layer<MT>(X, p.v.frag_hidden[l], p.v.bias_hidden[l], w, lane);
+        if (l < 3) HPROBE(13 + l);
+    }
     HPROBE(6);
     {
         const int n_units = (p.v.n_out + 31) >> 5;

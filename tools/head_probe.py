@@ -37,6 +37,14 @@ print(f'{n} workgroups; lifetime avg {tot.mean():.0f} ticks (min {tot.min()}, ma
 for i, nm in enumerate(names):
     print(f'  {nm:20s} {d[:, i].mean():9.0f} ticks avg  ({100 * d[:, i].mean() / tot.mean():5.1f} %)')
 if MODE == 'fp32':
+    kl = [a[:, 10] - a[:, 2], a[:, 11] - a[:, 10], a[:, 12] - a[:, 11]]
+    vl = [a[:, 13] - a[:, 5], a[:, 14] - a[:, 13], a[:, 15] - a[:, 14]]
+    print('  k hidden layers 1..3: ' + ', '.join(f'{x.mean():.0f}' for x in kl) + '   v hidden layers 1..3: ' + ', '.join(f'{x.mean():.0f}' for x in vl))
+    # by start order within the launch: the first 1024 workgroups start together (one round = 4 per CU x 256 CUs)
+    order = np.argsort(a[:, 0])
+    for nm, sel in (('first round (start in lockstep)', order[:1024]), ('later rounds', order[1024:])):
+        dd = d[sel]
+        print(f'  {nm}: lifetime {tot[sel].mean():.0f}; k hidden {dd[:, 2].mean():.0f}, v hidden {dd[:, 5].mean():.0f}, v out {dd[:, 6].mean():.0f}')
     mfma = 64 * (3 * 256 + 3 * 256 + 5 * 128)       # MFMA issue cycles of one wave (32-row workgroup): 6 hidden layers + its 5 v-out units
     print(f'  MFMA issue cycles of one wave: {mfma} ({100 * mfma / tot.mean():.1f} % of the lifetime; four workgroups share a CU)')
 else:
