@@ -814,6 +814,27 @@ def test_c3_full_image_tiled_restore_properties(dev):
     assert ((band - mean2).abs() * ok).max().item() < 1e-6
 
 
+def test_c3_full_image_16bit_modes_meet_the_psnr_gate(dev):
+    """C3 itself in the two opt-in 16-bit modes: the whole 1356x2040 LR image (117 tiles), sqrt(6)-gain head and gain-1.5 trunk as in the
+    full-tile reference vector.  The fp32 image is the pinned path (tile golden + the tiled-restore properties above); the bf16 (weight
+    pairs) and f16 images must be within the north-star gate of it, measured exactly as `evaluate` does (uint8, Y channel, crop 4):
+    |PSNR(mode, GT) - PSNR(fp32, GT)| <= 0.01 dB."""
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    from ciaosr_amd.metrics import psnr_tensors
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
+    seeded_init_(model, seed=0, gain=1.5, head_gain=SQRT6)
+    model = model.to(dev)
+    lq, gt = synthetic_pair(1356, 2040, 4)
+    lq = lq.to(dev)
+    ref = psnr_tensors(model.restore(lq).cpu(), gt, crop_border=4)
+    for mode in ('f16', 'bf16'):
+        out = model.restore(lq, options=mode).cpu()
+        assert torch.isfinite(out).all()
+        d = abs(psnr_tensors(out, gt, crop_border=4) - ref)
+        print(f'C3 full image {mode}: PSNR delta vs the fp32 image {d:.5f} dB (fp32 PSNR vs GT {ref:.4f})')
+        assert d <= 0.01, (mode, d)
+
+
 def test_tiling_vs_golden(dev):
     fx = load_golden('tiling_small')
     model = _restorer('edsr', 2, dev, dict(scale=2, tile=48, tile_overlap=16), mid=16, blocks=2, hidden=(64, 64))
