@@ -126,6 +126,32 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
         out, _ = restorer.run_tile(x_norm, hi, wi, tile, sf, opt)
         return out
 
+    # Tile batching (restorer.clip_test's `test_cfg.tile_batch`): this rank's next B tiles go through the encoder in ONE call (shared
+    # dense-layer launches, encoder_hip.forward_hwc_batch: every feature map bitwise the single-tile one); the head then runs tile by
+    # tile in the driver's order, so sends, receives and the blend order are unchanged.
+    gen = restorer.generator
+    enc = getattr(gen, '_encoder_hip', None)
+    n_batch = min(int(cfg.get('tile_batch', 8) or 1), 16)
+    if (n_batch > 1 and x_norm.is_cuda and x_norm.shape[0] == 1 and enc is not None and hasattr(enc, 'forward_hwc_batch')
+            and enc.supported() and getattr(gen, '_head', None) is not None):
+        tile_sz, origins = tile_grid(x_norm.shape[-2], x_norm.shape[-1], cfg.get('tile'), cfg.get('tile_overlap'))
+        mine = origins[rank::world]
+        pos = {o: i for i, o in enumerate(mine)}
+        cache = {}
+
+        def tile_fn(hi, wi, tile):                            # noqa: F811 - the batched variant replaces the one above
+            if (hi, wi) not in cache:
+                grp = mine[pos[(hi, wi)]:pos[(hi, wi)] + n_batch]
+                patches = torch.cat([x_norm[..., h0:h0 + tile, w0:w0 + tile] for (h0, w0) in grp], 0).contiguous().float()
+                feats = enc.forward_hwc_batch(patches, opt)
+                for j, o in enumerate(grp):
+                    cache[o] = (patches[j], feats[j])
+            patch, feat = cache.pop((hi, wi))
+            th, tw = round(patch.shape[-2] * sf), round(patch.shape[-1] * sf)
+            coord, cell = hip_ops.make_coord_cell(th, tw, patch.device)
+            out = gen._head.forward(None, patch, coord, cell, gen.eval_bsize, feature_hwc=feat, options=opt)
+            return out.unsqueeze(0)
+
     def blend_fn(E, Wt, out, y0, x0, th, tw):
         for bi in range(E.shape[0]):
             hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), y0, x0, th, tw)
