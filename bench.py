@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- HR Mpix/s of the CiaoSR LocalImplicitSR forward path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N > 1: either launched by torch.distributed.run, one rank per GPU,
+                                                          or from a plain shell -- bench.py then starts its N ranks itself)
 
 Workload (default, every N): BASELINE.json's metric config "RDN-CiaoSR x4 on 2K LR input, tiled inference" (C3; C4 for
 N > 1): RDN-CiaoSR (c64b16) x4, ONE synthetic DIV2K-shaped LR image of 1356x2040 -> 5424x8160, `clip_test` tiling
@@ -25,11 +26,39 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` from a plain shell with N > 1 (no WORLD_SIZE in the environment): start the N ranks here, the
+    way the reference's tools/dist_test.sh:8-10 does (`python -m torch.distributed.launch --nproc_per_node=$GPUS ... test.py`):
+    one fresh child `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same args>`; its stdout (rank 0's JSON line) is inherited, this process exits with its return code.  Runs BEFORE
+    torch is imported: the parent never touches the GPU and nothing is exec'ed from an initialised process."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument('--gpus', type=int, default=1)
+    n = ap.parse_known_args(argv)[0].gpus
+    if n <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == '__main__':
+    self_launch(sys.argv[1:])
+
+import torch                                    # noqa: E402 - after self_launch on purpose
+import torch.distributed as dist                # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0           # HBM3E spec
@@ -250,7 +279,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if args.gpus > 1 and world == 1:
-        raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)')
+        raise SystemExit('--gpus N > 1 with WORLD_SIZE=1 in the environment: unset WORLD_SIZE (bench.py then starts its own ranks) '
+                         'or launch with torch.distributed.run --nproc-per-node N')
     assert world == args.gpus, f'WORLD_SIZE {world} != --gpus {args.gpus}'
     if world > 1 and args.workload in ('c2', 'c3tile'):
         raise SystemExit(f'--workload {args.workload} is a single-tile, single-GPU measurement (use c3 / c3s for tile sharding, c2q for query sharding)')
@@ -294,6 +324,8 @@ def main():
         q_coord = make_coord((lr_h * scale, lr_w * scale)).unsqueeze(0).to(dev)
         q_cell = make_cell((lr_h * scale, lr_w * scale)).unsqueeze(0).to(dev)
 
+    tail = {}                                         # stream events of the last step (N > 1): exposed-tail figure
+
     def step():
         if world == 1:
             return model.restore(lq, options=opt)
@@ -301,9 +333,12 @@ def main():
         if args.workload == 'c2q':
             pred = predict_query_sharded(model, x, q_coord, q_cell, rank, world, options=opt)
         else:
-            pred = clip_test_distributed(model, x, rank, world, options=opt)
+            pred = clip_test_distributed(model, x, rank, world, options=opt, stats=tail)
         if rank == 0:
-            return hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
+            out = hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
+            tail['ready'] = torch.cuda.Event(enable_timing=True)
+            tail['ready'].record(torch.cuda.current_stream(dev))
+            return out
         return None
 
     def sync():
@@ -367,8 +402,13 @@ def main():
     prof_dom = hip_ops.profile.results()
     lib.ciaosr_prof_filter(None)
 
+    rank_ms = None
     if world > 1:
+        # every rank's own wall time of the timed region (load balance), then the contract's MAX over ranks
         tt = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        rank_ms = [round(float(t.item()) / args.steps * 1e3, 3) for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -452,7 +492,7 @@ def main():
             'value': round(out_pixels / 1e6 / (elapsed / args.steps), 4),
             'unit': 'Mpix/s', 'n_gpus': world, 'rccl_ranks': rccl_ranks, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms, 4), 'higher_is_better': True,
-            'scaling': 'weak' if world == 1 else 'strong', 'vs_baseline': None,
+            'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'fp32' else (
                 'f16 (IEEE half) MFMA inputs, saturating conversions, fp32 accumulate, in the head, the dense layers and the cs_attn contractions'
                 if args.precision == 'f16' else
@@ -470,6 +510,16 @@ def main():
             'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
                 prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
         }
+        if world > 1:
+            from ciaosr_amd.tile_shard import partition
+            line['rank_ms_per_step'] = rank_ms
+            if args.workload != 'c2q':
+                line['tiles_per_rank'] = [len(p) for p in partition(n_tiles_img, world)]
+                if 'last_own_tile' in tail and 'ready' in tail:
+                    # GPU-timeline time on rank 0 from "its last own tile's kernels are done" to "the image is ready": the last
+                    # round's receives, the remaining blends, tile_finalize and denorm_clamp -- the part of the exchange that does
+                    # NOT hide under compute (last timed step)
+                    line['exposed_tail_ms'] = round(tail['last_own_tile'].elapsed_time(tail['ready']), 3)
         if world == 1 and not args.no_extras and roof is not None:
             extras = {}
             # (1) the HBM-bound kernels of the staged route (north star: >= 40 % of the HBM roofline on the local-attention

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "../../include/ciaosr_hip.h"
 
@@ -28,20 +29,27 @@ struct ProfScope {
 };
 
 // > 64 KiB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  The attribute belongs to the
-// (kernel, device) pair, so the one-time setup is tracked per device: `done` is a zero-initialised flag array owned by the
-// call site (one per kernel).  Racing first calls both set the same value, which is harmless.  Returns false if HIP refuses.
+// (kernel, device) pair: `granted` (zero-initialised, owned by the call site, one per kernel) holds the largest size already
+// granted on each device, and the attribute is raised again whenever a launch needs more (a kernel whose LDS size depends on
+// its arguments, e.g. the weights-resident 1x1 with K = the block width).  Raising is serialised so that the attribute never
+// shrinks under a concurrent caller.  Returns false if HIP refuses.
 constexpr int kMaxDevices = 32;
-struct LdsAttrOnce { std::atomic<unsigned char> done[kMaxDevices]; };
+struct LdsAttrOnce {
+    std::atomic<unsigned> granted[kMaxDevices];
+    std::mutex raise;
+};
 template <typename K>
 static inline bool allow_big_lds(LdsAttrOnce& once, K kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return true;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return false;
-    if (once.done[dev].load(std::memory_order_acquire)) return true;
+    if (once.granted[dev].load(std::memory_order_acquire) >= bytes) return true;
+    std::lock_guard<std::mutex> lock(once.raise);
+    if (once.granted[dev].load(std::memory_order_relaxed) >= bytes) return true;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) !=
         hipSuccess)
         return false;
-    once.done[dev].store(1, std::memory_order_release);
+    once.granted[dev].store((unsigned)bytes, std::memory_order_release);
     return true;
 }
 

@@ -97,7 +97,22 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
     hipStream_t s = (hipStream_t)stream_;
     const size_t HW = (size_t)H * W, BHW = (size_t)B * HW;
     const int cb = C + G * NL;
-    CIAOSR_CHECK_ARG(BHW * cb * sizeof(float) < 0xFFFFFF00ull);
+    // The batched block buffers [B*HW][cb] are addressed with 32-bit buffer offsets by the halo-resident dense kernels: a batch that
+    // does not fit runs as sub-batches that do (same workgroups per image: still bitwise the one-image result); a SINGLE image that
+    // does not fit leaves the halo-resident routes to the generic ones, whose launchers check their own operands.
+    const size_t widest = (size_t)(cb > G * NB ? cb : G * NB);      // block buffer or global concat rows, whichever is wider
+    const bool fits32 = BHW * widest * sizeof(float) < 0xFFFFFF00ull;
+    if (B > 1 && !fits32) {
+        size_t bmax = (size_t)(0xFFFFFF00ull - 1) / (HW * widest * sizeof(float));
+        if (bmax < 1) bmax = 1;
+        for (int i = 0; i < B; i += (int)bmax) {
+            const int nb = B - i < (int)bmax ? B - i : (int)bmax;
+            const int rc = rdn_forward(x_nchw + (size_t)i * 3 * HW, nb, H, W, w, feat_hwc + (size_t)i * HW * C, opt, workspace, workspace_bytes,
+                                       stream_, prec);
+            if (rc != CIAOSR_OK) return rc;
+        }
+        return CIAOSR_OK;
+    }
     Arena ar(workspace, workspace_bytes);
     float* img4 = ar.take<float>(HW * 4);
     float* rows = ar.take<float>(HW * 36);
@@ -113,11 +128,11 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
     // 16-bit modes: the dense layers (97 % of the trunk's MACs) run on the bf16 / f16 MFMA when the map is big enough to give
     // every CU a tile (dense_h16.hip); first/last convolutions, LFF/GFF 1x1 and all residual sums stay fp32
-    bool dense16 = bf16 && C == 64 && G == 64 && min_tiles > 0 && b16::dense_h16_tiles(H, W) >= min_tiles;
+    bool dense16 = fits32 && bf16 && C == 64 && G == 64 && min_tiles > 0 && b16::dense_h16_tiles(H, W) >= min_tiles;
     if (bf16)
         for (int i = 0; i < NB * NL && dense16; ++i) dense16 = w->dense[i].frag16 != nullptr;
     // big maps, fp32: halo-resident gather-form dense layers (dense_f32.hip) instead of the scatter form
-    bool dense32 = !dense16 && C == 64 && G == 64 && min_tiles > 0 && dense_f32_tiles(H, W) >= min_tiles;
+    bool dense32 = fits32 && !dense16 && C == 64 && G == 64 && min_tiles > 0 && dense_f32_tiles(H, W) >= min_tiles;
     for (int i = 0; i < NB * NL && dense32; ++i) dense32 = w->dense[i].frag != nullptr;
     // f16 mode: the local feature fusion (1x1 over the block's 576 channels) too reads the 16-bit copy of the block buffer, on the
     // 16-bit GEMM with bias + residual in its epilogue; the dense layers then need no fp32 copy of their outputs, and the epilogue

@@ -9,14 +9,36 @@ import torch
 from . import _lib, hip_ops
 
 
-def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False):
-    w = conv.weight.detach().float()
+def _ceil32(c):
+    return (c + 31) // 32 * 32
+
+
+def _widen(w, b, widen):
+    """Zero-pad a conv's channel GROUPS from width c to the next multiple of 32 (the implicit-GEMM kernels take 32-channel K
+    steps): weight [co][g*c][k][k] -> [co'][g*c'][k][k], bias [co] -> [co'].  The extra output channels are exactly 0 (zero
+    weights, zero bias; relu(0) = 0) and the extra input channels meet zero weights, so the first c channels of every group are
+    the unpadded network's values bit for bit up to the order of the (unchanged) non-zero products."""
+    if widen is None:
+        return w, b
+    c, cp = widen
+    co, ci, kh, kw = w.shape
+    if ci % c == 0 and ci >= c:
+        g = ci // c
+        w = torch.nn.functional.pad(w.view(co, g, c, kh, kw), (0, 0, 0, 0, 0, cp - c)).reshape(co, g * cp, kh, kw)
+    if co == c:
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, cp - c))
+        b = torch.nn.functional.pad(b, (0, cp - c))
+    return w.contiguous(), b.contiguous()
+
+
+def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False, widen=None):
+    w, b0 = _widen(conv.weight.detach().float(), conv.bias.detach().float(), widen)
     co, ci, kh, kw = w.shape
     w = w.permute(0, 2, 3, 1)
     if pad_cin_to is not None and ci < pad_cin_to:
         w = torch.nn.functional.pad(w, (0, pad_cin_to - ci))
     w = w.reshape(co, -1).contiguous()
-    b = conv.bias.detach().float().contiguous()
+    b = b0.contiguous()
     hip_ops.require_gpu(w, b)
     keep += [w, b]
     st = _lib.ConvT()
@@ -94,24 +116,32 @@ class PackedEncoder:
             self._st_f16, self._keep_f16 = st, keep
         return self._st_f16
 
+    def width(self):
+        """(c, c'): the trunk's channel width and the width the kernels run it at (next multiple of 32, zero-padded weights)."""
+        n = self.net
+        c = (n.sfe1 if self.kind == 'rdn' else n.conv_first).out_channels
+        return c, _ceil32(c)
+
     def _build(self, key):
         n, keep = self.net, []
+        c, cp = self.width()
+        wd = (c, cp) if cp != c else None
         if self.kind == 'rdn':
             st = _lib.RdnWeightsT()
             nb, nl = len(n.rdbs), len(n.rdbs[0].layers)
-            st.mid_channels = n.sfe1.out_channels
-            st.growth = n.rdbs[0].layers[0].conv.out_channels
+            st.mid_channels = cp
+            st.growth = cp
             st.num_blocks, st.num_layers = nb, nl
-            st.sfe1 = _pack_conv(n.sfe1, keep, pad_cin_to=4)
-            st.sfe2 = _pack_conv(n.sfe2, keep, frag=True)
-            st.gff0 = _pack_conv(n.gff[0], keep)
-            st.gff1 = _pack_conv(n.gff[1], keep, frag=True)
+            st.sfe1 = _pack_conv(n.sfe1, keep, pad_cin_to=4, widen=wd)
+            st.sfe2 = _pack_conv(n.sfe2, keep, frag=True, widen=wd)
+            st.gff0 = _pack_conv(n.gff[0], keep, widen=wd)
+            st.gff1 = _pack_conv(n.gff[1], keep, frag=True, widen=wd)
             dense = (_lib.ConvT * (nb * nl))()
             lff = (_lib.ConvT * nb)()
             for b in range(nb):
                 for l in range(nl):
-                    dense[b * nl + l] = _pack_conv(n.rdbs[b].layers[l].conv, keep, frag16=True)
-                lff[b] = _pack_conv(n.rdbs[b].lff, keep)
+                    dense[b * nl + l] = _pack_conv(n.rdbs[b].layers[l].conv, keep, frag16=True, widen=wd)
+                lff[b] = _pack_conv(n.rdbs[b].lff, keep, widen=wd)
             st.dense, st.lff = dense, lff
             keep += [dense, lff]
             st.scatter_weight, st.scatter_bias, st.scatter_frag = None, None, None
@@ -121,7 +151,8 @@ class PackedEncoder:
                 ptrs = (C.c_void_p * (nb * nl))()
                 fptrs = (C.c_void_p * (nb * nl))()
                 for b in range(nb):
-                    convs = [n.rdbs[b].layers[l].conv.weight.detach().float() for l in range(nl)]   # [64][64(l+1)][3][3]
+                    convs = [_widen(n.rdbs[b].layers[l].conv.weight.detach().float(), n.rdbs[b].layers[l].conv.bias.detach().float(), wd)[0]
+                             for l in range(nl)]                                                 # [64][64(l+1)][3][3]
                     for s_ in range(nl):
                         sl = [convs[l][:, 64 * s_:64 * s_ + 64].permute(0, 2, 3, 1).reshape(64, 576) for l in range(s_, nl)]
                         wst = torch.cat(sl, 0).contiguous()
@@ -133,7 +164,8 @@ class PackedEncoder:
                                   hip_ops.stream_ptr())
                         keep.append(fr)
                         fptrs[b * nl + s_] = fr.data_ptr()
-                bias = torch.stack([torch.stack([n.rdbs[b].layers[l].conv.bias.detach().float() for l in range(nl)])
+                bias = torch.stack([torch.stack([_widen(n.rdbs[b].layers[l].conv.weight.detach().float(),
+                                                        n.rdbs[b].layers[l].conv.bias.detach().float(), wd)[1] for l in range(nl)])
                                     for b in range(nb)]).contiguous()
                 keep += [ptrs, fptrs, bias]
                 st.scatter_frag = C.cast(fptrs, C.POINTER(C.c_void_p))
@@ -142,28 +174,40 @@ class PackedEncoder:
         else:
             st = _lib.EdsrWeightsT()
             nb = len(n.body)
-            st.mid_channels = n.conv_first.out_channels
+            st.mid_channels = cp
             st.num_blocks = nb
             st.res_scale = float(n.body[0].res_scale) if nb else 1.0
-            st.conv_first = _pack_conv(n.conv_first, keep, pad_cin_to=4)
-            st.conv_after_body = _pack_conv(n.conv_after_body, keep, frag=True)
+            st.conv_first = _pack_conv(n.conv_first, keep, pad_cin_to=4, widen=wd)
+            st.conv_after_body = _pack_conv(n.conv_after_body, keep, frag=True, widen=wd)
             c1 = (_lib.ConvT * max(nb, 1))()
             c2 = (_lib.ConvT * max(nb, 1))()
             for b in range(nb):
-                c1[b] = _pack_conv(n.body[b].conv1, keep, frag=True)
-                c2[b] = _pack_conv(n.body[b].conv2, keep, frag=True)
+                c1[b] = _pack_conv(n.body[b].conv1, keep, frag=True, widen=wd)
+                c2[b] = _pack_conv(n.body[b].conv2, keep, frag=True, widen=wd)
             st.conv1, st.conv2 = c1, c2
             keep += [c1, c2]
         self._st, self._keep, self._key = st, keep, key
 
     def supported(self):
+        """Every width runs on the HIP trunk (narrow / odd widths zero-padded to a multiple of 32 at packing time).  Not covered:
+        other than 3 input channels, and an RDN whose growth differs from its width (mmedit's RDN feeds rdbs[b > 0] with
+        `channel_growth` channels and adds sfe1 (`mid_channels`) at the end, so it cannot even run with the two different)."""
         n = self.net
-        c = (n.sfe1 if self.kind == 'rdn' else n.conv_first).out_channels
-        if c % 32:
-            return False
         if self.kind == 'rdn':
-            return n.rdbs[0].layers[0].conv.out_channels == c and n.sfe1.in_channels == 3
+            return n.rdbs[0].layers[0].conv.out_channels == n.sfe1.out_channels and n.sfe1.in_channels == 3
         return n.conv_first.in_channels == 3
+
+    def why_unsupported(self):
+        n = self.net
+        if self.kind == 'rdn':
+            return (f'RDN trunk with in_channels={n.sfe1.in_channels}, mid_channels={n.sfe1.out_channels}, '
+                    f'channel_growth={n.rdbs[0].layers[0].conv.out_channels}: the HIP trunk needs in_channels=3 and '
+                    f'channel_growth == mid_channels')
+        return f'EDSR trunk with in_channels={n.conv_first.in_channels}: the HIP trunk needs in_channels=3'
+
+    def _narrow(self, out):
+        c, cp = self.width()
+        return out if c == cp else out[..., :c].contiguous()
 
     @torch.no_grad()
     def forward_hwc_batch(self, x_bchw, options=None):
@@ -182,7 +226,7 @@ class PackedEncoder:
         out = torch.empty(B, H, W, st.mid_channels, dtype=torch.float32, device=x_bchw.device)
         _lib.call('ciaosr_rdn_forward_batch_' + opt.suffix, hip_ops.ptr(x_bchw), B, H, W, C.byref(st), hip_ops.ptr(out), opt.c_arg(),
                   hip_ops.ptr(ws), ws.numel(), hip_ops.stream_ptr())
-        return out
+        return self._narrow(out)
 
     @torch.no_grad()
     def forward_hwc(self, x_chw, options=None):
@@ -207,4 +251,4 @@ class PackedEncoder:
         else:
             _lib.call(fn, hip_ops.ptr(x_chw), H, W, C.byref(st), hip_ops.ptr(out), hip_ops.ptr(ws), ws.numel(),
                       hip_ops.stream_ptr())
-        return out
+        return self._narrow(out)

@@ -74,6 +74,20 @@ def workspace(nbytes, device, slot='head'):
     return buf
 
 
+def take_workspaces(stream):
+    """Remove and return the scratch buffers that were grown on `stream` (a torch.cuda.Stream): the caller becomes their owner
+    (graphed_restore hands them to the captured graph's closure), and a later stream that happens to get the same raw handle
+    starts with fresh scratch.  `release_workspaces()` = the same for every stream, dropping the buffers."""
+    handle = stream.cuda_stream
+    keys = [k for k in _workspaces if k[3] == handle and k[2] == stream.device_index]
+    return {k: _workspaces.pop(k) for k in keys}
+
+
+def release_workspaces():
+    """Drop every cached scratch buffer (they are re-grown on demand)."""
+    _workspaces.clear()
+
+
 def gemm(a, b, bias=None, act=_lib.ACT_NONE, slope=0.0, alpha=1.0, b_is_kn=False, out=None):
     """out[M,N] = act((a[M,K] @ (b[N,K]^T | b[K,N]) + bias) * alpha) through ciaosr_gemm_f32."""
     require_gpu(a, b, bias, allow_row_stride=True)

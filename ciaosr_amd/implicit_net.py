@@ -6,8 +6,10 @@ Mirrors mmedited/models/backbones/sr_backbones/ciaosr_net.py:
   LocalImplicitSRRDN   (:267-342)  re-parents sfe1/sfe2/rdbs/gff, deletes `encoder`
   LocalImplicitSREDSR  (:345-408)  re-parents conv_first/body/conv_after_body
 Same constructor arguments, attribute and state_dict names, argument meaning and error behaviour.
-The arithmetic of query_rgb / batched_predict runs in libciaosr_hip.so (hand-written gfx950 kernels);
-the encoder trunk runs through PyTorch-ROCm.  Inference only.
+The arithmetic of query_rgb / batched_predict AND of the encoder trunks (gen_feature) runs in libciaosr_hip.so
+(hand-written gfx950 kernels).  There is no PyTorch trunk in the product: a trunk configuration the HIP library
+does not cover raises CiaoSRHipError (the PyTorch restatements live in tests/torch_trunks.py as checkers).
+Inference only.
 """
 import copy
 
@@ -15,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import hip_ops
+from ._lib import CiaoSRHipError
 from .head_hip import PackedHead
 from .encoder_hip import PackedEncoder
 from .nonlocal_attn import CrossScaleAttention
@@ -68,8 +71,9 @@ class LocalImplicitSRNet(nn.Module):
         `options` (extension, absent from the reference): hip_ops.Options / 'bf16' / None = exact-fp32 defaults."""
         chunk = None if (self.eval_bsize is None or not test_mode) else self.eval_bsize
         enc = getattr(self, '_encoder_hip', None)
-        if enc is not None and x.is_cuda and enc.supported():
+        if enc is not None:
             # HIP trunk: channels-last feature map goes straight into the head (no NCHW round trip)
+            self._require_hip_trunk(x)
             x = x.contiguous().float()
             if hasattr(enc, 'forward_hwc_batch'):            # RDN: the batch shares the trunk's dense-layer launches
                 feats = enc.forward_hwc_batch(x, options)
@@ -80,6 +84,20 @@ class LocalImplicitSRNet(nn.Module):
             return torch.stack(outs, 0)
         features = self.gen_feature(x, options)
         return self._predict(features, coord, cell, chunk, x, options)
+
+    def _require_hip_trunk(self, x):
+        """No silent PyTorch trunk: CPU input or a trunk shape outside the HIP library's coverage is an error."""
+        hip_ops.require_gpu(x.contiguous() if x.dtype == torch.float32 else x.float().contiguous())
+        enc = self._encoder_hip
+        if not enc.supported():
+            raise CiaoSRHipError('no HIP trunk for this encoder configuration (and no PyTorch fallback): ' + enc.why_unsupported())
+
+    def _gen_feature_hip(self, x, options=None):
+        """gen_feature of the three adapters: [B,3,H,W] -> [[B,C,H,W]] through the HIP trunk."""
+        self._require_hip_trunk(x)
+        x = x.contiguous().float()
+        enc = self._encoder_hip
+        return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b], options)) for b in range(x.shape[0])])]
 
     def query_rgb(self, features, coord, scale=None, options=None):
         """ciaosr_net.py:113-224 (no bilinear residual); `scale` is the cell tensor."""
@@ -130,21 +148,8 @@ class LocalImplicitSRRDN(LocalImplicitSRNet):
         self._encoder_hip = PackedEncoder(self, 'rdn')
 
     def gen_feature(self, x, options=None):
-        enc = self._encoder_hip
-        if x.is_cuda and enc.supported():
-            x = x.contiguous().float()
-            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b], options)) for b in range(x.shape[0])])]
-        return [self.gen_feature_torch(x)]
-
-    def gen_feature_torch(self, x):
-        """PyTorch-ROCm (MIOpen) trunk, kept for widths the HIP convolution does not cover."""
-        sfe1 = self.sfe1(x)
-        h = self.sfe2(sfe1)
-        local = []
-        for i in range(self.num_blocks):
-            h = self.rdbs[i](h)
-            local.append(h)
-        return self.gff(torch.cat(local, 1)) + sfe1
+        """ciaosr_net.py:321-342 on the HIP trunk (csrc/encoder.hip)."""
+        return self._gen_feature_hip(x, options)
 
 
 class LocalImplicitSREDSR(LocalImplicitSRNet):
@@ -162,20 +167,12 @@ class LocalImplicitSREDSR(LocalImplicitSRNet):
         self._encoder_hip = PackedEncoder(self, 'edsr')
 
     def gen_feature(self, x, options=None):
-        enc = self._encoder_hip
-        if x.is_cuda and enc.supported():
-            x = x.contiguous().float()
-            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(x[b], options)) for b in range(x.shape[0])])]
-        return [self.gen_feature_torch(x)]
-
-    def gen_feature_torch(self, x):
-        f = self.conv_first(x)
-        return self.conv_after_body(self.body(f)) + f
+        """ciaosr_net.py:393-408 on the HIP trunk (csrc/encoder.hip)."""
+        return self._gen_feature_hip(x, options)
 
 
 class LocalImplicitSRSWINIR(LocalImplicitSRNet):
-    """ciaosr_net.py:411-525: SwinIR trunk (HIP: csrc/swinir.hip; PyTorch-ROCm kept as `gen_feature_torch` for
-    configurations the HIP trunk does not cover) + the HIP head.  Leading `window_size` argument."""
+    """ciaosr_net.py:411-525: SwinIR trunk (HIP: csrc/swinir.hip) + the HIP head.  Leading `window_size` argument."""
 
     def __init__(self, window_size, encoder, imnet_q, imnet_k, imnet_v, query_mlp=None, key_mlp=None, value_mlp=None,
                  local_size=2, feat_unfold=True, eval_bsize=None, non_local_attn=True, multi_scale=[2],
@@ -197,12 +194,5 @@ class LocalImplicitSRSWINIR(LocalImplicitSRNet):
         self._encoder_hip = PackedSwinIR(self)
 
     def gen_feature(self, img, options=None):
-        enc = self._encoder_hip
-        if img.is_cuda and enc.supported():
-            img = img.contiguous().float()
-            return [torch.stack([hip_ops.hwc_to_nchw(enc.forward_hwc(img[b], options)) for b in range(img.shape[0])])]
-        return [self.gen_feature_torch(img)]
-
-    def gen_feature_torch(self, img):
-        from .encoders.swinir import swinir_features
-        return swinir_features(self, img)
+        """ciaosr_net.py:475-525 (reflect-pad to a window multiple, trunk, crop) on the HIP trunk (csrc/swinir.hip)."""
+        return self._gen_feature_hip(img, options)

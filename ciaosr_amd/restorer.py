@@ -122,16 +122,18 @@ class CiaoSR(BasicRestorer):
         cell = cell.unsqueeze(0).expand(n, -1, 2)
         return self.generator(patch, coord, cell, test_mode=True, options=self.options(options)), (th, tw)
 
-    def prepare(self, device=None):
-        """Pack every weight for the HIP kernels NOW, on the current stream (idempotent; re-packs only what changed).
+    def prepare(self, options=None):
+        """Pack every weight the call's precision reads NOW, on the current stream (idempotent; re-packs only what changed) --
+        including the 16-bit fragment copies of a 'bf16' / 'f16' call, which are otherwise packed lazily on first use.
         The tile loop runs tiles on several streams: nothing a tile reads may be first built on another tile's stream."""
+        opt = self.options(options)
         gen = self.generator
         head = getattr(gen, '_head', None)
         if head is not None:
-            head.struct()
+            head.struct(opt.half)
         enc = getattr(gen, '_encoder_hip', None)
         if enc is not None and enc.supported():
-            enc.struct()
+            enc.struct(opt.half)
         if getattr(gen, 'non_local_attn', False):
             gen.cs_attn.packed()
 
@@ -170,7 +172,7 @@ class CiaoSR(BasicRestorer):
                     hip_ops.tile_blend(E[bi], Wt[bi], out[bi].contiguous(), hi * sf, wi * sf, th, tw)
             return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
         cur = torch.cuda.current_stream(img_lq.device)
-        self.prepare()
+        self.prepare(options)
         th = tw = round(tile * sf)
         hip_ops.make_coord_cell(th, tw, img_lq.device)              # cached coordinates exist before any side stream reads them
         streams = self._tile_streams(n_streams, img_lq.device)
@@ -277,21 +279,26 @@ class CiaoSR(BasicRestorer):
         side = torch.cuda.Stream()
         side.wait_stream(cur)
         with torch.cuda.stream(side):
+            self.prepare(options)
             for _ in range(max(warmup, 1)):
                 self.restore(static_lq, coord, cell, options)
         cur.wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # capture on the SAME stream the warm-up ran on: hip_ops' scratch is per stream, so every workspace the captured launches
+        # point into already exists (nothing is allocated under capture) ...
+        with torch.cuda.graph(graph, stream=side):
             static_out = self.restore(static_lq, coord, cell, options)
 
-        # the graph holds raw pointers into the scratch buffers, the coordinate tensors and the packed weights that were
-        # live during capture: keep exactly those objects alive with the graph (a later, larger eager call re-allocates
-        # hip_ops' workspaces and a 17th coordinate shape clears its cache -- neither may free what the graph reads).
-        # Weights must not change after capture (a repack would be invisible to the captured launches).
-        keep = (dict(hip_ops._workspaces), dict(hip_ops._coord_cache),
+        # ... and is handed over to this closure: the graph holds raw pointers into the scratch buffers, the coordinate tensors
+        # and the packed weights that were live during capture, so exactly those objects live as long as the graph does and no
+        # longer (take_workspaces removes them from hip_ops' cache: a later eager call on a stream that re-uses the handle gets
+        # fresh scratch, and dropping `run` frees the memory).  Weights must not change after capture (a repack would be
+        # invisible to the captured launches).
+        keep = (hip_ops.take_workspaces(side), dict(hip_ops._coord_cache),
                 [getattr(m, '_packed', None) for m in self.modules()],
-                [(getattr(o, '_st', None), getattr(o, '_keep', None), getattr(o, '_mask_keep', None))
+                [(getattr(o, '_st', None), getattr(o, '_keep', None), getattr(o, '_mask_keep', None),
+                  getattr(o, '_st_f16', None), getattr(o, '_keep_f16', None))
                  for m in self.modules() for o in (getattr(m, '_head', None), getattr(m, '_encoder_hip', None)) if o is not None])
 
         def run(new_lq=None):

@@ -48,7 +48,13 @@ class PackedSwinIR:
         except (AttributeError, IndexError):
             return False
 
-    def struct(self):
+    def why_unsupported(self):
+        n = self.net
+        return (f'SwinIR trunk (embed_dim={n.conv_first.out_channels}, window_size={n.window_size}): the HIP trunk needs 3 input '
+                f'channels, resi_connection="1conv", patch_norm=True, window_size <= 8, head_dim even and <= 32, embed_dim and the '
+                f'MLP width multiples of 4, and the same depth in every group')
+
+    def struct(self, half=None):
         key = tuple((p.data_ptr(), p._version) for p in self._params())
         if self._st is not None and key == self._key:
             return self._st
@@ -103,18 +109,9 @@ class PackedSwinIR:
         """calculate_mask (swinir_net.py:192-213) for the padded map size, shift = window_size // 2."""
         k = (hp, wp, str(dev))
         if k not in self._masks:
+            from .encoders.swinir import shift_mask
             ws = self.net.window_size
-            sh = ws // 2
-            img = torch.zeros(hp, wp)
-            cnt = 0
-            for hs in (slice(0, -ws), slice(-ws, -sh), slice(-sh, None)):
-                for wsl in (slice(0, -ws), slice(-ws, -sh), slice(-sh, None)):
-                    img[hs, wsl] = cnt
-                    cnt += 1
-            mw = img.view(hp // ws, ws, wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
-            am = mw.unsqueeze(1) - mw.unsqueeze(2)
-            am = am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)
-            self._masks[k] = am.contiguous().to(dev)
+            self._masks[k] = shift_mask(hp, wp, ws, ws // 2).contiguous().to(dev)
         return self._masks[k]
 
     @torch.no_grad()

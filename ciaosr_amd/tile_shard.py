@@ -56,8 +56,11 @@ class _Mover:
 
 
 def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_fn, rank, world, group=None,
-                      device=None, gather_to_all=False):
+                      device=None, gather_to_all=False, mark=None):
     """Generic driver (device-agnostic so it can be exercised with gloo on CPU).
+
+    mark(name): optional probe, called at 'last_own_tile' (this rank's last tile has been queued) and, on rank 0,
+    at 'finalized' (every tile blended and normalised) -- bench.py records stream events there to report the exposed tail.
 
     tile_fn(hi, wi, tile)      -> [B, th*tw, 3] tensor (prediction of the LR crop), th = tw = tile*sf
     blend_fn(E, Wt, out, y0, x0, th, tw)  accumulates one tile (reference order)
@@ -76,6 +79,8 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
         for t in range(rank, n, world):
             hi, wi = origins[t]
             mover.send(tile_fn(hi, wi, tile), 0)
+        if mark is not None:
+            mark('last_own_tile')
         mover.drain()
         result = None
     else:
@@ -92,6 +97,8 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
             cur = [(t, mover.recv(shape, t % world, device)) for t in range(t0 + 1, min(t0 + world, n))]
             hi, wi = origins[t0]
             own = tile_fn(hi, wi, tile)
+            if mark is not None and t0 + world >= n:
+                mark('last_own_tile')
             for t, handle in prev:                         # tiles (t0 - R + 1 .. t0 - 1) precede t0 in the reference order
                 blend(t, mover.take(handle, device))
             blend(t0, own)
@@ -99,6 +106,8 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
         for t, handle in prev:
             blend(t, mover.take(handle, device))
         result = finalize_fn(E, Wt)
+        if mark is not None:
+            mark('finalized')
     if gather_to_all and world > 1:
         meta = [tuple(result.shape)] if rank == 0 else [None]
         dist.broadcast_object_list(meta, src=0, group=group)
@@ -113,8 +122,9 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
     return result
 
 
-def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False, options=None):
-    """Tile-sharded counterpart of CiaoSR.clip_test on the GPUs of one node."""
+def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False, options=None, stats=None):
+    """Tile-sharded counterpart of CiaoSR.clip_test on the GPUs of one node.
+    `stats` (optional dict) receives a stream event per probe point of `sharded_clip_test` (bench.py's exposed-tail figure)."""
     from . import hip_ops
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
@@ -159,8 +169,15 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
     def finalize_fn(E, Wt):
         return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(E.shape[0])])
 
+    mark = None
+    if stats is not None and x_norm.is_cuda:
+        def mark(name):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(x_norm.device))
+            stats[name] = ev
+
     return sharded_clip_test(tuple(x_norm.shape), cfg.get('tile'), cfg.get('tile_overlap'), sf, tile_fn, blend_fn,
-                             finalize_fn, rank, world, group, x_norm.device, gather_to_all)
+                             finalize_fn, rank, world, group, x_norm.device, gather_to_all, mark)
 
 
 # ---------------------------------------------------------------------------------------------------------------

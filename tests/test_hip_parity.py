@@ -17,6 +17,8 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4          # working tolerance of the fp32 path
 NORTH_STAR_TOL = 1e-3
+GT30_SEED = 30      # seed of the white noise that places GT' 30 dB from the reference output (realistic-quality PSNR gate)
+RMS_16BIT = {'bf16': 1.35e-3, 'f16': 3e-4}     # rms |build - reference| bounds on the full C3 tile: measured 1.02e-3 (bf16 pairs: 8-bit activations) + 30 %
 
 
 @pytest.fixture(scope='module')
@@ -242,10 +244,11 @@ def test_csattn_bf16_mode_vs_reference(dev, tag, precision):
     scale = want.abs().max().item()
     psnr = 10 * math.log10(scale ** 2 / max((err ** 2).mean().item(), 1e-20))
     print(f'{precision} cs_attn {tag}: max|d| vs reference {err.max().item():.3e} (scale {scale:.3f}), PSNR {psnr:.1f} dB')
+    # measured (round 3): bf16 max 5.7e-3 / 6.7e-3 of the scale, 62.7 / 61.9 dB; f16 6.3e-4 / 6.8e-4, 80.8 / 80.2 dB
     if precision == 'bf16':
-        assert err.max().item() < 0.05 * scale and psnr > 45.0
+        assert err.max().item() < 0.01 * scale and psnr > 58.0
     else:
-        assert err.max().item() < 0.00625 * scale and psnr > 63.0
+        assert err.max().item() < 0.001 * scale and psnr > 76.0
 
 
 # ------------------------------------------------------------------------------------------------
@@ -354,7 +357,9 @@ def test_head_bf16_mode_full_width_vs_reference(dev, name, C, hw, precision):
     scale = ref.abs().max().item()
     psnr = 10 * math.log10(scale ** 2 / max((err ** 2).mean().item(), 1e-20))
     print(f'{precision} head C={C}: max|d| {err.max().item():.3e} (out scale {scale:.3f}), PSNR vs reference {psnr:.1f} dB')
-    assert psnr > (38.0 if precision == 'bf16' else 50.0) and err.max().item() < 0.35 * scale
+    # measured (round 3): bf16 47.7 dB (C = 64) / 48.4 dB (C = 180), max 0.20 / 0.11 of the scale (isolated flips of the 4-way
+    # attention on these logit-std-40 fixtures); f16 62.5 / 63.3 dB, max 0.029 / 0.023 of the scale
+    assert psnr > (44.0 if precision == 'bf16' else 58.0) and err.max().item() < (0.3 if precision == 'bf16' else 0.05) * scale
 
 
 def test_fused_and_staged_head_paths_agree(dev):
@@ -420,54 +425,36 @@ def test_gather_rows_matches_reference_assembly(dev):
     assert torch.equal(inp_k[:, 9 * C + 2:], scale)
 
 
-def test_e2e_bf16_precision_mode_psnr(dev):
-    """Whole restore() with test_cfg.precision='bf16' (bf16 trunk dense layers + bf16 cs_attn contractions + bf16
-    fused head) against the fp32 path: RDN x4 on a 96x96 LR image (9216 LR pixels: every bf16 kernel engages)."""
-    import math
+@pytest.mark.parametrize('precision', ['bf16', 'f16'])
+def test_e2e_test_cfg_precision_selects_the_16bit_kernels_vs_reference(dev, precision):
+    """`test_cfg.precision` (+ `test_cfg.hip_options`) is what a config file uses to select a 16-bit mode: every 16-bit kernel
+    must engage (trunk dense layers, cs_attn contractions, fused head), popping the key restores the fp32 default, and the result
+    is held to the REFERENCE's 48x48 output (tests/golden/e2e_rdn_x4_48.npz) through the north star's PSNR gate."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
-    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32, hip_options=dict(dense_min_tiles=1)))
-    seeded_init_(model, seed=0, gain=1.7)             # network term rms 0.07 next to the bilinear residual, nothing saturates
+    from ciaosr_amd.metrics import psnr_tensors
+    fx = load_golden('e2e_rdn_x4_48')
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32, hip_options=dict(dense_min_tiles=1, csa_composed_min=1)))
+    seeded_init_(model, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=SQRT6)
     model = model.to(dev)
-    lq, _ = synthetic_pair(96, 96, 4)
-    lq = lq.to(dev)
-    ref = model.restore(lq)
-    model.test_cfg['precision'] = 'bf16'
+    lq = _t(fx['lq']).to(dev)
+    model.test_cfg['precision'] = precision
     try:
+        assert model.options().precision == precision and model.options().dense_min_tiles == 1
         with hip_ops.profile():
-            got = model.restore(lq)
+            got = model.restore(lq).cpu()
         prof = hip_ops.profile.results()
     finally:
         model.test_cfg.pop('precision')
-    for tag in ('enc_dense_bf16', 'csa_attn_v_bf16', 'csa_scores_bf16', 'head_kv_fused_bf16', 'head_decode_fused_bf16'):
-        assert tag in prof, (tag, sorted(prof))
+    for tag in ('enc_dense', 'csa_attn_v', 'csa_scores', 'head_kv_fused', 'head_decode_fused'):
+        assert f'{tag}_{precision}' in prof, (tag, sorted(prof))
     assert model.options().precision == 'fp32'
-    err = (got - ref).abs()
-    psnr = 10 * math.log10(1.0 / max((err ** 2).mean().item(), 1e-20))
-    print(f'bf16 e2e: max|d| {err.max().item():.3e}, PSNR vs fp32 output {psnr:.1f} dB')
-    assert psnr > 55.0 and err.max().item() < 0.03          # measured: 64.1 dB, 7.6e-3 (0.9 % rms of the network term)
-
-
-def test_cs_attn_bf16_mode_vs_fp32(dev):
-    """ciaosr_cs_attn_bf16 (scores and P.V' on the bf16 MFMA, gemm_h16.hip; odd map size -> reflect pad, ragged GEMM
-    tiles) against the fp32 path on the same input; PSNR-gated like the other bf16 kernels."""
-    import math
-    from ciaosr_amd import hip_ops
-    from ciaosr_amd.nonlocal_attn import CrossScaleAttention
-    from ciaosr_amd.init_utils import seeded_init_
-    att = CrossScaleAttention(channel=64, scale=[2]).to(dev).eval()
-    seeded_init_(att, seed=31, gain=1.5)
-    x = randn((1, 64, 67, 70), 32).to(dev)             # Hp x Wp = 68 x 70 = 4760 >= 4096: composed tail
-    ref = att(x)
-    with hip_ops.profile():
-        got = att(x, options='bf16')
-    prof = hip_ops.profile.results()
-    assert 'csa_attn_v_bf16' in prof and 'csa_scores_bf16' in prof, sorted(prof)
-    err = (got - ref).abs()
-    scale = ref.abs().max().item()
-    psnr = 10 * math.log10(scale ** 2 / max((err ** 2).mean().item(), 1e-20))
-    print(f'bf16 cs_attn: max|d| {err.max().item():.3e} (scale {scale:.3f}), PSNR vs fp32 {psnr:.1f} dB')
-    assert err.max().item() < 0.05 * scale and psnr > 45.0
+    ref = _t(fx['out'])
+    _, gt = synthetic_pair(48, 48, 4)
+    d_psnr = abs(psnr_tensors(got, gt, crop_border=4) - psnr_tensors(ref, gt, crop_border=4))
+    rms = (got - ref).double().pow(2).mean().sqrt().item()
+    print(f'test_cfg.precision={precision}: rms|d| vs reference {rms:.3e}, max {(got - ref).abs().max().item():.3e}, PSNR delta vs GT {d_psnr:.5f} dB')
+    assert d_psnr <= 0.01, d_psnr
 
 
 def test_staged_local_attention_kernel(dev):
@@ -587,9 +574,41 @@ def test_encoder_features_vs_oracle(dev, kind, hw):
     got = gen.gen_feature(x.to(dev))[0].cpu()
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() < 2e-5 * max(scale, 1.0) * 10, ((got - want).abs().max().item(), scale)
-    # the PyTorch-ROCm trunk must agree too (it serves widths the HIP convolution does not cover)
-    got_t = gen.gen_feature_torch(x.to(dev)).cpu()
+    # the PyTorch-ROCm evaluation of the same modules (tests/torch_trunks.py, a checker) must agree too
+    from tests import torch_trunks
+    with torch.no_grad():
+        got_t = (torch_trunks.rdn_features if kind == 'rdn' else torch_trunks.edsr_features)(gen, x.to(dev)).cpu()
     assert (got_t - want).abs().max().item() < 2e-4 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize('kind,mid,hw', [('edsr', 16, (19, 24)), ('edsr', 40, (33, 20)), ('rdn', 16, (21, 30)), ('rdn', 48, (48, 48))])
+def test_narrow_trunk_widths_run_on_the_hip_trunk(dev, kind, mid, hw):
+    """Widths that are not multiples of 32 (the tiny fixtures' 8 / 16-channel trunks, mid_channels = 48, ...) run on the HIP trunk
+    with zero-padded weights -- there is no PyTorch fallback -- and match the CPU oracle's trunk."""
+    from ciaosr_amd import CiaoSR, LocalImplicitSREDSR, LocalImplicitSRRDN, hip_ops
+    from ciaosr_amd.init_utils import seeded_init_
+    from oracle import ciaosr_oracle as orc
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[32, 32])
+    if kind == 'edsr':
+        gen = dict(type=LocalImplicitSREDSR, encoder=dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=mid, num_blocks=3),
+                   imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=None)
+    else:
+        gen = dict(type=LocalImplicitSRRDN, encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=mid, num_blocks=3,
+                                                          upscale_factor=4, num_layers=4, channel_growth=mid),
+                   imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=None)
+    model = CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), test_cfg=dict(scale=2)).eval()
+    seeded_init_(model, seed=5, gain=1.5)
+    params = {k[len('generator.'):]: v.detach().clone() for k, v in model.state_dict().items()}
+    x = randn((1, 3) + hw, 78) * 0.3
+    want = orc.encoder_features(x, params)
+    g = model.generator.to(dev)
+    assert g._encoder_hip.supported() and g._encoder_hip.width() == (mid, (mid + 31) // 32 * 32)
+    with hip_ops.profile():
+        got = g.gen_feature(x.to(dev))[0].cpu()
+    assert any(t.startswith('enc_') for t in hip_ops.profile.results()), 'HIP trunk did not run'
+    assert got.shape == want.shape == (1, mid) + hw
+    scale = max(want.abs().max().item(), 1.0)
+    assert (got - want).abs().max().item() < 1e-4 * scale, ((got - want).abs().max().item(), scale)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -689,14 +708,26 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     psnr_build = psnr_tensors(out, gt, crop_border=4)
     d_psnr = abs(psnr_build - float(fx['psnr_ref_gt']))
     mean_err = abs(out.double().mean().item() - float(fx['out_mean']))
-    print(f'tile192 {precision}: max|d| {errs}, PSNR(build,GT) {psnr_build:.4f} vs ref {float(fx["psnr_ref_gt"]):.4f} '
-          f'(delta {d_psnr:.5f} dB), |mean delta| {mean_err:.2e}')
+    # (a) rms of the error against the reference over the stored every-4th-pixel grid, and (b) the same gate at a REALISTIC quality
+    # level: the synthetic GT sits 15 dB from the random-weight output, where 0.01 dB admits an rms error of 8e-3; a trained model
+    # sits near 30 dB, where it admits 1.5e-3.  GT' = reference output + seeded white noise at exactly 30 dB.
+    ref_s4 = _t(fx['out_s4'])
+    got_s4 = out[..., ::4, ::4]
+    rms = (got_s4 - ref_s4).double().pow(2).mean().sqrt().item()
+    noise = torch.randn(ref_s4.shape, generator=torch.Generator().manual_seed(GT30_SEED), dtype=torch.float64) * 10 ** (-30 / 20)
+    gt30 = ref_s4.double() + noise
+    psnr30 = lambda a: -10 * math.log10((a.double() - gt30).pow(2).mean().item())
+    d_psnr30 = abs(psnr30(got_s4) - psnr30(ref_s4))
+    print(f'tile192 {precision}: max|d| {errs}, rms|d| {rms:.3e}, PSNR(build,GT) {psnr_build:.4f} vs ref {float(fx["psnr_ref_gt"]):.4f} '
+          f'(delta {d_psnr:.5f} dB), at 30 dB: PSNR(ref,GT\') {psnr30(ref_s4):.3f}, delta {d_psnr30:.5f} dB, |mean delta| {mean_err:.2e}')
     if precision == 'fp32':
-        assert d_psnr <= 0.01, d_psnr
+        assert d_psnr <= 0.01 and d_psnr30 <= 0.001, (d_psnr, d_psnr30)
         assert max(errs.values()) < NORTH_STAR_TOL, errs
-        assert mean_err < 1e-5
+        assert mean_err < 1e-5 and rms < 1e-5, (mean_err, rms)
     elif precision in ('bf16', 'f16'):
         assert d_psnr <= 0.01, d_psnr            # the north-star gate; measured 0.00014 dB (bf16 pairs)
+        assert d_psnr30 <= 0.01, d_psnr30        # ... and at a trained model's quality level
+        assert rms <= RMS_16BIT[precision], rms
         assert max(errs.values()) < 0.15, errs
     else:
         assert 0.01 < d_psnr <= 0.08, d_psnr     # measured 0.042 dB: single-bf16 weights do NOT meet the gate (see docstring)
@@ -769,6 +800,29 @@ def test_tile_batch_is_bitwise_the_one_tile_result(dev):
             model.test_cfg['tile_batch'] = nb
             got = model.restore(lq)
             assert torch.equal(one, got), (precision, nb, (one - got).abs().max().item())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'f16'])
+def test_encoder_batch_beyond_32bit_offsets_runs_as_sub_batches(dev, precision):
+    """A tile batch whose block buffers exceed the 32-bit buffer offsets of the halo-resident dense kernels (default tile_batch = 8 with
+    tiles of ~360 pixels and more: 8 x 368 x 368 x 1024 channels x 4 B = 4.4 GB) must run -- as sub-batches that fit -- and every
+    feature map must stay bitwise the single-image result (round-2 regression: CIAOSR_ERR_ARG)."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_init_
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=368, tile_overlap=32))
+    seeded_init_(model, seed=0, gain=1.0)
+    enc = model.generator.to(dev)._encoder_hip
+    opt = hip_ops.Options(precision)
+    x = (randn((8, 3, 368, 368), 5) * 0.25).to(dev)
+    with hip_ops.profile():
+        feats = enc.forward_hwc_batch(x, opt)
+    assert ('enc_dense_gather' if precision == 'fp32' else 'enc_dense_f16') in hip_ops.profile.results()
+    assert feats.shape == (8, 368, 368, 64) and bool(torch.isfinite(feats).all())
+    for i in (0, 6, 7):
+        assert torch.equal(feats[i], enc.forward_hwc(x[i], opt)), i
+    del feats
+    hip_ops.release_workspaces()
+    torch.cuda.empty_cache()
 
 
 def test_c3_full_image_tiled_restore_properties(dev):
@@ -878,6 +932,61 @@ def test_swinir_e2e_vs_golden(dev, precision):
     if precision == 'fp32':
         assert err < NORTH_STAR_TOL, err
     assert d_psnr <= 0.01, d_psnr
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'f16'])
+def test_swinir_c5_at_its_own_size_vs_reference(dev, precision):
+    """BASELINE config 5 at ITS size: SwinIR-CiaoSR x3.3, LR 48x48 -> 158x158 (Q = 24 964, C = 180), against the reference's
+    CiaoSR.forward_test output and the reference trunk's features (tests/golden/swinir_c5_48.npz).  48 = 6 windows of 8, so the
+    shifted blocks use their own `attn_mask` buffers (swinir_net.py:233-236) -- the 24x24 fixture takes `calculate_mask`.
+      fp32: trunk features <= 2e-4 * scale, output |delta| <= 1e-3, PSNR delta vs GT <= 0.01 dB
+      bf16 / f16: PSNR delta vs GT <= 0.01 dB at the fixture's 14.5 dB AND against GT' = reference + 30 dB noise."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    from ciaosr_amd.metrics import psnr_tensors
+    from tests.test_host_logic import _swinir_ciaosr
+    fx = load_golden('swinir_c5_48')
+    model = _swinir_ciaosr(dict(scale=3.3))
+    assert seeded_init_(model, seed=int(fx['weight_seed']), gain=1.0, head_gain=SQRT6) == str(fx['sha'])
+    model = model.to(dev)
+    ht, wt = [int(v) for v in fx['target']]
+    assert (ht, wt) == (158, 158)
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    lq = _t(fx['lq']).to(dev)
+    if precision == 'fp32':
+        feat = model.generator.gen_feature(model.normalize(lq))[0][0].cpu()
+        want = _t(fx['feat_s2'])
+        ferr = (feat[:, ::2, ::2] - want).abs().max().item()
+        print(f'C5 48x48 trunk: max|d| vs reference features {ferr:.3e} (scale {want.abs().max().item():.3f})')
+        assert ferr < 2e-4 * max(want.abs().max().item(), 1.0), ferr
+    model.test_cfg['precision'] = precision
+    with hip_ops.profile():
+        out = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)['output']
+    prof = hip_ops.profile.results()
+    assert 'swin_window_attention' in prof
+    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_bf16', 'f16': 'head_kv_fused_f16'}[precision] in prof
+    ref = _t(fx['out'])
+    err = (out - ref).abs().max().item()
+    rms = (out - ref).double().pow(2).mean().sqrt().item()
+    _, gt = synthetic_pair(48, 48, 3.3)
+    psnr_ref = psnr_tensors(ref, gt, crop_border=3)
+    assert abs(psnr_ref - float(fx['psnr_ref_gt'])) < 1e-6
+    d_psnr = abs(psnr_tensors(out, gt, crop_border=3) - psnr_ref)
+    gt30 = ref.double() + torch.randn(ref.shape, generator=torch.Generator().manual_seed(GT30_SEED), dtype=torch.float64) * 10 ** (-30 / 20)
+    psnr30 = lambda a: -10 * math.log10((a.double() - gt30).pow(2).mean().item())
+    d_psnr30 = abs(psnr30(out) - psnr30(ref))
+    print(f'C5 48x48 {precision}: max|d| {err:.3e}, rms {rms:.3e}, PSNR delta vs GT {d_psnr:.5f} dB, at 30 dB {d_psnr30:.5f} dB')
+    if precision == 'fp32':
+        assert err < NORTH_STAR_TOL, err
+    assert d_psnr <= 0.01, d_psnr
+    if precision == 'bf16':
+        # bf16 mode (8-bit ACTIVATIONS; weights as pairs) does NOT meet the gate at 30 dB on this ill-conditioned fixture (head gain
+        # sqrt(6): logit std ~40, so 2^-9 relative activation noise moves the 4-way attention): rms 3.6e-3, measured 0.060 dB.
+        # f16 (11-bit activations, same MFMA rate) does: 0.0007 dB.  f16 is the 16-bit mode to use; the bf16 bound is what it delivers.
+        assert d_psnr30 <= 0.09, d_psnr30
+    else:
+        assert d_psnr30 <= 0.01, d_psnr30
 
 
 def test_tools_test_cli_end_to_end(dev, tmp_path, capsys):
@@ -1128,8 +1237,9 @@ def test_swinir_trunk_hip_vs_torch(dev, hw):
     gen = model.generator.to(dev).eval()
     assert gen._encoder_hip.supported()
     x = (randn((1, 3) + hw, 91) * 0.3).to(dev)
+    from tests.torch_trunks import swinir_features
     with torch.no_grad():
-        want = gen.gen_feature_torch(x)
+        want = swinir_features(gen, x)           # checker; pinned to the reference's features by tests/test_host_logic.py
     with hip_ops.profile():
         got = gen.gen_feature(x)[0]
     assert 'swin_window_attention' in hip_ops.profile.results(), 'HIP SwinIR trunk did not run'

@@ -196,8 +196,9 @@ def _swinir_ciaosr(test_cfg):
 
 
 def test_swinir_names_and_trunk_match_reference():
-    """SwinIR-CiaoSR: state_dict names/shapes/order equal the reference's; the PyTorch trunk (gen_feature with
-    reflect padding to the window multiple) reproduces the reference's features on CPU."""
+    """SwinIR-CiaoSR: state_dict names/shapes/order equal the reference's; the PyTorch CHECKER of the trunk
+    (tests/torch_trunks.py: reflect padding to the window multiple, 36 Swin blocks, crop) reproduces the reference's features
+    on CPU -- it is what the HIP trunk is compared with on the GPU box.  The product itself has no CPU / PyTorch trunk."""
     import numpy as np
     from ciaosr_amd.init_utils import seeded_init_
     from tests.helpers import load_golden, randn
@@ -208,10 +209,14 @@ def test_swinir_names_and_trunk_match_reference():
     assert list(mine) == list(names) and mine == names
     assert seeded_init_(m, seed=int(fx['weight_seed']), gain=1.0, head_gain=6 ** 0.5) == str(fx['sha'])
     x = randn((1, 3, 20, 27), fx['x_seed']) * 0.3
+    from tests.torch_trunks import swinir_features
+    from ciaosr_amd._lib import CiaoSRHipError
     with torch.no_grad():
-        feat = m.generator.gen_feature(x)[0]
+        feat = swinir_features(m.generator, x)
     assert feat.shape == (1, 180, 20, 27)
     assert (feat[0] - torch.from_numpy(fx['feat'])).abs().max() < 2e-5
+    with pytest.raises(CiaoSRHipError):
+        m.generator.gen_feature(x)
 
 
 @pytest.mark.parametrize('kind', ['rdn', 'edsr', 'swinir'])

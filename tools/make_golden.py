@@ -367,9 +367,46 @@ def gen_swinir(ref):
          target=np.array([ht, wt]))
 
 
+def gen_swinir48(ref):
+    """BASELINE config 5 at ITS OWN size: SwinIR-CiaoSR x3.3, LR 48x48 -> 158x158 (Q = 24 964, C = 180) through the reference's
+    CiaoSR.forward_test (whole-image path, ciaosr.py:158-169), plus the reference trunk's feature map of the same input
+    (ciaosr_net.py:475-525; every 2nd pixel stored).  48 = 6 windows of 8: the blocks' own attn_mask buffers are used
+    (input_resolution == x_size, swinir_net.py:233-236), unlike the 24x24 fixture, which takes calculate_mask."""
+    import torch.nn as nn
+    from ciaosr_amd.metrics import psnr_tensors
+    from mmedited.models.backbones.sr_backbones.swinir_net import SwinIR
+    orig_cuda = nn.Module.cuda
+    nn.Module.cuda = lambda self, device=None: self          # swinir_net.py:684,723,725 hard-code .cuda()
+    try:
+        q, k, v = mlp_cfg((256,) * 4)
+        gen = dict(type=ref.LocalImplicitSRSWINIR, window_size=8,
+                   encoder=dict(type=SwinIR, upscale=4, in_chans=3, img_size=48, window_size=8, img_range=1.,
+                                depths=[6] * 6, embed_dim=180, num_heads=[6] * 6, mlp_ratio=2,
+                                upsampler='pixelshuffle', resi_connection='1conv'),
+                   imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+        model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040),
+                           rgb_std=(1., 1., 1.), test_cfg=ref.ConfigDict(scale=3.3)).eval()
+    finally:
+        nn.Module.cuda = orig_cuda
+    sha = seeded_init_(model, seed=2, gain=1.0, head_gain=SQRT6)
+    lq, gt = synthetic_pair(48, 48, 3.3)
+    coord, cell, (ht, wt) = coords_for(48, 48, 3.3)
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        feat = model.generator.gen_feature(lq - torch.tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1))[0]
+        res = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+    out = res['output']
+    psnr_ref = psnr_tensors(out, gt, crop_border=3)
+    print(f'  swinir_c5_48: {time.time() - t0:.0f} s, feat std {feat.std():.3f}, out {tuple(out.shape)} range [{out.min():.3f},{out.max():.3f}] '
+          f'std {out.std():.3f} frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f} PSNR(ref,GT) {psnr_ref:.4f}')
+    save('swinir_c5_48', feat_s2=feat[0][:, ::2, ::2], lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(2),
+         target=np.array([ht, wt]), psnr_ref_gt=np.array(psnr_ref, dtype=np.float64))
+
+
 ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, tiny_act=gen_tiny_head_act, csattn_scales=gen_csattn_scales, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
-           head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir)
+           head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir, swinir48=gen_swinir48)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

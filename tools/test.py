@@ -12,10 +12,42 @@ import argparse
 import os
 import sys
 
-import torch
-
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+
+
+def self_launch(argv):
+    """`tools/test.py CONFIG CKPT --launcher pytorch --gpus N` from a plain shell (no WORLD_SIZE): start the N ranks as ONE
+    child `python -m torch.distributed.run ... tools/test.py <same args>` and exit with its return code -- what the reference's
+    tools/dist_test.sh:8-10 does with torch.distributed.launch.  Runs before torch is imported, so this parent never
+    initialises the GPU and nothing is exec'ed."""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument('--launcher', default='none')
+    ap.add_argument('--gpus', type=int, default=0)
+    a = ap.parse_known_args(argv)[0]
+    if a.launcher != 'pytorch' or 'WORLD_SIZE' in os.environ:
+        return
+    n = a.gpus
+    if n <= 0:
+        import torch                              # device_count() does not initialise the GPU on this image
+        n = max(torch.cuda.device_count(), 1)
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == '__main__':
+    self_launch(sys.argv[1:])
+
+import torch                                      # noqa: E402 - after self_launch on purpose
 
 
 def parse_args(argv=None):
@@ -30,6 +62,7 @@ def parse_args(argv=None):
     p.add_argument('--tmpdir')
     p.add_argument('--launcher', choices=['none', 'pytorch', 'slurm', 'mpi'], default='none')
     p.add_argument('--local_rank', type=int, default=0)
+    p.add_argument('--gpus', type=int, default=0, help='with --launcher pytorch from a plain shell: ranks to start (default: every visible GPU)')
     p.add_argument('--lq-folder', default=None, help='override cfg.data.test.lq_folder')
     p.add_argument('--gt-folder', default=None, help='override cfg.data.test.gt_folder')
     return p.parse_args(argv)
@@ -63,8 +96,10 @@ def main(argv=None):
     rank, world = 0, 1
     if distributed:
         rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', args.local_rank)))
-        dist.init_process_group(cfg.get('dist_params', {}).get('backend', 'nccl'))
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', args.local_rank)) % max(torch.cuda.device_count(), 1))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # CIAOSR_DIST_BACKEND=gloo: rehearse the N-rank path on fewer GPUs than ranks (host-staged copies)
+        dist.init_process_group(os.environ.get('CIAOSR_DIST_BACKEND') or cfg.get('dist_params', {}).get('backend', 'nccl'))
     if args.seed is not None:
         torch.manual_seed(args.seed)
     dev = torch.device('cuda', torch.cuda.current_device())

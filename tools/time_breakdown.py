@@ -35,7 +35,6 @@ def timeit(name, fn, n=20):
 feat = g._encoder_hip.forward_hwc(x[0])
 timeit('normalize', lambda: model.normalize(lq))
 timeit('encoder_hip', lambda: g._encoder_hip.forward_hwc(x[0]))
-timeit('encoder_torch(MIOpen)', lambda: g.gen_feature_torch(x))
 timeit('head', lambda: g._head.forward(None, x[0], coord, cell, 30000, feature_hwc=feat))
 timeit('generator.forward', lambda: g(x, coord.unsqueeze(0), cell.unsqueeze(0), test_mode=True))
 timeit('restore (full step)', lambda: model.restore(lq))
