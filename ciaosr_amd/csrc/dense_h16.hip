@@ -25,6 +25,8 @@
 //   * the K-slices are summed through LDS once per layer (fixed order: deterministic) in the epilogue.
 // Swapped operands (weights = A, activations = B): a lane owns one pixel and 4x4 consecutive channels.
 
+#include <cstdlib>
+
 #include "h16_util.h"
 #include "ops.h"
 
@@ -259,6 +261,214 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same layer with TWO workgroups per CU (one 16-bit weight per product: f16, or bf16-single).
+//
+// The kernel above holds one workgroup per CU (142 VGPR + 160 accumulators): its per-workgroup fixed part -- first weights and halo
+// patch from L2 / HBM, the K-slice reduction through LDS, the stores (8.6 us of a 19 us average launch) -- and every exposed
+// latency inside the group loop (SQ counters: matrix pipe 21 % busy, 39 % of the wave cycles parked in s_waitcnt / barriers)
+// stall the matrix pipe directly.  Here the registers beside the 160 accumulators are cut to < 96, so that a second, independent
+// workgroup shares the CU and fills those holes:
+//   * the halo patch goes from memory STRAIGHT to LDS (`buffer_load_dwordx4 ... lds`, 25 x 1 KB pieces): no 28 staging + 14
+//     address registers.  A DMA writes lane-contiguous bytes, so the patch is an UNPADDED [14][14] array of 128-B pixels whose eight
+//     16-B channel chunks are XOR-swizzled with g(py, px) = ((px >> 1) - 2 py) & 7 -- applied to the SOURCE address of the DMA and
+//     to the ds_read_b128 address alike.  Brute force over every (tap, pixel tile, K slice, 16-lane group of ds_read_b128): the 16
+//     lanes of a group always hit 16 distinct bank quads (the padded 2240-B pitch of the kernel above is not DMA-compatible);
+//     out-of-image halo pixels are out-of-range buffer offsets, which the DMA writes as zeros;
+//   * activation fragments single-buffered: tile r of the next tap is read right behind the two MFMAs that use tile r of this
+//     one; weight ring 3 taps (requested 2 ahead; the partner workgroup covers the rest of the L2 latency);
+//   * the K-slice reduction runs in four 40-KB passes in the LDS the NEXT patch does not occupy, so the next image's first patch
+//     can land during the epilogue (66 560 B of LDS per workgroup: two per CU);
+//   * grid.y = image slices: with a batch of tiles every CU gets two workgroups that walk different images.
+// Per image the MACs and their order are those of the kernel above (and of a single-image launch): bitwise the same result.
+constexpr int D2_PATCH = 25 * 1024;              // 1568 chunks of 16 B, rounded up to whole 1-KB DMA pieces
+constexpr int D2_FREE = 15360;
+constexpr int D2_P1 = D2_PATCH + D2_FREE;        // [P0][free][P1]
+constexpr size_t kDense2Lds = 2 * D2_PATCH + D2_FREE;      // 66 560 B
+constexpr int D2_RED = 4 * DMT * 2 * 64 * 16;    // one reduction pass: 4 waves x 5 tiles x 2 register quads x 64 lanes x 16 B = 40 960
+static_assert(D2_RED <= D2_PATCH + D2_FREE, "reduction scratch must fit beside the next patch");
+
+__global__ __launch_bounds__(256, 2) void dense_h16_dma_kernel(DenseH16P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    const int ty0 = (blockIdx.x / p.tiles_x) * DT, tx0 = (blockIdx.x % p.tiles_x) * DT;
+    // images of this workgroup: slice blockIdx.y of gridDim.y
+    const int per = (p.n_img + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int img0 = (int)blockIdx.y * per, img1 = img0 + per < p.n_img ? img0 + per : p.n_img;
+    if (img0 >= img1) return;
+    const unsigned img_bytes = (unsigned)((size_t)p.H * p.W * p.ldxb * 2);
+    const i32x4 desc = {(int)(unsigned)(size_t)p.xb, (int)(((size_t)p.xb >> 32) & 0xFFFFu), (int)p.xb_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+
+    // DMA pieces of this wave: piece i = w + 4 s (s < 7, i < 25) fills LDS bytes [1024 i, 1024 i + 1024) of a patch buffer; lane ->
+    // LDS chunk c = 64 i + lane = (pixel c / 8, slot c % 8), which holds the pixel's channel chunk j = slot ^ g(py, px)
+    constexpr int D2S = 7;
+    unsigned goff[D2S];
+#pragma unroll
+    for (int s = 0; s < D2S; ++s) {
+        const int c = 64 * (w + 4 * s) + lane;
+        const int px_ = c >> 3, slot = c & 7;
+        const int py = px_ / DP, pxx = px_ - py * DP;
+        const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
+        const bool ok = px_ < DP * DP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int j = slot ^ (((pxx >> 1) - 2 * py) & 7);
+        goff[s] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)p.ldxb * 2u + (unsigned)j * 16u) : kOobD;
+    }
+    const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
+    auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
+    auto dma_patch = [&](int buf, int g, int img) {
+        const unsigned add = (unsigned)phys(g) * 128u + (unsigned)img * img_bytes;
+#pragma unroll
+        for (int s = 0; s < D2S; ++s) {
+            if (w + 4 * s < 25) {                     // wave-uniform
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf ? D2_P1 : 0) + 1024u * (unsigned)(w + 4 * s));
+                const unsigned voff = goff[s] == kOobD ? kOobD : goff[s] + add;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(dst), "s"(desc) : "memory");
+            }
+        }
+    };
+
+    // B operand (activations): centre pixel of lane li in each of the 5 pixel tiles.  pbase = byte offset of the pixel, hpk = the three
+    // swizzle keys (px >> 1) - 2 py (+ the dx = -1 / 0 / +1 corrections), 4 bits each
+    int pbase[DMT], hpk[DMT];
+#pragma unroll
+    for (int r = 0; r < DMT; ++r) {
+        int idx = 32 * r + li;
+        idx = idx < DT * DT ? idx : DT * DT - 1;
+        const int y = idx / DT, x = idx - y * DT;
+        const int py = y + 1, pxx = x + 1;
+        pbase[r] = (py * DP + pxx) * 128;
+        const int h = (pxx >> 1) - 2 * py, par = pxx & 1;
+        hpk[r] = ((h + par - 1) & 7) | ((h & 7) << 4) | (((h + par) & 7) << 8);
+    }
+    const int jch = 2 * w + lh;                  // this lane's 16-B channel chunk of a pixel: the wave's K slice, this half's 8 channels
+    auto b_addr = [&](int r, int tap) -> int {   // tap = 3 (dy + 1) + (dx + 1), compile-time
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int key = ((hpk[r] >> (4 * (dx + 1))) - 2 * dy) & 7;
+        return pbase[r] + (dy * DP + dx) * 128 + ((jch ^ key) << 4);
+    };
+    const uint4* wl = p.wf + lane;
+    const int kpt = 4 * p.groups;
+    auto frag = [&](int nt, int g, int tap) -> uint4 { return wl[(size_t)(nt * p.nks + tap * kpt + 4 * phys(g) + w) * 64]; };
+
+    f32x16 acc[2][DMT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < DMT; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+    };
+    zero_acc();
+
+    constexpr int PF = 2, RING = 3;              // weights requested PF taps ahead, ring indexed by tap % RING (9 % 3 == 0)
+    uint4 wq[RING][2];
+#pragma unroll
+    for (int tp = 0; tp < PF; ++tp) { wq[tp][0] = frag(0, 0, tp); wq[tp][1] = frag(1, 0, tp); }
+    dma_patch(0, 0, img0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int G = p.groups;
+    uint4 b[DMT];
+    int pbuf = 0;
+#pragma unroll 1
+    for (int img = img0; img < img1; ++img) {
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const bool last_g = g + 1 == G;
+        const bool more = !last_g || img + 1 < img1;
+        const int ng_next = last_g ? 0 : g + 1, nimg_next = last_g ? img + 1 : img;
+        const unsigned char* pb = lds + (pbuf ? D2_P1 : 0);
+        // keep the 45 (tile, tap) read addresses out of registers: without this hipcc hoists all of them out of the group loop
+#pragma unroll
+        for (int r = 0; r < DMT; ++r) asm volatile("" : "+v"(pbase[r]), "+v"(hpk[r]));
+#pragma unroll
+        for (int r = 0; r < DMT; ++r) b[r] = *reinterpret_cast<const uint4*>(pb + b_addr(r, 0));
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            {   // weights PF taps ahead
+                int ng = g, ntap = tap + PF;
+                bool have = true;
+                if (ntap >= 9) { ntap -= 9; ng = ng_next; have = more; }
+                if (have) { wq[(tap + PF) % RING][0] = frag(0, ng, ntap); wq[(tap + PF) % RING][1] = frag(1, ng, ntap); }
+            }
+            if (more && tap == 1) dma_patch(pbuf ^ 1, ng_next, nimg_next);      // the other buffer: last read before the previous barrier
+#pragma unroll
+            for (int r = 0; r < DMT; ++r) {
+                acc[0][r] = mfma_h16<kF16>(wq[tap % RING][0], b[r], acc[0][r]);
+                acc[1][r] = mfma_h16<kF16>(wq[tap % RING][1], b[r], acc[1][r]);
+                if (tap + 1 < 9) b[r] = *reinterpret_cast<const uint4*>(pb + b_addr(r, tap + 1));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!last_g) {
+            // the next patch (DMAs of tap 1) has landed once at most the 2 PF weight loads issued after it are outstanding
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * PF) : "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            pbuf ^= 1;
+        }
+    }
+    // K-slice reduction + epilogue of this image in four passes (output half nt, register-quad pair qh) through the LDS that the NEXT
+    // patch (buffer pbuf ^ 1, possibly still landing) does not occupy.  red[w][r][q2][lane] = accumulator registers 4 (2 qh + q2) .. + 3
+    {
+        const size_t ipix = (size_t)img * p.H * p.W;
+        float4* red = reinterpret_cast<float4*>(lds + (pbuf ? (int)kDense2Lds - D2_RED : 0));
+        __syncthreads();                          // every wave is done reading the current patch
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int nt = pass >> 1, qh = pass & 1;
+#pragma unroll
+            for (int r = 0; r < DMT; ++r)
+#pragma unroll
+                for (int q2 = 0; q2 < 2; ++q2) {
+                    const int q = 2 * qh + q2;
+                    red[((w * DMT + r) * 2 + q2) * 64 + lane] =
+                        make_float4(acc[nt][r][4 * q], acc[nt][r][4 * q + 1], acc[nt][r][4 * q + 2], acc[nt][r][4 * q + 3]);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int unit = t + 256 * u;             // (r, q2, lane), 640 units
+                if (unit < DMT * 2 * 64) {
+                    const int ul = unit & 63, q2 = (unit >> 6) & 1, r = unit >> 7;
+                    float4 v = red[((0 * DMT + r) * 2 + q2) * 64 + ul];
+#pragma unroll
+                    for (int ww = 1; ww < 4; ++ww) {
+                        const float4 o = red[((ww * DMT + r) * 2 + q2) * 64 + ul];
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    const int idx = 32 * r + (ul & 31);
+                    const int y = ty0 + idx / DT, x = tx0 + idx % DT;
+                    if (idx < DT * DT && y < p.H && x < p.W) {
+                        const int co = 32 * nt + 8 * (2 * qh + q2) + 4 * (ul >> 5);
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + co);
+                        v.x = fmaxf(v.x + bb.x, 0.f); v.y = fmaxf(v.y + bb.y, 0.f);
+                        v.z = fmaxf(v.z + bb.z, 0.f); v.w = fmaxf(v.w + bb.w, 0.f);
+                        const size_t pix = ipix + (size_t)y * p.W + x;
+                        if (p.x) *reinterpret_cast<float4*>(p.x + pix * p.ldx + p.col_out + co) = v;
+                        *reinterpret_cast<uint2*>(p.xb_out + pix * p.ldxb + p.col_out + co) = pack_h16x4<kF16>(v.x, v.y, v.z, v.w);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (img + 1 < img1) {                         // next image: its first patch (requested during the last group) is in buffer pbuf ^ 1
+        zero_acc();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        pbuf ^= 1;
+    }
+    }
+}
+
 // fp32 columns [col, col+64) of X -> the same columns of the bf16 copy
 __global__ void cast_group_h16_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ Xb, int ldxb, int col,
                                        long HW) {
@@ -299,11 +509,17 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
     p.x = X; p.ldx = ldx; p.xb_out = Xb; p.col_out = 64 * (l + 1);
     CIAOSR_BIG_LDS(dense_h16_kernel<true>, kDenseLds);
     CIAOSR_BIG_LDS(dense_h16_kernel<false>, kDenseLds);
+    CIAOSR_BIG_LDS(dense_h16_dma_kernel, kDense2Lds);
     ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
+    static const int variant = getenv("CIAOSR_DENSE_V") ? atoi(getenv("CIAOSR_DENSE_V")) : 2;     // developer A/B: 1 = the round-2 kernel
     if (p.wf_lo)
         hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
-    else
+    else if (variant == 1 || n_img < 2)      // one image = 256 workgroups on 256 CUs: nothing to pair up, the deeper pipeline of the first kernel wins (2.74 vs 2.96 ms)
         hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
+    else {   // two workgroups per CU; a batch is cut into image slices so that both slots of every CU are filled
+        static const int slices = getenv("CIAOSR_DENSE_SLICES") ? atoi(getenv("CIAOSR_DENSE_SLICES")) : 2;
+        hipLaunchKernelGGL(dense_h16_dma_kernel, dim3(dense_h16_tiles(H, W), n_img < slices ? n_img : slices), dim3(256), kDense2Lds, s, p);
+    }
     return launch_status("dense" CIAOSR_H16_SUFFIX);
 }
 

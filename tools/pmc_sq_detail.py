@@ -1,4 +1,4 @@
-"""Per-kernel SQ stall / instruction-mix summary from the two --pmc passes of tools/pmc_bf16.sh.
+"""Per-kernel SQ stall / instruction-mix summary from the two --pmc passes of tools/pmc_sq.sh.
    python tools/pmc_sq_detail.py gpurun_out/pmc_bf16 [name-filter]"""
 import collections, csv, glob, sys
 root = sys.argv[1]
