@@ -263,9 +263,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
-                         'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation')
+                         'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
+                         'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product): the fp32-tolerance fast mode')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
@@ -435,7 +436,8 @@ def main():
                     roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
                                 frac=round(ach / peak, 4), traffic=None)
                     roof['algorithmic_flop_per_launch'] = round(amount / launches_per_step)
-                    if kind == 'flop16' and args.precision == 'bf16' and not args.bf16_single and dominant in ('head_kv_fused_bf16', 'head_decode_fused_bf16', 'enc_dense_bf16'):
+                    if kind == 'flop16' and ((args.precision == 'bf16' and not args.bf16_single) or args.precision == 'f16-pairs') and \
+                            dominant.rsplit('_', 1)[0] in ('head_kv_fused', 'head_decode_fused', 'enc_dense'):
                         # hi + lo weight pairs: the kernel issues two MFMAs per algorithmic product
                         roof['executed_mfma_flop_per_launch'] = 2 * roof['algorithmic_flop_per_launch']
                         roof['mfma_pipe_frac'] = round(2 * ach / peak, 4)
@@ -495,7 +497,8 @@ def main():
             'scaling': 'strong', 'vs_baseline': None,
             'dtype': 'f32' if args.precision == 'fp32' else (
                 'f16 (IEEE half) MFMA inputs, saturating conversions, fp32 accumulate, in the head, the dense layers and the cs_attn contractions'
-                if args.precision == 'f16' else
+                + ('; weights as half hi+lo pairs' if args.precision == 'f16-pairs' else '')
+                if args.precision.startswith('f16') else
                 'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
                 + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),
             'data': 'synthetic',
@@ -549,8 +552,11 @@ def main():
                 model.restore(tl, options=oh)
                 extras['c3_tile_f16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=oh), 3, dev), 3)
                 extras['c3_tile_fp32_ms'] = round(time_steps(lambda: model.restore(tl), 3, dev), 3)
-                if args.workload == 'c3':        # the whole C3 image in the two opt-in 16-bit modes (PSNR-gated extensions; not the headline)
-                    for nm, o in (('f16', oh), ('bf16', o16)):
+                op = hip_ops.Options('f16-pairs')
+                model.restore(tl, options=op)
+                extras['c3_tile_f16_pairs_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=op), 3, dev), 3)
+                if args.workload == 'c3':        # the whole C3 image in the opt-in 16-bit modes (PSNR-gated extensions; not the headline)
+                    for nm, o in (('f16', oh), ('f16_pairs', op), ('bf16', o16)):
                         model.restore(lq, options=o)
                         t_ = time_steps(lambda: model.restore(lq, options=o), 1, dev)
                         extras[f'c3_{nm}_mode_ms'] = round(t_, 1)

@@ -45,7 +45,7 @@ class OptionsT(C.Structure):
     """ciaosr_options_t: per-call route options (include/ciaosr_hip.h)."""
     _fields_ = [('head_route', C.c_int), ('csa_composed_min', C.c_int), ('dense_min_tiles', C.c_int),
                 ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('bf16_single', C.c_int),
-                ('reserved', C.c_int * 1)]
+                ('f16_pairs', C.c_int)]
 
 
 HEAD_STAGED, HEAD_NO_LOGIT_TABLE = 1, 2
@@ -114,6 +114,7 @@ SIGNATURES = {
     'ciaosr_pack_fragments_f16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_bf16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ciaosr_pack_fragments_f16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
     'ciaosr_gather_rows_f32': (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),

@@ -137,7 +137,8 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
     // f16 mode: the local feature fusion (1x1 over the block's 576 channels) too reads the 16-bit copy of the block buffer, on the
     // 16-bit GEMM with bias + residual in its epilogue; the dense layers then need no fp32 copy of their outputs, and the epilogue
     // writes the next block's 16-bit input group.  (bf16 mode keeps the fp32 lff: its weights would need the hi + lo pair.)
-    const bool lff16 = dense16 && prec == kF16 && cb % 8 == 0 && G % 4 == 0 && G <= 128;
+    const bool pairs16 = prec == kF16 && opt && opt->f16_pairs;       // half weight pairs: the lff keeps its fp32 weights, like the bf16 mode
+    const bool lff16 = dense16 && prec == kF16 && !pairs16 && cb % 8 == 0 && G % 4 == 0 && G <= 128;
     int rc;
 #define RUN(x) do { rc = (x); if (rc != CIAOSR_OK) return rc; } while (0)
     if (B > 1 && !(dense16 || dense32)) {       // small maps: one image after the other through the single-image routes
@@ -170,7 +171,7 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
                 RUN(h16_ops(prec).dense_layer(lff16 ? nullptr : x, cb, Xb, cb, H, W, l, c.frag16,
-                                              (prec == kF16 || (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, B, s));
+                                              (prec == kF16 ? !pairs16 : (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, B, s));
             }
             if (lff16) {
                 // RDB output = x + lff(dense) from the 16-bit rows: fp32 to the global concat and the next block's input, 16-bit to the

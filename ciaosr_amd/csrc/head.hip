@@ -129,8 +129,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                         size_t workspace_bytes, void* stream_, Prec prec) {
     const bool bf16 = prec != kF32;                  // a 16-bit MFMA mode (bf16 or f16 entry)
     const int route = opt ? opt->head_route : 0;
-    const bool lo = prec == kBF16 && !(opt && opt->bf16_single);      // bf16 entry: hi + lo weight pairs unless single is asked for
-    CIAOSR_CHECK_ARG(!opt || opt->reserved[0] == 0);
+    // hi + lo weight pairs: the bf16 entry unless single is asked for, the f16 entry when pairs are asked for
+    const bool lo = (prec == kBF16 && !(opt && opt->bf16_single)) || (prec == kF16 && opt && opt->f16_pairs);
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
     CIAOSR_CHECK_ARG(w->local_size >= 1 && w->local_size <= 3 && w->softmax_scale != 0.f);
@@ -190,7 +190,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     // f16 mode: on the 16-bit GEMM from a half copy of U (the staged route's activation buffers are free on the fused route)
     const size_t u16_bytes = (size_t)p.HW * p.Dv * 2 + 256, w16_bytes = (size_t)(p.wk0 + p.wv0) * p.Dv * 2 + 512;
-    if (prec == kF16 && (p.D & 7) == 0 && (p.Dv & 7) == 0 && u16_bytes + w16_bytes <= R * p.wmax * sizeof(float) &&
+    if (prec == kF16 && !lo && (p.D & 7) == 0 && (p.Dv & 7) == 0 && u16_bytes + w16_bytes <= R * p.wmax * sizeof(float) &&
         (size_t)p.HW * p.Dv * 2 < 0xFFFFFF00ull) {
         const H16Ops& h = h16_ops(prec);
         unsigned short* U16 = reinterpret_cast<unsigned short*>(bufA);
@@ -219,7 +219,9 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     if (use_table) {
         const int last = w->k.n_layers - 1;
         const long total = (long)p.HW * 9;
-        const bool table16 = bf16 && (p.D & 7) == 0;   // bf16 mode: the table GEMM on the bf16 MFMA (fp32 table out)
+        // 16-bit modes: the table GEMM on the 16-bit MFMA (fp32 table out).  (Half-pairs mode: the exact-fp32 GEMM here was measured
+        // and changes nothing -- max |delta| 1.04e-3 -> 1.14e-3 on the full-tile vector, +0.9 ms: W5's rounding is not what limits it.)
+        const bool table16 = bf16 && (p.D & 7) == 0;
         if (table16) RUN(transpose_cast_h16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, prec == kF16, s));
         for (long r0 = 0; r0 < total; r0 += kQkChunk) {
             const int nr = (int)((total - r0) < kQkChunk ? (total - r0) : kQkChunk);

@@ -696,6 +696,11 @@ extern "C" int ciaosr_pack_fragments_f16(const float* W, int ld, int N, int K, v
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
     return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0);
 }
+
+extern "C" int ciaosr_pack_fragments_f16_lo(const float* W, int ld, int N, int K, void* out, void* stream) {
+    CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
+    return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 1);
+}
 #else
 #ifdef CIAOSR_PROBE
 extern "C" int ciaosr_debug_probe16_read(unsigned long long* host, int n_words) {

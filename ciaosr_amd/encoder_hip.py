@@ -111,7 +111,10 @@ class PackedEncoder:
                 _lib.call('ciaosr_pack_fragments_f16', c.weight, k_, n_, k_, hip_ops.ptr(f), hip_ops.stream_ptr())
                 keep.append(f)
                 c.frag16 = f.data_ptr()
-                c.frag16_lo = None
+                lo = torch.empty_like(f)                     # half(w - half(w)): read only with Options(f16_pairs=1)
+                _lib.call('ciaosr_pack_fragments_f16_lo', c.weight, k_, n_, k_, hip_ops.ptr(lo), hip_ops.stream_ptr())
+                keep.append(lo)
+                c.frag16_lo = lo.data_ptr()
             st.dense = dense
             self._st_f16, self._keep_f16 = st, keep
         return self._st_f16

@@ -107,7 +107,10 @@ class PackedHead:
                     _lib.call('ciaosr_pack_fragments_f16', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(f), hip_ops.stream_ptr())
                     keep.append(f)
                     m.frag16[i] = f.data_ptr()
-                    m.frag16_lo[i] = None
+                    lo = torch.empty_like(f)                 # half(w - half(w)): read only with Options(f16_pairs=1)
+                    _lib.call('ciaosr_pack_fragments_f16_lo', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(lo), hip_ops.stream_ptr())
+                    keep.append(lo)
+                    m.frag16_lo[i] = lo.data_ptr()
             self._st_f16, self._keep_f16 = st, keep
         return self._st_f16
 

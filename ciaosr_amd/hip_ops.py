@@ -183,14 +183,18 @@ class Options:
     """Per-call evaluation options, passed explicitly down the call chain (no process-global switches).
 
     precision  'fp32' (exact-fp32 MFMA, the contract precision), 'bf16' (bf16 MFMA inputs, fp32 accumulation; weights as
-               hi + lo pairs unless bf16_single) or 'f16' (IEEE half MFMA inputs, one MFMA per product, saturating at 65504):
+               hi + lo pairs unless bf16_single), 'f16' (IEEE half MFMA inputs, one MFMA per product, saturating at 65504)
+               or 'f16-pairs' (= 'f16' with f16_pairs=1: half activations, every weight as a half hi + lo pair):
                selects the _f32 / _bf16 / _f16 entry point of the C ABI.
     the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
     Immutable; `replace()` returns a modified copy."""
-    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single')
+    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'f16_pairs')
     __slots__ = ('precision',) + _C_FIELDS + ('_c',)
 
     def __init__(self, precision='fp32', **kw):
+        if precision in ('f16-pairs', 'f16_pairs', 'f16p'):      # the fp32-tolerance fast mode: half activations, half weight PAIRS
+            precision = 'f16'
+            kw.setdefault('f16_pairs', 1)
         object.__setattr__(self, 'precision', {'fp32': 'fp32', 'f32': 'fp32', 'bf16': 'bf16', 'f16': 'f16', 'fp16': 'f16', 'half': 'f16'}[precision])
         for f in self._C_FIELDS:
             object.__setattr__(self, f, int(kw.pop(f, 0)))

@@ -221,7 +221,7 @@ class CiaoSR(BasicRestorer):
         prec = cfg.get('precision', None)
         if prec is None and not extra:
             return hip_ops.DEFAULT_OPTIONS
-        return hip_ops.Options(prec or 'fp32', **extra)
+        return hip_ops.Options(prec or 'fp32', **extra)          # 'fp32' | 'bf16' | 'f16' | 'f16-pairs'
 
     @torch.no_grad()
     def restore(self, lq, coord=None, cell=None, options=None):

@@ -78,7 +78,10 @@ typedef struct ciaosr_options {
                              * lo = bf16(w - hi): 16 mantissa bits, two MFMAs per product); 1 = hi only (one MFMA, 8 bits).
                              * Rounding WEIGHTS to 8 bits is a fixed perturbation whose response is spatially coherent and
                              * fails the 0.01 dB PSNR gate on smooth features; activations stay single bf16 */
-    int reserved[1];        /* must be 0 */
+    int f16_pairs;          /* _f16 entries: 0 (default) = one IEEE-half weight per product; 1 = every dense-layer / head weight enters
+                             * the MFMA as a half PAIR hi + lo (hi = half(w), lo = half(w - hi): ~20 mantissa bits, two MFMAs per product)
+                             * and the layers the plain f16 mode runs with single 16-bit weights elsewhere (RDB local feature fusion,
+                             * layer-0 tables) take the fp32 route of the bf16 mode: the "fp32-tolerance" fast mode (activations stay half) */
 } ciaosr_options_t;
 
 /* ---- layout plumbing -------------------------------------------------------------------- */
@@ -187,6 +190,8 @@ int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* ou
  * (DESIGN 4.3); the price is the range: activations and weights beyond 65504 are clamped, below 6e-8 flushed to 0. */
 size_t ciaosr_fragment_f16_bytes(int N, int K);
 int ciaosr_pack_fragments_f16(const float* W, int ld, int N, int K, void* out, void* stream);
+/* Rounding residual w - half(w) of the same matrix in the same fragment order: the lo half of the pair of opt->f16_pairs. */
+int ciaosr_pack_fragments_f16_lo(const float* W, int ld, int N, int K, void* out, void* stream);
 
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
@@ -270,8 +275,8 @@ int ciaosr_head_forward_bf16(const float* feat_hwc, int H, int W, const ciaosr_h
                              const float* coord, const float* cell, int Q, int chunk, float* rgb,
                              const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace,
                              size_t workspace_bytes, void* stream);
-/* Same with IEEE half MFMA inputs (ciaosr_mlp_t.frag16 packed by ciaosr_pack_fragments_f16; one MFMA per product,
- * frag16_lo and opt->bf16_single ignored). */
+/* Same with IEEE half MFMA inputs (ciaosr_mlp_t.frag16 packed by ciaosr_pack_fragments_f16; one MFMA per product;
+ * opt->bf16_single ignored).  opt->f16_pairs: frag16_lo (ciaosr_pack_fragments_f16_lo) is read too -- two MFMAs per product. */
 int ciaosr_head_forward_f16(const float* feat_hwc, int H, int W, const ciaosr_head_weights_t* w,
                             const ciaosr_csattn_weights_t* csattn, const float* x_lr_nchw,
                             const float* coord, const float* cell, int Q, int chunk, float* rgb,
@@ -327,7 +332,8 @@ int ciaosr_rdn_forward_f32(const float* x_nchw, int H, int W, const ciaosr_rdn_w
 int ciaosr_rdn_forward_bf16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                             const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
                             void* stream);
-/* Same with IEEE half operands (ciaosr_conv_t.frag16 packed by ciaosr_pack_fragments_f16; frag16_lo ignored). */
+/* Same with IEEE half operands (ciaosr_conv_t.frag16 packed by ciaosr_pack_fragments_f16; frag16_lo -- packed by
+ * ciaosr_pack_fragments_f16_lo -- is read only with opt->f16_pairs). */
 int ciaosr_rdn_forward_f16(const float* x_nchw, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                            const ciaosr_options_t* opt /*host, NULL = defaults*/, void* workspace, size_t workspace_bytes,
                            void* stream);

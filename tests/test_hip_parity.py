@@ -664,7 +664,7 @@ def _tile192_checks(out, fx, tol):
     return errs
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16-single', 'f16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16-single', 'f16', 'f16-pairs'])
 def test_e2e_full_c3_tile_vs_reference(dev, precision):
     """One full C3 tile: 192x192 LR -> 768x768 through CiaoSR.forward_test (clip_test with one tile; RDN trunk on the
     halo-resident dense kernels, cs_attn on the composed tail, 589 824 queries = 20 reference eval_bsize chunks) against
@@ -681,7 +681,12 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
       delivers.
       f16 mode (IEEE half MFMA inputs, ONE MFMA per product like bf16-single): 11 mantissa bits put the weight
       perturbation 8x lower, and the gate holds: <= 0.01 dB asserted (CPU emulation of the rounding points: slope
-      -2.0e-4 against bf16-single's -4.2e-3)."""
+      -2.0e-4 against bf16-single's -4.2e-3).
+      f16-pairs (`Options('f16-pairs')`: half activations, every dense-layer / head weight as a half hi + lo pair, two MFMAs per
+      product; fp32 local feature fusion and layer-0 tables): PSNR delta 0.0000 dB at 15 dB and 0.0002 dB at 30 dB, rms 1.3e-4, but
+      max |delta| = 1.04e-3 over the stored pixels -- 4 % ABOVE the north star's fp32 bound of 1e-3, so it is NOT an fp32-tolerance
+      mode on this ill-conditioned (head gain sqrt 6) vector.  What is left is the 11-bit rounding of the ACTIVATIONS in front of the
+      4-way softmax (logit std ~40); W5 through the exact-fp32 table GEMM changed nothing (1.14e-3).  Asserted: < 1.5e-3."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.metrics import psnr_tensors
@@ -692,7 +697,8 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     model = model.to(dev)
     lq, gt = synthetic_pair(192, 192, 4)
     opt = {'fp32': hip_ops.Options('fp32'), 'bf16': hip_ops.Options('bf16'),
-           'bf16-single': hip_ops.Options('bf16', bf16_single=1), 'f16': hip_ops.Options('f16')}[precision]
+           'bf16-single': hip_ops.Options('bf16', bf16_single=1), 'f16': hip_ops.Options('f16'),
+           'f16-pairs': hip_ops.Options('f16-pairs')}[precision]
     with hip_ops.profile():
         out = model.restore(lq.to(dev), options=opt).cpu()
     prof = hip_ops.profile.results()
@@ -700,7 +706,7 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         for tag in ('enc_dense_gather', 'csa_attn_v_edge', 'head_logit_table'):
             assert tag in prof, (tag, sorted(prof))
     else:
-        sfx = '_f16' if precision == 'f16' else '_bf16'
+        sfx = '_f16' if precision.startswith('f16') else '_bf16'
         for tag in ('enc_dense', 'csa_attn_v', 'csa_scores', 'head_kv_fused', 'head_logit_table'):
             assert tag + sfx in prof, (tag + sfx, sorted(prof))
     assert out.shape == (1, 3, 768, 768)
@@ -724,6 +730,10 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         assert d_psnr <= 0.01 and d_psnr30 <= 0.001, (d_psnr, d_psnr30)
         assert max(errs.values()) < NORTH_STAR_TOL, errs
         assert mean_err < 1e-5 and rms < 1e-5, (mean_err, rms)
+    elif precision == 'f16-pairs':
+        assert d_psnr <= 0.01 and d_psnr30 <= 0.01, (d_psnr, d_psnr30)
+        assert max(errs.values()) < 1.5e-3, errs      # measured 1.04e-3: just above the fp32 bound (see the docstring)
+        assert rms < 1.7e-4, rms
     elif precision in ('bf16', 'f16'):
         assert d_psnr <= 0.01, d_psnr            # the north-star gate; measured 0.00014 dB (bf16 pairs)
         assert d_psnr30 <= 0.01, d_psnr30        # ... and at a trained model's quality level
