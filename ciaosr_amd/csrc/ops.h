@@ -56,6 +56,10 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
 bool gemm_small_ok(int M, int N, int K, int lda, int ldw);
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,
                    const float* res, int ldres, int M, int N, int K, int act, float slope, float alpha, hipStream_t s, const char* tag);
+// conv1x1_f32.hip: weights-resident fp32 1x1 convolution to 64 channels (the RDB local feature fusion on big maps)
+bool conv1x1_resident_ok(long M, int N, int K, int ldx, int ldw);
+int conv1x1_resident_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res, int ldres, float* dst,
+                         int ld_dst, float* dst2, int ld_dst2, long M, int K, hipStream_t s, const char* tag);
 // conv_small_f32.hip: 3x3 convolutions of small maps in one launch (needs ciaosr_pack_fragments_f32 weights)
 bool conv3x3_small_ok(int H, int W, int Cin, int Cout, int ld_src, int act);
 int conv3x3_small(const float* src, int ld_src, int H, int W, int Cin, const float* frag, const float* bias, int Cout, float* dst,
