@@ -126,7 +126,9 @@ __global__ __launch_bounds__(512, 2) void conv1x1_resident_f32_kernel(Res1x1P p)
 }
 
 bool conv1x1_resident_ok(long M, int N, int K, int ldx, int ldw) {
-    return N == 64 && K >= 64 && K <= R1_MAXK && (K & 7) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0 && M >= 2048 &&
+    // from ~1.5 row tiles per wave of the 256 x 8-wave grid on: below that (one 192x192 tile = 1152 tiles for 2048 waves) half the
+    // waves idle while every CU still loads the 148 KB of weights, and the generic tile kernel is faster (0.82 vs 1.07 ms per tile)
+    return N == 64 && K >= 64 && K <= R1_MAXK && (K & 7) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0 && M >= 3 * 32768 &&
            ((size_t)(M - 1) * ldx + K) * 4 < 0xFFFFFF00ull;
 }
 

@@ -33,12 +33,14 @@ constexpr bool kF16 = CIAOSR_F16 != 0;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GM = 256, GN = 128, GK = 32;
+constexpr int GM = 256, GN = 128, GK = 32;               // GM: the default row tile (MT = 4 MFMA tiles per wave); MT = 3 -> 192 rows
 constexpr int GRS = GK * 2;                               // LDS row stride in bytes (32 bf16, chunk-swizzled, no pad)
 constexpr int GCH = GK / 8;                               // 16-byte chunks per row
-constexpr int GSA = GM * GCH / 256, GSB = GN * GCH / 256; // staging chunks per thread (A: 4, B: 2)
-constexpr int GA_T = GM * GRS, GB_T = GN * GRS;           // bytes per stage
-constexpr size_t kGemm16Lds = 3 * (size_t)(GA_T + GB_T);  // three stages, 73 728 B: two workgroups per CU
+constexpr int GSB = GN * GCH / 256;                       // B staging chunks per thread (2); A: MT
+constexpr int GB_T = GN * GRS;                            // bytes of B per stage
+constexpr size_t kGemm16Lds = 3 * (size_t)(GM * GRS + GB_T);  // three stages of the 256-row tile, 73 728 B: two workgroups per CU
+constexpr int GPR = GN * 2 + 16;                          // row pitch of the 16-bit output tile staged in LDS by the softmax epilogue
+static_assert((size_t)GM * GPR <= kGemm16Lds, "the staged output tile must fit the stage buffers");
 constexpr unsigned kOob16 = 0xFFFFFFF0u;
 
 struct Gemm16P {
@@ -63,10 +65,11 @@ struct Gemm16P {
 };
 
 // store epilogue of one 256 x 128 tile: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li, columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
-__device__ __forceinline__ void store_tile(const Gemm16P& p, const f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int li, int lh) {
+template <int MT>
+__device__ __forceinline__ void store_tile(const Gemm16P& p, const f32x16 (&acc)[MT][2], int m0, int n0, int wm, int wn, int li, int lh) {
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + 128 * wm + 32 * mt + li;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 32 * MT * wm + 32 * mt + li;
         if (m >= p.M) continue;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -101,28 +104,48 @@ __device__ __forceinline__ void store_tile(const Gemm16P& p, const f32x16 (&acc)
     }
 }
 
-// softmax pass 1: partial (max, sum of exp) of this wave's 64-column strip
-__device__ __forceinline__ void stats_tile(const Gemm16P& p, const f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int li, int lh) {
-    // partial softmax statistics of this wave's 64-column strip: a row's 32 values sit in two lanes (li, li + 32)
+// softmax pass 1: partial (max, sum of exp) of this wave's 64-column strip.  alpha > 0 (checked by the launcher): the maximum is
+// taken on the raw accumulators and exp(alpha x - m) = exp2(x (alpha log2 e) - m log2 e) is one FMA + v_exp_f32 per value -- this
+// epilogue is VALU-bound (128 values per lane against 144 MFMAs per wave at K = 288), 10 -> 3 VALU operations per value; interior
+// tiles skip the column predicates altogether.
+template <int MT>
+__device__ __forceinline__ void stats_tile(const Gemm16P& p, const f32x16 (&acc)[MT][2], int m0, int n0, int wm, int wn, int li, int lh) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float c1 = p.alpha * kLog2e;
+    const bool full = n0 + GN <= p.N;                      // uniform
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + 128 * wm + 32 * mt + li;
-        float mx = -INFINITY;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + 32 * MT * wm + 32 * mt + li;
+        float mx = -INFINITY, sum = 0.f;
+        if (full) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, acc[mt][nt][e]);
+            const float ms = mx * c1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) mx = fmaxf(mx, acc[mt][nt][4 * q + e] * p.alpha);
-        float sum = 0.f;
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+                for (int e = 0; e < 16; ++e) sum += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][e], c1, -ms));
+        } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) sum += __expf(acc[mt][nt][4 * q + e] * p.alpha - mx);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N) mx = fmaxf(mx, acc[mt][nt][4 * q + e]);
+            const float ms = mx * c1;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh + e < p.N)
+                            sum += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][4 * q + e], c1, -ms));
+        }
+        mx *= p.alpha;                                     // the statistics are kept in logit units
         const float mo = __shfl_xor(mx, 32, 64), so = __shfl_xor(sum, 32, 64);
         const float mm = fmaxf(mx, mo);
         // a strip with no valid column on either lane keeps (-inf, 0): exp(-inf - -inf) is avoided
@@ -131,39 +154,58 @@ __device__ __forceinline__ void stats_tile(const Gemm16P& p, const f32x16 (&acc)
     }
 }
 
-// softmax pass 2: probabilities exp(v - row max) / row sum as 16-bit, pad columns zeroed
-__device__ __forceinline__ void softmax_tile(const Gemm16P& p, const f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int li, int lh) {
+// softmax pass 2: probabilities exp(v - row max) / row sum as 16-bit, pad columns zeroed.  The tile goes through LDS (the stage
+// buffers are free after the k-loop) so that it leaves in full 256-byte row pieces: written straight from the accumulator layout a
+// lane stores 8 bytes per row for 32 different rows per instruction -- 16-byte fragments of 18-KB-apart rows, 680 MB per 192x192
+// tile at 1.6 TB/s, the whole pass at 0.18 of the MFMA peak.
+template <int MT>
+__device__ __forceinline__ void softmax_tile(const Gemm16P& p, const f32x16 (&acc)[MT][2], int m0, int n0, int wm, int wn, int li, int lh,
+                                             unsigned char* lds, int t) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float c1 = p.alpha * kLog2e;
+    __syncthreads();                                       // every wave is done with the last stage
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + 128 * wm + 32 * mt + li;
-        if (m >= p.M) continue;
-        const float2 st = p.stats[m];
+    for (int mt = 0; mt < MT; ++mt) {
+        const int r = 32 * MT * wm + 32 * mt + li, m = m0 + r;
+        const float2 st = m < p.M ? p.stats[m] : make_float2(0.f, 0.f);
+        const float ms = st.x * kLog2e;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int n = n0 + 64 * wn + 32 * nt + 8 * q + 4 * lh;
-                if (n >= p.npad) continue;
+                const int c = 64 * wn + 32 * nt + 8 * q + 4 * lh, n = n0 + c;
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = n + e < p.N ? __expf(acc[mt][nt][4 * q + e] * p.alpha - st.x) * st.y : 0.f;
-                *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v[0], v[1], v[2], v[3]);
+                for (int e = 0; e < 4; ++e)
+                    v[e] = n + e < p.N ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][4 * q + e], c1, -ms)) * st.y : 0.f;
+                *reinterpret_cast<uint2*>(lds + r * GPR + c * 2) = pack_h16x4<kF16>(v[0], v[1], v[2], v[3]);
             }
+    }
+    __syncthreads();
+    // 16 chunks of 16 bytes per row: a wave instruction stores 4 whole rows of the tile
+#pragma unroll
+    for (int u = 0; u < MT * 4; ++u) {
+        const int idx = t + 256 * u, r = idx >> 4, ch = idx & 15;
+        const int m = m0 + r, n = n0 + 8 * ch;
+        if (m < p.M && n < p.npad)
+            *reinterpret_cast<uint4*>(p.C16 + (size_t)m * p.ldc16 + n) = *reinterpret_cast<const uint4*>(lds + r * GPR + ch * 16);
     }
 }
 
 // ---- the kernel: one 256 x 128 tile per workgroup, operands staged by LDS-DMA, epilogue by EPI -------------------------------
 // lane i of a wave's 1-KB slice writes LDS chunk i and fetches the logical chunk (i % 4) ^ key(row); hipcc's __syncthreads() would
 // drain the DMAs, hence the raw barrier and the counted waits.
-template <int EPI>
+template <int EPI, int MT>
 __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];      // [3] x { A [GM][GRS], B [GN][GRS] }
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];      // [3] x { A [GM_][GRS], B [GN][GRS] }
+    constexpr int GM_ = 64 * MT;                           // rows of this tile: 2 wave rows x MT MFMA tiles
+    constexpr int GSA = MT, GA_T = GM_ * GRS;
     constexpr int STG = GA_T + GB_T;
     const int bid = blockIdx.x;
     const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
-    const int m0 = (lid / p.tiles_n) * GM, n0 = (lid % p.tiles_n) * GN;
+    const int m0 = (lid / p.tiles_n) * GM_, n0 = (lid % p.tiles_n) * GN;
 
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = w >> 1, wn = w & 1, li = lane & 31, lh = lane >> 5;
@@ -214,9 +256,9 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -225,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     const int lswz = (li >> 2) & 3;
-    const int a_row = (128 * wm + li) * GRS, b_row = GA_T + (64 * wn + li) * GRS;
+    const int a_row = (32 * MT * wm + li) * GRS, b_row = GA_T + (64 * wn + li) * GRS;
     int buf = 0;
 #pragma unroll 1
     for (int k = 0; k < nk; ++k) {
@@ -238,22 +280,22 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
 #pragma unroll
         for (int ks = 0; ks < GK / 16; ++ks) {
             const int co = ((2 * ks + lh) ^ lswz) * 16;
-            uint4 fb[2], fa[4];
+            uint4 fb[2], fa[MT];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) fb[nt] = *reinterpret_cast<const uint4*>(st + b_row + nt * 32 * GRS + co);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(st + a_row + mt * 32 * GRS + co);
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(st + a_row + mt * 32 * GRS + co);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[mt][nt] = mfma_h16<kF16>(fb[nt], fa[mt], acc[mt][nt]);
         }
         buf = buf == 2 ? 0 : buf + 1;
     }
-    if constexpr (EPI == 1) stats_tile(p, acc, m0, n0, wm, wn, li, lh);
-    else if constexpr (EPI == 2) softmax_tile(p, acc, m0, n0, wm, wn, li, lh);
-    else store_tile(p, acc, m0, n0, wm, wn, li, lh);
+    if constexpr (EPI == 1) stats_tile<MT>(p, acc, m0, n0, wm, wn, li, lh);
+    else if constexpr (EPI == 2) softmax_tile<MT>(p, acc, m0, n0, wm, wn, li, lh, lds16, t);
+    else store_tile<MT>(p, acc, m0, n0, wm, wn, li, lh);
 }
 
 // fp32 rows -> bf16 rows (first `cols` columns, cols % 4 == 0); pad columns [cols, ld_dst) are zeroed
@@ -318,6 +360,27 @@ __global__ __launch_bounds__(256) void softmax_rows_h16_kernel(const float* __re
     }
 }
 
+// Row tile of a launch: 256 rows (MT = 4) unless 192-row tiles (MT = 3) cut the number of chip-wide rounds enough -- two workgroups
+// per CU = 512 tiles per round, and a launch costs (rounds x rows per tile): the 192x192 tile's P.V' (M = 36864, N = 1024) is 1152
+// tiles of 256 rows = 2.25 rounds, paid as 3 x 256, against 1536 tiles of 192 rows = 3 rounds x 192.
+static int pick_mt(int M, int tiles_n) {
+    const long c4 = (long)ceil_div((long)ceil_div(M, 256) * tiles_n, 512) * 4;
+    const long c3 = (long)ceil_div((long)ceil_div(M, 192) * tiles_n, 512) * 3;
+    return c3 * 10 < c4 * 9 ? 3 : 4;
+}
+template <int EPI>
+static int launch_gemm16(Gemm16P& p, int mt, hipStream_t s) {
+    p.n_wg = ceil_div(p.M, 64 * mt) * p.tiles_n;
+    if (mt == 3) {
+        CIAOSR_BIG_LDS((gemm_h16_kernel<EPI, 3>), kGemm16Lds);
+        hipLaunchKernelGGL((gemm_h16_kernel<EPI, 3>), dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    } else {
+        CIAOSR_BIG_LDS((gemm_h16_kernel<EPI, 4>), kGemm16Lds);
+        hipLaunchKernelGGL((gemm_h16_kernel<EPI, 4>), dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    }
+    return CIAOSR_OK;
+}
+
 int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,
                  int K, float alpha, hipStream_t s, const char* tag) {
     if (M <= 0 || N <= 0) return CIAOSR_OK;
@@ -332,10 +395,9 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    p.n_wg = ceil_div(M, GM) * p.tiles_n;
-    CIAOSR_BIG_LDS(gemm_h16_kernel<0>, kGemm16Lds);
     ProfScope prof(tag ? tag : "gemm" CIAOSR_H16_SUFFIX, s);
-    hipLaunchKernelGGL(gemm_h16_kernel<0>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    const int rc = launch_gemm16<0>(p, pick_mt(M, p.tiles_n), s);
+    if (rc != CIAOSR_OK) return rc;
     return launch_status("gemm" CIAOSR_H16_SUFFIX);
 }
 
@@ -460,10 +522,9 @@ int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
-    p.n_wg = ceil_div(M, GM) * p.tiles_n;
-    CIAOSR_BIG_LDS(gemm_h16_kernel<0>, kGemm16Lds);
     ProfScope prof(tag, s);
-    hipLaunchKernelGGL(gemm_h16_kernel<0>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    const int rc = launch_gemm16<0>(p, pick_mt(M, p.tiles_n), s);
+    if (rc != CIAOSR_OK) return rc;
     return launch_status("conv1x1" CIAOSR_H16_SUFFIX);
 }
 
@@ -508,18 +569,19 @@ int softmax_gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* 
     p.tiles_n = ceil_div(N, GN);
     // (Several consecutive column tiles per workgroup as one software pipeline measured the same time on the 192x192 tile's scores
     // -- M = 36864, N = 9216, K = 288: each 256 x 128 tile pulls 221 KB through L2 for 18.9 MFLOP -- and was dropped.)
-    p.n_wg = ceil_div(M, GM) * p.tiles_n;
+    CIAOSR_CHECK_ARG(alpha > 0.f);                    // the pass-1 maximum is taken on the raw accumulators
     p.n_part = 2 * p.tiles_n;
     p.part = reinterpret_cast<float2*>(scratch);
     float2* stats = p.part + (size_t)M * p.n_part;
     p.stats = stats;
     p.npad = (int)round_up((size_t)N, 8) <= ldp ? (int)round_up((size_t)N, 8) : ldp;
-    CIAOSR_BIG_LDS(gemm_h16_kernel<1>, kGemm16Lds);
-    CIAOSR_BIG_LDS(gemm_h16_kernel<2>, kGemm16Lds);
     ProfScope prof(tag, s);
-    hipLaunchKernelGGL(gemm_h16_kernel<1>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    const int mt = pick_mt(M, p.tiles_n);
+    int rc = launch_gemm16<1>(p, mt, s);
+    if (rc != CIAOSR_OK) return rc;
     hipLaunchKernelGGL(softmax_stats_merge_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, p.part, p.n_part, (long)M, stats);
-    hipLaunchKernelGGL(gemm_h16_kernel<2>, dim3(p.n_wg), dim3(256), kGemm16Lds, s, p);
+    rc = launch_gemm16<2>(p, mt, s);
+    if (rc != CIAOSR_OK) return rc;
     return launch_status("softmax_gemm" CIAOSR_H16_SUFFIX);
 }
 

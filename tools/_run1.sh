@@ -1,2 +1,2 @@
-python -m pytest tests/test_hip_parity.py -q -x -k "rdn_trunk or tile_batch_is_bitwise or full_c3_tile_vs_reference or sub_batches or encoder_features" 2>&1 | tail -3
-python3 bench.py --workload c3 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('c3 fp32', d['ms_per_step'], {k:round(v,1) for k,v in list(d['kernels_ms_per_step'].items())[:12]})"
+python -m pytest tests/test_hip_parity.py -q -x -k "csattn or full_c3_tile_vs_reference or precision_selects or head_bf16_mode" 2>&1 | tail -3
+python3 tools/kernel_lab.py --quick f16=f16 bf16=bf16 2>&1 | tail -2
