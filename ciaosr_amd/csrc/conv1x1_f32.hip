@@ -126,16 +126,17 @@ __global__ __launch_bounds__(512, 2) void conv1x1_resident_f32_kernel(Res1x1P p)
 }
 
 bool conv1x1_resident_ok(long M, int N, int K, int ldx, int ldw) {
-    // from ~1.5 row tiles per wave of the 256 x 8-wave grid on: below that (one 192x192 tile = 1152 tiles for 2048 waves) half the
-    // waves idle while every CU still loads the 148 KB of weights, and the generic tile kernel is faster (0.82 vs 1.07 ms per tile)
-    return N == 64 && K >= 64 && K <= R1_MAXK && (K & 7) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0 && M >= 3 * 32768 &&
+    // M = rows of ONE image: the choice must not depend on how many tiles share a launch (a tile's result is bitwise the same alone,
+    // in a batch and on a side stream).  Big maps only; a single 192x192 tile (1152 row tiles for 2048 waves) runs it at 1.07 ms
+    // against 0.82 ms of the generic tile kernel, a batch of 8 at 0.57 against 0.82 per tile.
+    return N == 64 && K >= 64 && K <= R1_MAXK && (K & 7) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0 && M >= 32768 &&
            ((size_t)(M - 1) * ldx + K) * 4 < 0xFFFFFF00ull;
 }
 
 // dst[m][0..64) (and dst2 when given) = X[m][0..K) . W^T + bias + res[m][0..64); rows [0, M) of every operand
 int conv1x1_resident_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res, int ldres, float* dst,
                          int ld_dst, float* dst2, int ld_dst2, long M, int K, hipStream_t s, const char* tag) {
-    CIAOSR_CHECK_ARG(X && W && bias && dst && conv1x1_resident_ok(M, 64, K, ldx, ldw));
+    CIAOSR_CHECK_ARG(X && W && bias && dst && M > 0 && conv1x1_resident_ok(32768, 64, K, ldx, ldw) && ((size_t)(M - 1) * ldx + K) * 4 < 0xFFFFFF00ull);
     CIAOSR_CHECK_ARG((ldres & 3) == 0 && (ld_dst & 3) == 0 && (ld_dst2 & 3) == 0 && aligned16(X) && aligned16(W) && aligned16(bias) &&
                      aligned16(dst) && (!res || aligned16(res)) && (!dst2 || aligned16(dst2)));
     Res1x1P p;

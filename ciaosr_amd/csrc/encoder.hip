@@ -212,7 +212,7 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
         const ciaosr_conv_t& f = w->lff[b];
         CIAOSR_CHECK_ARG(conv_ok(f, cb, G, 1));
         // RDB output = x + lff(dense): goes to the global concat and is the next block's input
-        if (conv1x1_resident_ok((long)BHW, G, cb, cb, cb) && fits32) {
+        if (conv1x1_resident_ok((long)HW, G, cb, cb, cb) && fits32) {
             // big maps: the whole batch in ONE launch of the weights-resident kernel (the B images' rows are contiguous in every buffer)
             RUN(conv1x1_resident_f32(x, cb, f.weight, cb, f.bias, x, cb, Gc + (size_t)b * G, G * NB, b + 1 < NB ? xn : nullptr, cb, (long)BHW, cb,
                                      s, "enc_conv1x1"));
