@@ -12,6 +12,7 @@ python3 $R/bench.py --workload c3tile --steps 5 --warmup 2 --no-extras --no-cpu-
 python3 $R/bench.py --workload c3tile --precision bf16 --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $O/c3tile_bf16_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3tile --precision f16 --steps 5 --warmup 2 --no-extras --no-cpu-baseline > $O/c3tile_f16_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3 --precision f16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc > $O/c3_f16_bench.json 2>> $O/c3_bench.err
+python3 $R/bench.py --workload c3 --precision f16-pairs --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc > $O/c3_f16_pairs_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3 --precision bf16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc > $O/c3_bf16_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c2 --steps 20 --warmup 5 > $O/c2_bench.json 2>> $O/c3_bench.err
 # kernel stats of the SAME command as the driver's bench, on the 6-tile variant of C3 and on one tile (trace size bounded)
