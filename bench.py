@@ -267,6 +267,7 @@ def main():
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
                          'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product): the fp32-tolerance fast mode')
+    ap.add_argument('--tile-batch', type=int, default=0, help='developer: test_cfg.tile_batch (0 = the default 8)')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
@@ -314,7 +315,7 @@ def main():
 
     scale = 4
     lr_h, lr_w, n_tiles_img, wl_desc = WORKLOADS[args.workload]
-    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32))
+    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32, **({'tile_batch': args.tile_batch} if args.tile_batch else {})))
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
     lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
