@@ -268,6 +268,7 @@ def main():
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
                          'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product): the fp32-tolerance fast mode')
     ap.add_argument('--tile-batch', type=int, default=0, help='developer: test_cfg.tile_batch (0 = the default 8)')
+    ap.add_argument('--encoder-ahead', action='store_true', help='test_cfg.encoder_ahead: trunk of the next tile batch on a side stream under the heads of the current one (bitwise the same image; per-kernel timings then overlap)')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
@@ -315,7 +316,7 @@ def main():
 
     scale = 4
     lr_h, lr_w, n_tiles_img, wl_desc = WORKLOADS[args.workload]
-    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32, **({'tile_batch': args.tile_batch} if args.tile_batch else {})))
+    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32, **({'tile_batch': args.tile_batch} if args.tile_batch else {}), **({'encoder_ahead': True} if args.encoder_ahead else {})))
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
     lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
@@ -562,6 +563,15 @@ def main():
                         t_ = time_steps(lambda: model.restore(lq, options=o), 1, dev)
                         extras[f'c3_{nm}_mode_ms'] = round(t_, 1)
                         extras[f'c3_{nm}_mode_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
+                    # opt-in test_cfg.encoder_ahead: the trunk of tile batch k + 1 on a side stream under the heads of batch k (bitwise the
+                    # same image).  Not the headline: per-kernel event timings overlap while two streams share the chip.
+                    model.test_cfg['encoder_ahead'] = True
+                    for nm, o in (('fp32', hip_ops.DEFAULT_OPTIONS), ('f16', oh)):
+                        model.restore(lq, options=o)
+                        t_ = time_steps(lambda: model.restore(lq, options=o), 1, dev)
+                        extras[f'c3_{nm}_encoder_ahead_ms'] = round(t_, 1)
+                        extras[f'c3_{nm}_encoder_ahead_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
+                    model.test_cfg['encoder_ahead'] = False
                 c2 = synthetic_pair(48, 48, scale)[0].to(dev)
                 for _ in range(3):
                     model.restore(c2)

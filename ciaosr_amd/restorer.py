@@ -159,6 +159,8 @@ class CiaoSR(BasicRestorer):
                 hasattr(getattr(self.generator, '_encoder_hip', None), 'forward_hwc_batch')):
             # `test_cfg.tile_batch` (an extension; default 8) consecutive tiles share the encoder's dense-layer launches; every tile
             # is bitwise the one-at-a-time result and the blend order is the reference's
+            if self.test_cfg.get('encoder_ahead', False) and getattr(self.generator, '_head', None) is not None:
+                return self._clip_test_encoder_ahead(img_lq, tile, origins, n_batch, sf, E, Wt, options)
             for i0 in range(0, len(origins), n_batch):
                 group = origins[i0:i0 + n_batch]
                 outs, (th, tw) = self.run_tiles(img_lq, group, tile, sf, options)
@@ -202,6 +204,46 @@ class CiaoSR(BasicRestorer):
         for st in streams:
             cur.wait_stream(st)
         return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
+
+    def _clip_test_encoder_ahead(self, img_lq, tile, origins, n_batch, sf, E, Wt, options):
+        """`test_cfg.encoder_ahead = True` (an extension, off by default for the same reason as `tile_streams`: per-kernel event
+        timings are meaningless while two streams share the chip): the RDN trunk of tile batch k + 1 runs on a side stream UNDER the
+        heads of batch k (cs_attn + fused head kernels, the caller's stream).  The trunk's 130 strictly dependent launches per batch
+        and the heads' long MFMA kernels fill each other's ramp / drain / memory phases.  Same kernels on the same data in the same
+        per-tile order: the image is bitwise the default path's."""
+        gen = self.generator
+        opt = self.options(options)
+        enc = gen._encoder_hip
+        dev = img_lq.device
+        cur = torch.cuda.current_stream(dev)
+        self.prepare(opt)
+        th = tw = round(tile * sf)
+        coord, cell = hip_ops.make_coord_cell(th, tw, dev)
+        side = self._tile_streams(1, dev)[0]
+        side.wait_stream(cur)
+        groups = [origins[i0:i0 + n_batch] for i0 in range(0, len(origins), n_batch)]
+
+        def trunk(group):
+            with torch.cuda.stream(side):
+                patches = torch.cat([img_lq[..., hi:hi + tile, wi:wi + tile] for (hi, wi) in group], 0).contiguous().float()
+                feats = enc.forward_hwc_batch(patches, opt)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return patches, feats, ev
+
+        nxt = trunk(groups[0])
+        for k, group in enumerate(groups):
+            patches, feats, ev = nxt
+            if k + 1 < len(groups):
+                nxt = trunk(groups[k + 1])                       # queued behind batch k's trunk, runs under batch k's heads
+            cur.wait_event(ev)
+            patches.record_stream(cur)
+            feats.record_stream(cur)
+            for j, (hi, wi) in enumerate(group):
+                out = gen._head.forward(None, patches[j], coord, cell, gen.eval_bsize, feature_hwc=feats[j], options=opt)
+                hip_ops.tile_blend(E[0], Wt[0], out.contiguous(), hi * sf, wi * sf, th, tw)
+        cur.wait_stream(side)
+        return torch.stack([hip_ops.tile_finalize(E[0], Wt[0])])
 
     def _tile_streams(self, n, device):
         key = (n, device.index)

@@ -792,6 +792,13 @@ def test_tile_streams_are_bitwise_the_single_stream_result(dev):
         assert torch.equal(model.restore(lq), one)
         model.test_cfg['tile_streams'] = 3
         assert torch.equal(model.restore(lq), one)
+        # the trunk of tile batch k + 1 on a side stream under the heads of batch k (test_cfg.encoder_ahead), batches of 2 and 8
+        model.test_cfg['tile_streams'] = 1
+        model.test_cfg['encoder_ahead'] = True
+        for nb in (2, 8):
+            model.test_cfg['tile_batch'] = nb
+            assert torch.equal(model.restore(lq), one), (precision, nb)
+            assert torch.equal(model.restore(lq), one), (precision, nb)
 
 
 def test_tile_batch_is_bitwise_the_one_tile_result(dev):
