@@ -45,7 +45,7 @@ class OptionsT(C.Structure):
     """ciaosr_options_t: per-call route options (include/ciaosr_hip.h)."""
     _fields_ = [('head_route', C.c_int), ('csa_composed_min', C.c_int), ('dense_min_tiles', C.c_int),
                 ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('bf16_single', C.c_int),
-                ('f16_pairs', C.c_int)]
+                ('dense_direct', C.c_int), ('reserved', C.c_int * 3), ('f16_pairs', C.c_int)]
 
 
 HEAD_STAGED, HEAD_NO_LOGIT_TABLE = 1, 2
@@ -53,7 +53,7 @@ HEAD_STAGED, HEAD_NO_LOGIT_TABLE = 1, 2
 
 class ConvT(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int),
-                ('frag16', C.c_void_p), ('frag16_lo', C.c_void_p), ('frag', C.c_void_p)]
+                ('frag16', C.c_void_p), ('frag16_lo', C.c_void_p), ('frag', C.c_void_p), ('frag_wino', C.c_void_p)]
 
 
 class RdnWeightsT(C.Structure):

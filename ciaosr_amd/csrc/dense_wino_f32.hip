@@ -1,0 +1,278 @@
+// fp32 dense-block convolution for big maps in WINOGRAD form, F(2x2, 3x3) (round 3): the same 3x3 dense layer as dense_f32.hip
+// (mmedit RDB.layers[l].conv over cat(x, d_0 .. d_{l-1}), called from ciaosr_net.py:330-337) with 16 multiplies per 2x2 output tile and
+// (ci, co) pair instead of 36: 2.25x fewer MFMAs, and -- because a workgroup's 128 pixels are exactly one 32-row MFMA tile of
+// Winograd tiles -- none of the 160-for-144 row padding of the direct kernel (2.8x fewer MFMA cycles per pixel and input group).
+//
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A        g 3x3 weights, d the 4x4 input tile whose top-left is the output tile's (-1, -1)
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]      G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]      A^T = [1 1 1 0; 0 1 -1 -1]
+// fp32 throughout on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32); the transforms are additions (B, A) and host-side
+// pre-multiplication of the weights (G, in fp64, rounded once).  Not bitwise a direct fmaf chain: the products are of transformed
+// operands (error growth of F(2x2, 3x3) ~ 4x a direct convolution's rounding, measured against the oracle in the tests).
+//
+// Decomposition:
+//   * workgroup = 8 x 16 output pixels = 4 x 8 Winograd tiles = the 32 rows of one MFMA tile, x all 64 output channels;
+//   * wave i (of 4) owns row i of the 4x4 transformed domain: positions (i, 0..3) -> 4 positions x 2 channel halves = 8 accumulator
+//     tiles (128 registers); every wave runs the FULL K loop for its positions, so there is no K-slice reduction -- the only
+//     cross-wave step is the row half of the output transform (A^T along i), 64 KB through LDS once per layer;
+//   * the 10 x 18-pixel halo patch of one 64-channel input group (fp32, 46 KB, unpadded 256-B pixels whose sixteen 16-B chunks are
+//     XOR-swizzled with ((px >> 1) & 7) | (((py >> 1) & 1) << 3): the 16 lanes of a ds_read_b128 group -- tiles two pixels apart --
+//     hit 16 distinct bank quads for every (a, b) of the 4x4 window) is staged once per group, next group prefetched in registers;
+//   * per 8-channel step a wave reads the 2 x 4 window pixels its row needs (8 ds_read_b128), forms its four transformed values
+//     with 32 additions, and issues 32 MFMAs against 8 pre-packed 1-KB weight fragments from L2 (the transformed weights
+//     U[p] = (G g G^T)[p] as 16 separate [64][cin] matrices in ciaosr_pack_fragments_f32 order).
+#include "ops.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WTH = 8, WTW = 16;                 // output tile (pixels)
+constexpr int WPH = WTH + 2, WPW = WTW + 2;      // patch with the 1-pixel halo
+constexpr int WPATCH = WPH * WPW * 256;          // 46 080 B per buffer (64 fp32 per pixel, unpadded, chunk-swizzled)
+constexpr int WCHUNKS = WPH * WPW * 16;
+constexpr int WLOADS = (WCHUNKS + 255) / 256;    // 12
+constexpr size_t kWinoLds = 2 * (size_t)WPATCH;  // 92 160 B >= the 64-KB output-transform scratch
+constexpr unsigned kOobW = 0xFFFFFFF0u;
+
+struct DenseWinoP {
+    float* x; int ldx;
+    unsigned x_bytes;
+    int H, W, tiles_x;
+    int groups;
+    const float4* wf;                            // 16 fragment arrays [2][nj][64 lanes] float4, one per transformed position, back to back
+    int nj; long pos_stride;                     // nj = cin / 8; float4 per position array
+    const float* bias;
+    int col_out;
+};
+
+__device__ __forceinline__ int wino_swz(int py, int px) { return ((px >> 1) & 7) | (((py >> 1) & 1) << 3); }
+
+__global__ __launch_bounds__(256) void dense_wino_f32_kernel(DenseWinoP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsw[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    const int ty0 = (blockIdx.x / p.tiles_x) * WTH, tx0 = (blockIdx.x % p.tiles_x) * WTW;
+    const int img = blockIdx.y;
+    const unsigned img_off = (unsigned)((size_t)img * p.H * p.W * p.ldx * 4);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
+
+    // patch staging: thread -> 16-byte chunks t + 256 s (pixel = chunk / 16)
+    unsigned goff[WLOADS];
+    int loff[WLOADS];
+#pragma unroll
+    for (int s = 0; s < WLOADS; ++s) {
+        const int c = t + 256 * s;
+        const int px_ = c >> 4, part = c & 15;
+        const int py = px_ / WPW, pxx = px_ - py * WPW;
+        const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
+        const bool ok = c < WCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        goff[s] = ok ? (img_off + (unsigned)(gy * p.W + gx) * (unsigned)p.ldx * 4u + (unsigned)part * 16u) : kOobW;
+        loff[s] = c < WCHUNKS ? px_ * 256 + ((part ^ wino_swz(py, pxx)) << 4) : -1;
+    }
+    const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
+    auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
+    i32x4 P[WLOADS];
+    auto load_chunk = [&](int s, int g) {
+        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobW ? (int)kOobW : (int)(goff[s] + (unsigned)phys(g) * 256u), 0, 0);
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < WLOADS; ++s)
+            if (loff[s] >= 0) *reinterpret_cast<i32x4*>(ldsw + buf * WPATCH + loff[s]) = P[s];
+    };
+
+    // this lane's Winograd tile and the 2 x 4 window pixels row i of B^T d needs:  r_b = d[a1][b] + s2 d[a2][b]
+    //   i = 0: d0 - d2      i = 1: d1 + d2      i = 2: d2 - d1      i = 3: d1 - d3
+    const int tyw = li >> 3, txw = li & 7;
+    const int a1 = w == 0 ? 0 : (w == 2 ? 2 : 1), a2 = w == 0 ? 2 : (w == 1 ? 2 : (w == 2 ? 1 : 3));
+    const float s2 = w == 1 ? 1.f : -1.f;
+    int pbase[2][4], pswz[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int py = 2 * tyw + (r == 0 ? a1 : a2), px = 2 * txw + b;
+            pbase[r][b] = (py * WPW + px) * 256;
+            pswz[r][b] = wino_swz(py, px);
+        }
+    // weights: fragment (position 4 w + j, nt) of k-chunk jc = 8 g + jj
+    const float4* wl = p.wf + (size_t)(4 * w) * p.pos_stride + lane;
+    auto frag = [&](int j, int nt, int jc) -> float4 { return wl[(size_t)j * p.pos_stride + (size_t)(nt * p.nj + jc) * 64]; };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][nt][e] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < WLOADS; ++s) load_chunk(s, 0);
+    store_patch(0);
+    float4 w0[4][2], w1[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) w0[j][nt] = frag(j, nt, 8 * phys(0));
+    __syncthreads();
+
+    const int G = p.groups;
+    int pbuf = 0;
+    // Software pipeline over the 8-channel steps of a group: the window reads and the B^T d B transform of step jj + 1 are issued
+    // BETWEEN the four 8-MFMA blocks of step jj (one wave per SIMD: placed in front of its own MFMAs, the ~250-cycle LDS round trip
+    // and the ~80 VALU of the transform would sit exposed in front of every 2048-cycle MFMA block).  Only a group's first step
+    // (new patch buffer) pays them in the open.
+    auto load_d = [&](const unsigned char* pb, int jj, float4 (&d)[2][4]) {
+        const int ch = 2 * jj + lh;                                  // this lane's 16-B chunk: channels 8 jj + 4 lh .. + 3
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) d[r][b] = *reinterpret_cast<const float4*>(pb + pbase[r][b] + ((ch ^ pswz[r][b]) << 4));
+    };
+    auto rows = [&](const float4 (&d)[2][4], float4 (&r)[4]) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            r[b] = make_float4(d[0][b].x + s2 * d[1][b].x, d[0][b].y + s2 * d[1][b].y, d[0][b].z + s2 * d[1][b].z, d[0][b].w + s2 * d[1][b].w);
+    };
+    auto cols = [&](const float4 (&r)[4], float4 (&v)[4]) {
+        v[0] = make_float4(r[0].x - r[2].x, r[0].y - r[2].y, r[0].z - r[2].z, r[0].w - r[2].w);
+        v[1] = make_float4(r[1].x + r[2].x, r[1].y + r[2].y, r[1].z + r[2].z, r[1].w + r[2].w);
+        v[2] = make_float4(r[2].x - r[1].x, r[2].y - r[1].y, r[2].z - r[1].z, r[2].w - r[1].w);
+        v[3] = make_float4(r[1].x - r[3].x, r[1].y - r[3].y, r[1].z - r[3].z, r[1].w - r[3].w);
+    };
+    float4 v[2][4];                                                  // transformed inputs of the current / next step
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const bool more = g + 1 < G;
+        const unsigned char* pb = ldsw + pbuf * WPATCH;
+        {
+            float4 d[2][4], r[4];
+            load_d(pb, 0, d);
+            rows(d, r);
+            cols(r, v[0]);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            {   // weights of the next 8-channel step (a step is 32 MFMAs = 2048 cycles: one step of lookahead covers the L2 latency)
+                int jc = 8 * phys(g) + jj + 1;
+                bool have = true;
+                if (jj == 7) { have = more; jc = more ? 8 * phys(g + 1) : 0; }
+                if (have) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) w1[j][nt] = frag(j, nt, jc);
+                }
+            }
+            if (more) {                                              // next group's patch, spread over the steps
+                if (jj < WLOADS) load_chunk(jj, g + 1);
+                if (jj + 8 < WLOADS) load_chunk(jj + 8, g + 1);
+            }
+            float4 d[2][4], r[4];
+            if (jj < 7) load_d(pb, jj + 1, d);
+            __builtin_amdgcn_sched_barrier(0);                       // keep the requests at the top of the step (hipcc sinks them otherwise)
+            const float4 (&vc)[4] = v[jj & 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].x, vc[j].x, acc[j][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (jj < 7) rows(d, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].y, vc[j].y, acc[j][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (jj < 7) cols(r, v[(jj + 1) & 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].z, vc[j].z, acc[j][nt], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].w, vc[j].w, acc[j][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) w0[j][nt] = w1[j][nt];
+        }
+        if (more) {
+            store_patch(pbuf ^ 1);
+            pbuf ^= 1;
+        }
+        __syncthreads();
+    }
+
+    // Output transform.  Column half (A^T along j) in registers: t_x = m_0 + m_1 + m_2 (x = 0), m_1 - m_2 - m_3 (x = 1); row half
+    // (A^T along i = wave) through LDS in a fixed order: Y_0 = t[0] + t[1] + t[2], Y_1 = t[1] - t[2] - t[3].
+    //   red[i][x][nt][q][lane] = float4 of registers 4 q .. 4 q + 3 (channels 32 nt + 8 q + 4 lh .. + 3 of Winograd tile li)
+    float4* red = reinterpret_cast<float4*>(ldsw);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 t0, t1;
+            t0.x = acc[0][nt][4 * q] + acc[1][nt][4 * q] + acc[2][nt][4 * q];
+            t0.y = acc[0][nt][4 * q + 1] + acc[1][nt][4 * q + 1] + acc[2][nt][4 * q + 1];
+            t0.z = acc[0][nt][4 * q + 2] + acc[1][nt][4 * q + 2] + acc[2][nt][4 * q + 2];
+            t0.w = acc[0][nt][4 * q + 3] + acc[1][nt][4 * q + 3] + acc[2][nt][4 * q + 3];
+            t1.x = acc[1][nt][4 * q] - acc[2][nt][4 * q] - acc[3][nt][4 * q];
+            t1.y = acc[1][nt][4 * q + 1] - acc[2][nt][4 * q + 1] - acc[3][nt][4 * q + 1];
+            t1.z = acc[1][nt][4 * q + 2] - acc[2][nt][4 * q + 2] - acc[3][nt][4 * q + 2];
+            t1.w = acc[1][nt][4 * q + 3] - acc[2][nt][4 * q + 3] - acc[3][nt][4 * q + 3];
+            red[(((w * 2 + 0) * 2 + nt) * 4 + q) * 64 + lane] = t0;
+            red[(((w * 2 + 1) * 2 + nt) * 4 + q) * 64 + lane] = t1;
+        }
+    __syncthreads();
+    float* const xi = p.x + (size_t)img * p.H * p.W * p.ldx;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int unit = t + 256 * u;                  // (y, x, nt, q, lane): 2 x 2 x 2 x 4 x 64
+        const int ul = unit & 63, q = (unit >> 6) & 3, nt = (unit >> 8) & 1, xx = (unit >> 9) & 1, yy = unit >> 10;
+        auto rd = [&](int i) -> float4 { return red[(((i * 2 + xx) * 2 + nt) * 4 + q) * 64 + ul]; };
+        float4 v;
+        if (yy == 0) {
+            const float4 a = rd(0), b = rd(1), c = rd(2);
+            v = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
+        } else {
+            const float4 a = rd(1), b = rd(2), c = rd(3);
+            v = make_float4(a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w);
+        }
+        const int tl = ul & 31;
+        const int y = ty0 + 2 * (tl >> 3) + yy, x = tx0 + 2 * (tl & 7) + xx;
+        if (y < p.H && x < p.W) {
+            const int co = 32 * nt + 8 * q + 4 * (ul >> 5);
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+            v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
+            v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+            *reinterpret_cast<float4*>(xi + ((size_t)y * p.W + x) * p.ldx + p.col_out + co) = v;
+        }
+    }
+}
+
+int dense_wino_tiles(int H, int W) { return ceil_div(H, WTH) * ceil_div(W, WTW); }
+
+// dense layer l of a block in Winograd form; frag_wino = 16 fragment arrays of the transformed weights (encoder_hip.py packs them)
+int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino, const float* bias, int n_img, hipStream_t s) {
+    CIAOSR_CHECK_ARG(X && frag_wino && bias && (ldx & 3) == 0 && aligned16(X) && aligned16(frag_wino) && aligned16(bias));
+    const size_t x_bytes = (size_t)n_img * H * W * ldx * 4;
+    CIAOSR_CHECK_ARG(n_img >= 1 && n_img <= 65535 && x_bytes < 0xFFFFFF00ull);
+    DenseWinoP p;
+    p.x = X; p.ldx = ldx; p.x_bytes = (unsigned)x_bytes;
+    p.H = H; p.W = W; p.tiles_x = ceil_div(W, WTW);
+    p.groups = l + 1;
+    p.wf = reinterpret_cast<const float4*>(frag_wino);
+    p.nj = 64 * (l + 1) / 8;
+    p.pos_stride = (long)2 * p.nj * 64;
+    p.bias = bias;
+    p.col_out = 64 * (l + 1);
+    CIAOSR_BIG_LDS(dense_wino_f32_kernel, kWinoLds);
+    ProfScope prof("enc_dense_wino", s);
+    hipLaunchKernelGGL(dense_wino_f32_kernel, dim3(dense_wino_tiles(H, W), n_img), dim3(256), kWinoLds, s, p);
+    return launch_status("dense_wino_f32");
+}
+
+}  // namespace ciaosr

@@ -56,6 +56,9 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
 bool gemm_small_ok(int M, int N, int K, int lda, int ldw);
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,
                    const float* res, int ldres, int M, int N, int K, int act, float slope, float alpha, hipStream_t s, const char* tag);
+// dense_wino_f32.hip: fp32 dense layers of big maps in Winograd F(2x2, 3x3) form
+int dense_wino_tiles(int H, int W);
+int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino, const float* bias, int n_img, hipStream_t s);
 // conv1x1_f32.hip: weights-resident fp32 1x1 convolution to 64 channels (the RDB local feature fusion on big maps)
 bool conv1x1_resident_ok(long M, int N, int K, int ldx, int ldw);
 int conv1x1_resident_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res, int ldres, float* dst,

@@ -46,6 +46,20 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False, widen=None
     st.frag16 = None
     st.frag16_lo = None
     st.frag = None
+    st.frag_wino = None
+    if frag16 and kh == 3 and co == 64 and ci % 64 == 0:
+        # Winograd F(2x2, 3x3) form of the weights for the fp32 big-map kernel (dense_wino_f32.hip): U = G g G^T per (co, ci), in
+        # fp64, rounded once; position p = 4 i + j as its own [co][ci] matrix in MFMA fragment order, the 16 arrays back to back
+        Gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+        g = w.view(co, 3, 3, ci).double()                                   # [co][a][b][ci]
+        U = torch.einsum('ia,oabc,jb->ijoc', Gm, g, Gm).float().contiguous()     # [4][4][co][ci]
+        nfl = _lib.load().ciaosr_fragment_floats(co, ci)
+        fw = torch.empty(16 * nfl, dtype=torch.float32, device=w.device)
+        for pos in range(16):
+            up = U[pos // 4, pos % 4]
+            _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(up), ci, co, ci, C.c_void_p(fw.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
+        keep += [fw]                    # (U is read by the pack launches on this stream: stream-ordered reuse makes dropping it safe)
+        st.frag_wino = fw.data_ptr()
     if frag16:
         # bf16 MFMA fragments of the [cout][k*k*cin] matrix for the bf16 trunk mode (dense_h16.hip)
         n_, k_ = w.shape

@@ -78,6 +78,10 @@ typedef struct ciaosr_options {
                              * lo = bf16(w - hi): 16 mantissa bits, two MFMAs per product); 1 = hi only (one MFMA, 8 bits).
                              * Rounding WEIGHTS to 8 bits is a fixed perturbation whose response is spatially coherent and
                              * fails the 0.01 dB PSNR gate on smooth features; activations stay single bf16 */
+    int dense_direct;       /* _f32 RDN trunk, big maps: 0 (default) = dense layers in Winograd F(2x2, 3x3) form when ciaosr_conv_t.frag_wino
+                             * is given (fp32 arithmetic on transformed operands: not bitwise a direct convolution, within 1e-5 of it);
+                             * 1 = the direct halo-resident kernel (exact fmaf chains, 2.8x the MFMA cycles) */
+    int reserved[3];        /* must be 0 */
     int f16_pairs;          /* _f16 entries: 0 (default) = one IEEE-half weight per product; 1 = every dense-layer / head weight enters
                              * the MFMA as a half PAIR hi + lo (hi = half(w), lo = half(w - hi): ~20 mantissa bits, two MFMAs per product)
                              * and the layers the plain f16 mode runs with single 16-bit weights elsewhere (RDB local feature fusion,
@@ -294,6 +298,10 @@ typedef struct ciaosr_conv {
     const float* frag;   /* optional: ciaosr_pack_fragments_f32 of the same matrix; lets ciaosr_rdn_forward_f32 run the
                           * dense layers of maps with >= 128 tiles of 12x12 pixels through the halo-resident kernel, and any
                           * 3x3 trunk convolution of a map of <= 18432 pixels through the one-launch small-map kernel */
+    const float* frag_wino; /* optional (3x3, cout = 64, cin a multiple of 64): the Winograd F(2x2, 3x3) form of the weights,
+                          * U[p] = (G g G^T)[p], p = 4 i + j = 0..15, each [cout][cin] matrix packed by ciaosr_pack_fragments_f32, the 16
+                          * arrays back to back; lets ciaosr_rdn_forward_f32 run the dense layers of big maps with 2.25x fewer MFMAs
+                          * (dense_wino_f32.hip).  NULL = the direct halo-resident kernel (`frag`) */
 } ciaosr_conv_t;
 
 typedef struct ciaosr_rdn_weights {

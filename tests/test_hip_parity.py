@@ -492,11 +492,18 @@ def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw):
     gen = model.generator.to(dev)
     scatter = gen.gen_feature(x.to(dev))[0].cpu()
     with hip_ops.profile():
-        got = gen.gen_feature(x.to(dev), hip_ops.Options(dense_min_tiles=1))[0].cpu()
+        got = gen.gen_feature(x.to(dev), hip_ops.Options(dense_min_tiles=1, dense_direct=1))[0].cpu()
     assert 'enc_dense_gather' in hip_ops.profile.results(), 'halo-resident fp32 dense kernel did not run'
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() < 2e-4 * max(scale, 1.0), ((got - want).abs().max().item(), scale)
     assert (got - scatter).abs().max().item() < 2e-4 * max(scale, 1.0)
+    # the default big-map route: the same layers in Winograd F(2x2, 3x3) form (dense_wino_f32.hip; ragged 8x16 tiles here)
+    with hip_ops.profile():
+        wino = gen.gen_feature(x.to(dev), hip_ops.Options(dense_min_tiles=1))[0].cpu()
+    assert 'enc_dense_wino' in hip_ops.profile.results(), 'Winograd fp32 dense kernel did not run'
+    ew, ed = (wino - want).abs().max().item(), (got - want).abs().max().item()
+    print(f'rdn trunk {hw}: max|d| vs oracle: winograd {ew:.3e}, direct {ed:.3e} (scale {scale:.3f})')
+    assert ew < 2e-4 * max(scale, 1.0), (ew, scale)
     # third implementation of the same layers: the generic tap-major convolution in scatter form (conv_f32.hip)
     generic = gen.gen_feature(x.to(dev), hip_ops.Options(scatter_small_max=-1))[0].cpu()
     assert (generic - want).abs().max().item() < 2e-4 * max(scale, 1.0)
