@@ -113,6 +113,9 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'enc_dense_scatter': (dense, 'flop'),
         'enc_dense_bf16': (dense, 'flop16'),
         'enc_dense_gather': (dense, 'flop'),
+        # the same layers in Winograd F(2x2, 3x3) form: ALGORITHMIC flops are the direct convolution's (the kernel executes 1/2.25 of them,
+        # so its fraction of the fp32 MFMA peak on algorithmic work can exceed 1)
+        'enc_dense_wino': (dense, 'flop'),
         'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),
         # the blocks' local feature fusion in f16 mode: memory-bound (16-bit rows in, fp32 residual in, two fp32 + one 16-bit rows out)
         'enc_conv1x1_bf16': (blocks * HW * ((C + C * layers) * 2.0 + C * 4.0 + 2 * C * 4.0 + C * 2.0), 'byte'),
@@ -472,7 +475,7 @@ def main():
                           'head_kv_fused': 'head_kv_fused_kernel', 'head_fused': 'head_fused_kernel',
                           'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_h16_kernel',
                           'head_kv_fused_f16': 'head_kv_fused_h16_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
-                          'enc_dense_gather': 'dense_f32_kernel'}
+                          'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
                 pmc_path = os.path.join(REPO, 'profiles', f'r2_{unit}_pmc_hbm_traffic.json')
                 live_traffic = None

@@ -11,14 +11,14 @@
 //
 // Decomposition:
 //   * workgroup = 8 x 16 output pixels = 4 x 8 Winograd tiles = the 32 rows of one MFMA tile, x all 64 output channels;
-//   * wave i (of 4) owns row i of the 4x4 transformed domain: positions (i, 0..3) -> 4 positions x 2 channel halves = 8 accumulator
-//     tiles (128 registers); every wave runs the FULL K loop for its positions, so there is no K-slice reduction -- the only
+//   * 8 waves = 4 rows i of the 4x4 transformed domain x 2 output-channel halves: wave (i, nt) owns positions (i, 0..3) of its 32
+//     channels = 4 accumulator tiles (64 registers; two waves per SIMD); every wave runs the FULL K loop for its positions, so there is no K-slice reduction -- the only
 //     cross-wave step is the row half of the output transform (A^T along i), 64 KB through LDS once per layer;
 //   * the 10 x 18-pixel halo patch of one 64-channel input group (fp32, 46 KB, unpadded 256-B pixels whose sixteen 16-B chunks are
 //     XOR-swizzled with ((px >> 1) & 7) | (((py >> 1) & 1) << 3): the 16 lanes of a ds_read_b128 group -- tiles two pixels apart --
 //     hit 16 distinct bank quads for every (a, b) of the 4x4 window) is staged once per group, next group prefetched in registers;
 //   * per 8-channel step a wave reads the 2 x 4 window pixels its row needs (8 ds_read_b128), forms its four transformed values
-//     with 32 additions, and issues 32 MFMAs against 8 pre-packed 1-KB weight fragments from L2 (the transformed weights
+//     with 32 additions, and issues 16 MFMAs against 4 pre-packed 1-KB weight fragments from L2 (the transformed weights
 //     U[p] = (G g G^T)[p] as 16 separate [64][cin] matrices in ciaosr_pack_fragments_f32 order).
 #include "ops.h"
 
@@ -31,7 +31,7 @@ constexpr int WTH = 8, WTW = 16;                 // output tile (pixels)
 constexpr int WPH = WTH + 2, WPW = WTW + 2;      // patch with the 1-pixel halo
 constexpr int WPATCH = WPH * WPW * 256;          // 46 080 B per buffer (64 fp32 per pixel, unpadded, chunk-swizzled)
 constexpr int WCHUNKS = WPH * WPW * 16;
-constexpr int WLOADS = (WCHUNKS + 255) / 256;    // 12
+constexpr int WLOADS = (WCHUNKS + 511) / 512;    // 6 (512 threads)
 constexpr size_t kWinoLds = 2 * (size_t)WPATCH;  // 92 160 B >= the 64-KB output-transform scratch
 constexpr unsigned kOobW = 0xFFFFFFF0u;
 
@@ -48,20 +48,23 @@ struct DenseWinoP {
 
 __device__ __forceinline__ int wino_swz(int py, int px) { return ((px >> 1) & 7) | (((py >> 1) & 1) << 3); }
 
-__global__ __launch_bounds__(256) void dense_wino_f32_kernel(DenseWinoP p) {
+__global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsw[];
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    // 8 waves = 4 rows i of the transformed domain x 2 output-channel halves: two waves per SIMD cover each other's LDS round trips,
+    // transform VALU and weight waits (the window reads and the transform are done by both waves of a row: LDS and VALU have the room)
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    const int w = wv & 3, nth = wv >> 2;
     const int ty0 = (blockIdx.x / p.tiles_x) * WTH, tx0 = (blockIdx.x % p.tiles_x) * WTW;
     const int img = blockIdx.y;
     const unsigned img_off = (unsigned)((size_t)img * p.H * p.W * p.ldx * 4);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
 
-    // patch staging: thread -> 16-byte chunks t + 256 s (pixel = chunk / 16)
+    // patch staging: thread -> 16-byte chunks t + 512 s (pixel = chunk / 16)
     unsigned goff[WLOADS];
     int loff[WLOADS];
 #pragma unroll
     for (int s = 0; s < WLOADS; ++s) {
-        const int c = t + 256 * s;
+        const int c = t + 512 * s;
         const int px_ = c >> 4, part = c & 15;
         const int py = px_ / WPW, pxx = px_ - py * WPW;
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
@@ -97,24 +100,20 @@ __global__ __launch_bounds__(256) void dense_wino_f32_kernel(DenseWinoP p) {
         }
     // weights: fragment (position 4 w + j, nt) of k-chunk jc = 8 g + jj
     const float4* wl = p.wf + (size_t)(4 * w) * p.pos_stride + lane;
-    auto frag = [&](int j, int nt, int jc) -> float4 { return wl[(size_t)j * p.pos_stride + (size_t)(nt * p.nj + jc) * 64]; };
+    auto frag = [&](int j, int jc) -> float4 { return wl[(size_t)j * p.pos_stride + (size_t)(nth * p.nj + jc) * 64]; };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[j][nt][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
 #pragma unroll
     for (int s = 0; s < WLOADS; ++s) load_chunk(s, 0);
     store_patch(0);
-    float4 w0[4][2], w1[4][2];
+    float4 w0[4], w1[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) w0[j][nt] = frag(j, nt, 8 * phys(0));
+    for (int j = 0; j < 4; ++j) w0[j] = frag(j, 8 * phys(0));
     __syncthreads();
 
     const int G = p.groups;
@@ -160,44 +159,31 @@ __global__ __launch_bounds__(256) void dense_wino_f32_kernel(DenseWinoP p) {
                 if (jj == 7) { have = more; jc = more ? 8 * phys(g + 1) : 0; }
                 if (have) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) w1[j][nt] = frag(j, nt, jc);
+                    for (int j = 0; j < 4; ++j) w1[j] = frag(j, jc);
                 }
             }
             if (more) {                                              // next group's patch, spread over the steps
                 if (jj < WLOADS) load_chunk(jj, g + 1);
-                if (jj + 8 < WLOADS) load_chunk(jj + 8, g + 1);
             }
             float4 d[2][4], r[4];
             if (jj < 7) load_d(pb, jj + 1, d);
             __builtin_amdgcn_sched_barrier(0);                       // keep the requests at the top of the step (hipcc sinks them otherwise)
             const float4 (&vc)[4] = v[jj & 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].x, vc[j].x, acc[j][nt], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].x, vc[j].x, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (jj < 7) rows(d, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].y, vc[j].y, acc[j][nt], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].y, vc[j].y, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (jj < 7) cols(r, v[(jj + 1) & 1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].z, vc[j].z, acc[j], 0, 0, 0);
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].z, vc[j].z, acc[j][nt], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j][nt].w, vc[j].w, acc[j][nt], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].w, vc[j].w, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) w0[j][nt] = w1[j][nt];
+            for (int j = 0; j < 4; ++j) w0[j] = w1[j];
         }
         if (more) {
             store_patch(pbuf ^ 1);
@@ -210,27 +196,28 @@ __global__ __launch_bounds__(256) void dense_wino_f32_kernel(DenseWinoP p) {
     // (A^T along i = wave) through LDS in a fixed order: Y_0 = t[0] + t[1] + t[2], Y_1 = t[1] - t[2] - t[3].
     //   red[i][x][nt][q][lane] = float4 of registers 4 q .. 4 q + 3 (channels 32 nt + 8 q + 4 lh .. + 3 of Winograd tile li)
     float4* red = reinterpret_cast<float4*>(ldsw);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    {
+        const int nt = nth;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 t0, t1;
-            t0.x = acc[0][nt][4 * q] + acc[1][nt][4 * q] + acc[2][nt][4 * q];
-            t0.y = acc[0][nt][4 * q + 1] + acc[1][nt][4 * q + 1] + acc[2][nt][4 * q + 1];
-            t0.z = acc[0][nt][4 * q + 2] + acc[1][nt][4 * q + 2] + acc[2][nt][4 * q + 2];
-            t0.w = acc[0][nt][4 * q + 3] + acc[1][nt][4 * q + 3] + acc[2][nt][4 * q + 3];
-            t1.x = acc[1][nt][4 * q] - acc[2][nt][4 * q] - acc[3][nt][4 * q];
-            t1.y = acc[1][nt][4 * q + 1] - acc[2][nt][4 * q + 1] - acc[3][nt][4 * q + 1];
-            t1.z = acc[1][nt][4 * q + 2] - acc[2][nt][4 * q + 2] - acc[3][nt][4 * q + 2];
-            t1.w = acc[1][nt][4 * q + 3] - acc[2][nt][4 * q + 3] - acc[3][nt][4 * q + 3];
+            t0.x = acc[0][4 * q] + acc[1][4 * q] + acc[2][4 * q];
+            t0.y = acc[0][4 * q + 1] + acc[1][4 * q + 1] + acc[2][4 * q + 1];
+            t0.z = acc[0][4 * q + 2] + acc[1][4 * q + 2] + acc[2][4 * q + 2];
+            t0.w = acc[0][4 * q + 3] + acc[1][4 * q + 3] + acc[2][4 * q + 3];
+            t1.x = acc[1][4 * q] - acc[2][4 * q] - acc[3][4 * q];
+            t1.y = acc[1][4 * q + 1] - acc[2][4 * q + 1] - acc[3][4 * q + 1];
+            t1.z = acc[1][4 * q + 2] - acc[2][4 * q + 2] - acc[3][4 * q + 2];
+            t1.w = acc[1][4 * q + 3] - acc[2][4 * q + 3] - acc[3][4 * q + 3];
             red[(((w * 2 + 0) * 2 + nt) * 4 + q) * 64 + lane] = t0;
             red[(((w * 2 + 1) * 2 + nt) * 4 + q) * 64 + lane] = t1;
         }
+    }
     __syncthreads();
     float* const xi = p.x + (size_t)img * p.H * p.W * p.ldx;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int unit = t + 256 * u;                  // (y, x, nt, q, lane): 2 x 2 x 2 x 4 x 64
+    for (int u = 0; u < 4; ++u) {
+        const int unit = t + 512 * u;                  // (y, x, nt, q, lane): 2 x 2 x 2 x 4 x 64
         const int ul = unit & 63, q = (unit >> 6) & 3, nt = (unit >> 8) & 1, xx = (unit >> 9) & 1, yy = unit >> 10;
         auto rd = [&](int i) -> float4 { return red[(((i * 2 + xx) * 2 + nt) * 4 + q) * 64 + ul]; };
         float4 v;
@@ -271,7 +258,7 @@ int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* fr
     p.col_out = 64 * (l + 1);
     CIAOSR_BIG_LDS(dense_wino_f32_kernel, kWinoLds);
     ProfScope prof("enc_dense_wino", s);
-    hipLaunchKernelGGL(dense_wino_f32_kernel, dim3(dense_wino_tiles(H, W), n_img), dim3(256), kWinoLds, s, p);
+    hipLaunchKernelGGL(dense_wino_f32_kernel, dim3(dense_wino_tiles(H, W), n_img), dim3(512), kWinoLds, s, p);
     return launch_status("dense_wino_f32");
 }
 

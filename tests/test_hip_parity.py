@@ -671,7 +671,7 @@ def _tile192_checks(out, fx, tol):
     return errs
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16-single', 'f16', 'f16-pairs'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp32-direct', 'bf16', 'bf16-single', 'f16', 'f16-pairs'])
 def test_e2e_full_c3_tile_vs_reference(dev, precision):
     """One full C3 tile: 192x192 LR -> 768x768 through CiaoSR.forward_test (clip_test with one tile; RDN trunk on the
     halo-resident dense kernels, cs_attn on the composed tail, 589 824 queries = 20 reference eval_bsize chunks) against
@@ -703,14 +703,14 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     assert sha == str(fx['sha'])
     model = model.to(dev)
     lq, gt = synthetic_pair(192, 192, 4)
-    opt = {'fp32': hip_ops.Options('fp32'), 'bf16': hip_ops.Options('bf16'),
+    opt = {'fp32': hip_ops.Options('fp32'), 'fp32-direct': hip_ops.Options('fp32', dense_direct=1), 'bf16': hip_ops.Options('bf16'),
            'bf16-single': hip_ops.Options('bf16', bf16_single=1), 'f16': hip_ops.Options('f16'),
            'f16-pairs': hip_ops.Options('f16-pairs')}[precision]
     with hip_ops.profile():
         out = model.restore(lq.to(dev), options=opt).cpu()
     prof = hip_ops.profile.results()
-    if precision == 'fp32':
-        for tag in ('enc_dense_gather', 'csa_attn_v_edge', 'head_logit_table'):
+    if precision in ('fp32', 'fp32-direct'):
+        for tag in ('enc_dense_wino' if precision == 'fp32' else 'enc_dense_gather', 'csa_attn_v_edge', 'head_logit_table'):
             assert tag in prof, (tag, sorted(prof))
     else:
         sfx = '_f16' if precision.startswith('f16') else '_bf16'
@@ -733,7 +733,7 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     d_psnr30 = abs(psnr30(got_s4) - psnr30(ref_s4))
     print(f'tile192 {precision}: max|d| {errs}, rms|d| {rms:.3e}, PSNR(build,GT) {psnr_build:.4f} vs ref {float(fx["psnr_ref_gt"]):.4f} '
           f'(delta {d_psnr:.5f} dB), at 30 dB: PSNR(ref,GT\') {psnr30(ref_s4):.3f}, delta {d_psnr30:.5f} dB, |mean delta| {mean_err:.2e}')
-    if precision == 'fp32':
+    if precision in ('fp32', 'fp32-direct'):        # default = Winograd dense layers; 'fp32-direct' = the direct kernel (dense_direct=1)
         assert d_psnr <= 0.01 and d_psnr30 <= 0.001, (d_psnr, d_psnr30)
         assert max(errs.values()) < NORTH_STAR_TOL, errs
         assert mean_err < 1e-5 and rms < 1e-5, (mean_err, rms)
@@ -840,7 +840,7 @@ def test_encoder_batch_beyond_32bit_offsets_runs_as_sub_batches(dev, precision):
     x = (randn((8, 3, 368, 368), 5) * 0.25).to(dev)
     with hip_ops.profile():
         feats = enc.forward_hwc_batch(x, opt)
-    assert ('enc_dense_gather' if precision == 'fp32' else 'enc_dense_f16') in hip_ops.profile.results()
+    assert ('enc_dense_wino' if precision == 'fp32' else 'enc_dense_f16') in hip_ops.profile.results()
     assert feats.shape == (8, 368, 368, 64) and bool(torch.isfinite(feats).all())
     for i in (0, 6, 7):
         assert torch.equal(feats[i], enc.forward_hwc(x[i], opt)), i
