@@ -16,7 +16,7 @@
 //     cross-wave step is the row half of the output transform (A^T along i), 64 KB through LDS once per layer;
 //   * the 10 x 18-pixel halo patch of one 64-channel input group (fp32, 46 KB, unpadded 256-B pixels whose sixteen 16-B chunks are
 //     XOR-swizzled with ((px >> 1) & 7) | (((py >> 1) & 1) << 3): the 16 lanes of a ds_read_b128 group -- tiles two pixels apart --
-//     hit 16 distinct bank quads for every (a, b) of the 4x4 window) is staged once per group, next group prefetched in registers;
+//     hit 16 distinct bank quads for every (a, b) of the 4x4 window) is staged once per group by LDS-DMA into the other of two buffers;
 //   * per 8-channel step a wave reads the 2 x 4 window pixels its row needs (8 ds_read_b128), forms its four transformed values
 //     with 32 additions, and issues 16 MFMAs against 4 pre-packed 1-KB weight fragments from L2 (the transformed weights
 //     U[p] = (G g G^T)[p] as 16 separate [64][cin] matrices in ciaosr_pack_fragments_f32 order).
@@ -31,7 +31,6 @@ constexpr int WTH = 8, WTW = 16;                 // output tile (pixels)
 constexpr int WPH = WTH + 2, WPW = WTW + 2;      // patch with the 1-pixel halo
 constexpr int WPATCH = WPH * WPW * 256;          // 46 080 B per buffer (64 fp32 per pixel, unpadded, chunk-swizzled)
 constexpr int WCHUNKS = WPH * WPW * 16;
-constexpr int WLOADS = (WCHUNKS + 511) / 512;    // 6 (512 threads)
 constexpr size_t kWinoLds = 2 * (size_t)WPATCH;  // 92 160 B >= the 64-KB output-transform scratch
 constexpr unsigned kOobW = 0xFFFFFFF0u;
 
@@ -59,29 +58,34 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
     const unsigned img_off = (unsigned)((size_t)img * p.H * p.W * p.ldx * 4);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
 
-    // patch staging: thread -> 16-byte chunks t + 512 s (pixel = chunk / 16)
-    unsigned goff[WLOADS];
-    int loff[WLOADS];
+    // patch staging by LDS-DMA (`buffer_load_dwordx4 ... lds`, no staging registers): piece i = wv + 8 s (i < 45) fills LDS bytes
+    // [1024 i, 1024 i + 1024) of a patch buffer; lane -> LDS chunk c = 64 i + lane = (pixel c / 16, slot c % 16), which holds the
+    // pixel's channel chunk slot ^ swz(py, px) (the swizzle goes on the SOURCE address: a DMA writes lane-contiguous bytes);
+    // out-of-image halo pixels are out-of-range offsets, written as zeros
+    constexpr int WPIECES = WCHUNKS / 64;            // 45
+    constexpr int WDS = (WPIECES + 7) / 8;           // 6 per wave
+    unsigned goff[WDS];
 #pragma unroll
-    for (int s = 0; s < WLOADS; ++s) {
-        const int c = t + 512 * s;
-        const int px_ = c >> 4, part = c & 15;
+    for (int s = 0; s < WDS; ++s) {
+        const int c = 64 * (wv + 8 * s) + lane;
+        const int px_ = c >> 4, slot = c & 15;
         const int py = px_ / WPW, pxx = px_ - py * WPW;
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
-        const bool ok = c < WCHUNKS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        goff[s] = ok ? (img_off + (unsigned)(gy * p.W + gx) * (unsigned)p.ldx * 4u + (unsigned)part * 16u) : kOobW;
-        loff[s] = c < WCHUNKS ? px_ * 256 + ((part ^ wino_swz(py, pxx)) << 4) : -1;
+        const bool ok = px_ < WPH * WPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        goff[s] = ok ? (img_off + (unsigned)(gy * p.W + gx) * (unsigned)p.ldx * 4u + (unsigned)(slot ^ wino_swz(py, pxx)) * 16u) : kOobW;
     }
     const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
     auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
-    i32x4 P[WLOADS];
-    auto load_chunk = [&](int s, int g) {
-        P[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, goff[s] == kOobW ? (int)kOobW : (int)(goff[s] + (unsigned)phys(g) * 256u), 0, 0);
-    };
-    auto store_patch = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < WLOADS; ++s)
-            if (loff[s] >= 0) *reinterpret_cast<i32x4*>(ldsw + buf * WPATCH + loff[s]) = P[s];
+    const i32x4 desc = {(int)(unsigned)(size_t)p.x, (int)(((size_t)p.x >> 32) & 0xFFFFu), (int)p.x_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ldsw;
+    auto dma_piece = [&](int s, int buf, int g) {
+        if (wv + 8 * s < WPIECES) {                  // wave-uniform
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * WPATCH) + 1024u * (unsigned)(wv + 8 * s));
+            const unsigned voff = goff[s] == kOobW ? kOobW : goff[s] + (unsigned)phys(g) * 256u;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(desc) : "memory");
+        }
     };
 
     // this lane's Winograd tile and the 2 x 4 window pixels row i of B^T d needs:  r_b = d[a1][b] + s2 d[a2][b]
@@ -109,12 +113,17 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 
 #pragma unroll
-    for (int s = 0; s < WLOADS; ++s) load_chunk(s, 0);
-    store_patch(0);
-    float4 w0[4], w1[4];
+    for (int s = 0; s < WDS; ++s) dma_piece(s, 0, 0);
+    // weight ring of 4 steps indexed by jj % 4 (8 % 4 == 0: static indices), requested WPF steps ahead
+    constexpr int WPF = 2;
+    float4 wr[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w0[j] = frag(j, 8 * phys(0));
-    __syncthreads();
+    for (int s0 = 0; s0 < WPF; ++s0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[s0][j] = frag(j, 8 * phys(0) + s0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
 
     const int G = p.groups;
     int pbuf = 0;
@@ -153,43 +162,43 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
         }
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            {   // weights of the next 8-channel step (a step is 32 MFMAs = 2048 cycles: one step of lookahead covers the L2 latency)
-                int jc = 8 * phys(g) + jj + 1;
+            if (more && jj < WDS) dma_piece(jj, pbuf ^ 1, g + 1);      // next group's patch, one piece per step, BEFORE this step's weight
+                                                                         // requests (vmcnt retires in order: they give it two steps to land)
+            {   // weights WPF steps ahead (a step is 16 MFMAs of this wave = 2048 cycles of the shared pipe; every workgroup of the
+                // launch walks the same fragments, so the L2 round trip under load is longer than one step)
+                int jc = 8 * phys(g) + jj + WPF;
                 bool have = true;
-                if (jj == 7) { have = more; jc = more ? 8 * phys(g + 1) : 0; }
+                if (jj + WPF >= 8) { have = more; jc = more ? 8 * phys(g + 1) + jj + WPF - 8 : 0; }
                 if (have) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w1[j] = frag(j, jc);
+                    for (int j = 0; j < 4; ++j) wr[(jj + WPF) & 3][j] = frag(j, jc);
                 }
-            }
-            if (more) {                                              // next group's patch, spread over the steps
-                if (jj < WLOADS) load_chunk(jj, g + 1);
             }
             float4 d[2][4], r[4];
             if (jj < 7) load_d(pb, jj + 1, d);
             __builtin_amdgcn_sched_barrier(0);                       // keep the requests at the top of the step (hipcc sinks them otherwise)
             const float4 (&vc)[4] = v[jj & 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].x, vc[j].x, acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[jj & 3][j].x, vc[j].x, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (jj < 7) rows(d, r);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].y, vc[j].y, acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[jj & 3][j].y, vc[j].y, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (jj < 7) cols(r, v[(jj + 1) & 1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].z, vc[j].z, acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[jj & 3][j].z, vc[j].z, acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[j].w, vc[j].w, acc[j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[jj & 3][j].w, vc[j].w, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) w0[j] = w1[j];
         }
         if (more) {
-            store_patch(pbuf ^ 1);
+            // every DMA piece of the next patch is older than the last 2 x 4 weight requests of this wave
+            asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * WPF) : "memory");
             pbuf ^= 1;
         }
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // Output transform.  Column half (A^T along j) in registers: t_x = m_0 + m_1 + m_2 (x = 0), m_1 - m_2 - m_3 (x = 1); row half
