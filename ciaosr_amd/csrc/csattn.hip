@@ -112,9 +112,15 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     if (sc == 2) RUN(avgpool2(xp, p.Hp, p.Wp, C, x2, s));
     else RUN(downsample(xp, p.Hp, p.Wp, C, sc, x2, s));
     RUN(conv1x1(x2, w->w_match2, w->b_match2, w->slope_match2, R, p.Ch, p.L));
-    RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
-    RUN(patch_rows(R, p.Ch, p.Hp / sc, p.Wp / sc, p.Ch, 3, 1, 1, p.Hp / sc, p.Wp / sc, Kn, 9 * p.Ch, 1, w->escape_nan, s,
-                   "csa_patch_k"));
+    // fp32: the correlation scores as a 3x3 diagonal box sum of the per-pixel correlation (csa_scores_f32.hip: K = 32 instead of 288,
+    // no patch rows at all) -- per-call option csa_scores_gemm = 1 keeps the patch-row GEMM
+    const bool box_scores = prec == kF32 && !(opt && opt->csa_scores_gemm) && csa_scores_box_ok(p.Ch, p.Ch, p.Ch) &&
+                            (size_t)p.L <= p.n_Kn;
+    if (!box_scores) {
+        RUN(patch_rows(M, p.Ch, p.Hp, p.Wp, p.Ch, 3, 1, 1, p.Hp, p.Wp, Qp, 9 * p.Ch, 0, 0.f, s, "csa_patch_q"));
+        RUN(patch_rows(R, p.Ch, p.Hp / sc, p.Wp / sc, p.Ch, 3, 1, 1, p.Hp / sc, p.Wp / sc, Kn, 9 * p.Ch, 1, w->escape_nan, s,
+                       "csa_patch_k"));
+    }
     // composed fold+down tail from this many (padded) LR pixels on: per-call option, default 4096
     const int composed_min = opt && opt->csa_composed_min ? opt->csa_composed_min : 4096;
     const bool composed = sc == 2 && w->w_down_masked && composed_min > 0 && HWp >= composed_min;     // the composed tail is scale 2's
@@ -165,8 +171,12 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
         RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 16L * C, 4L * C, 4L * C, s));
         return CIAOSR_OK;
     }
-    RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
-                 CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
+    if (box_scores)
+        RUN(csa_scores_box_f32(M, p.Ch, p.Hp, p.Wp, R, p.Ch, p.Hp / sc, p.Wp / sc, p.Ch, w->softmax_scale, w->escape_nan, Kn /*norms*/, S,
+                               p.Lld, s));
+    else
+        RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
+                     CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
     RUN(softmax_rows(S, HWp, p.L, p.Lld, s));
     if (composed) {
         // composed fold + down (patch_ops.hip): attn.V with N = 16C instead of 36C, no 2x map, no separate down conv

@@ -59,6 +59,10 @@ int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float
 // dense_wino_f32.hip: fp32 dense layers of big maps in Winograd F(2x2, 3x3) form
 int dense_wino_tiles(int H, int W);
 int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino, const float* bias, int n_img, hipStream_t s);
+// csa_scores_f32.hip: fp32 cs_attn correlation scores as a 3x3 diagonal box sum of the per-pixel correlation (Ch = 32)
+bool csa_scores_box_ok(int Ch, int ldm, int ldr);
+int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, int ldr, int Hl, int Wl, int Ch, float alpha, float floor_,
+                       float* nrm, float* S, int ld_s, hipStream_t s);
 // conv1x1_f32.hip: weights-resident fp32 1x1 convolution to 64 channels (the RDB local feature fusion on big maps)
 bool conv1x1_resident_ok(long M, int N, int K, int ldx, int ldw);
 int conv1x1_resident_f32(const float* X, int ldx, const float* W, int ldw, const float* bias, const float* res, int ldres, float* dst,

@@ -81,7 +81,9 @@ typedef struct ciaosr_options {
     int dense_direct;       /* _f32 RDN trunk, big maps: 0 (default) = dense layers in Winograd F(2x2, 3x3) form when ciaosr_conv_t.frag_wino
                              * is given (fp32 arithmetic on transformed operands: not bitwise a direct convolution, within 1e-5 of it);
                              * 1 = the direct halo-resident kernel (exact fmaf chains, 2.8x the MFMA cycles) */
-    int reserved[3];        /* must be 0 */
+    int csa_scores_gemm;    /* _f32 cs_attn with 32 match channels: 0 (default) = correlation scores as a 3x3 diagonal box sum of the
+                             * per-pixel correlation (K = 32, no patch rows); 1 = the 288-wide patch-row GEMM.  Same fp32 products, other order */
+    int reserved[2];        /* must be 0 */
     int f16_pairs;          /* _f16 entries: 0 (default) = one IEEE-half weight per product; 1 = every dense-layer / head weight enters
                              * the MFMA as a half PAIR hi + lo (hi = half(w), lo = half(w - hi): ~20 mantissa bits, two MFMAs per product)
                              * and the layers the plain f16 mode runs with single 16-bit weights elsewhere (RDB local feature fusion,
