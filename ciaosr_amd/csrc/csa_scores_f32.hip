@@ -3,12 +3,11 @@
 //
 //   S[p][l] = alpha n_l sum_{a,b in {-1,0,1}} D[p + (a,b)][l + (a,b)],      D[p'][l'] = <M[p'], R[l']>  (C/2 = 32 channels)
 // (zero outside either map; n_l = 1 / max(|3x3 patch of R at l|, floor)): the patch correlation is a 3x3 DIAGONAL BOX SUM of a
-// per-pixel correlation with K = 32 instead of K = 288.  A workgroup owns 8x16 query pixels x 8x16 key pixels = 128 x 128 scores:
-//   A. D over the two halos (180 x 180, padded to 192 x 192 = 6 x 6 MFMA tiles of K = 32: 9.2k MFMA cycles per wave against the
-//      42k of the 128 x 128 x 288 GEMM tile) on the exact-fp32 MFMA, operands straight from L2 one tile ahead, into LDS
-//      ([180][185] fp32, 133 KB: one workgroup per CU);
-//   B. every thread box-sums 64 scores out of LDS (9 reads + 8 adds each; lanes along l: conflict-free rows), scales and stores.
-// 4.5x fewer flops than the GEMM (halo recomputation included), the same fp32 products summed in a different order.
+// per-pixel correlation with K = 32 instead of K = 288.  An item = 8x16 query pixels x 4x16 key pixels = 128 x 64 scores:
+//   A. D over the two halos (180 x 108, padded to 6 x 4 MFMA tiles of K = 32) on the exact-fp32 MFMA into LDS ([180][109] fp32);
+//   B. every thread box-sums 32 scores out of LDS (9 reads + 8 adds each; lanes along l: conflict-free rows), scales and stores.
+// A and B of consecutive items overlap: producer and consumer waves, two D buffers (kernel comment).  3.4x fewer flops than the GEMM
+// (halo recomputation and tile padding included), the same fp32 products summed in a different order.
 // Replaces csa_patch_q + csa_patch_k + the csa_scores GEMM of the fp32 path for Ch = 32.
 #include "ops.h"
 
@@ -17,11 +16,14 @@ namespace ciaosr {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BSH = 8, BSW = 16;               // block of pixels (both maps)
-constexpr int BHH = BSH + 2, BHW = BSW + 2;    // with the 1-pixel halo: 10 x 18 = 180
-constexpr int BHN = BHH * BHW;                 // 180
-constexpr int BDP = 185;                       // D row pitch in floats (odd: column-wise accumulator writes spread over the banks)
-constexpr size_t kBoxLds = (size_t)BHN * BDP * 4;      // 133 200 B
+constexpr int BSH = 8, BSW = 16;               // block of query pixels
+constexpr int BLH = 4, BLW = 16;               // block of key pixels
+constexpr int BHW = BSW + 2;                   // halo row width of both blocks (18)
+constexpr int BPN = (BSH + 2) * BHW;           // 180 query halo pixels (6 MFMA row tiles)
+constexpr int BLN = (BLH + 2) * BHW;           // 108 key halo pixels (4 MFMA column tiles)
+constexpr int BDP = 109;                       // D row pitch in floats (odd: column-wise accumulator writes spread over the banks)
+constexpr int BDB = BPN * BDP * 4;             // bytes of one D buffer (78 480)
+constexpr size_t kBoxLds = 2 * (size_t)BDB;    // two buffers: 156 960 B, one 512-thread workgroup per CU
 constexpr unsigned kOobB = 0xFFFFFFF0u;
 
 struct BoxP {
@@ -29,7 +31,7 @@ struct BoxP {
     const float* R; int ldr; unsigned r_bytes; int Hl, Wl;      // key map [Hl*Wl][ldr]
     const float* nrm;                                            // [Hl*Wl] alpha / max(patch norm, floor)
     float* S; int lds_;                                          // [Hp*Wp][lds_]
-    int pbx, lbx, n_lb;                                          // blocks per row of each map, key blocks in total
+    int pbx, lbx, n_lb, n_items;                                 // blocks per row of each map, key blocks in total, (query, key) block pairs
 };
 
 // alpha / max(|3x3 patch|, floor) of every key pixel (zero padding)
@@ -53,84 +55,122 @@ __global__ void csa_key_norms_kernel(const float* __restrict__ R, int ldr, int H
     if (lane == 0) nrm[l] = alpha / fmaxf(sqrtf(ss), floor_);
 }
 
-__global__ __launch_bounds__(256) void csa_scores_box_f32_kernel(BoxP p) {
-    extern __shared__ __attribute__((aligned(16))) float Dl[];          // [BHN][BDP]
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
-    const int pb = blockIdx.x / p.n_lb, lb = blockIdx.x - pb * p.n_lb;   // key blocks fastest: a query block's M rows stay in L2
-    const int py0 = (pb / p.pbx) * BSH, px0 = (pb % p.pbx) * BSW;
-    const int ly0 = (lb / p.lbx) * BSH, lx0 = (lb % p.lbx) * BSW;
-    const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.M), 0, p.m_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
+// PERSISTENT, wave-specialised: a workgroup walks a contiguous run of (query block, key block) items.  Waves 0..3 (one per SIMD)
+// PRODUCE the D block of item i + 1 on the MFMA into one LDS buffer while waves 4..7 CONSUME item i from the other: box sums, scale,
+// store.  MFMA work and LDS / VALU work overlap inside the CU; one barrier per item.  A producer wave owns one 32-column key tile
+// and keeps the SIX query-halo operand tiles in registers for as long as the query block does not change (144 key blocks per query
+// block on the 192x192 tile), so an item costs it four 16-byte loads and 96 MFMAs.
+__global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
+    extern __shared__ __attribute__((aligned(16))) float Dl[];          // [2][BPN][BDP]
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    const int per = (p.n_items + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = (int)blockIdx.x * per, i1 = min(i0 + per, p.n_items);
+    if (i0 >= i1) return;
+    auto item_pb = [&](int it) -> int { return it / p.n_lb; };
+    auto item_lb = [&](int it) -> int { return it - (it / p.n_lb) * p.n_lb; };
 
-    // ---- A: D tiles.  Halo index h = hy * 18 + hx -> map pixel (y0 - 1 + hy, x0 - 1 + hx), zero (out-of-range offset) outside.
-    // Operand fragments (32 rows x 32 channels): lane (li, lh) holds channels 8 j + 4 lh .. + 3, j = 0..3 -- the k index inside a
-    // fragment may be permuted consistently on both operands.  Tile t = w + 4 k (k < 9): (query tile t / 6, key tile t % 6).
-    auto row_off = [&](int h, int y0, int x0, int Hh, int Ww, int ld) -> unsigned {
-        const int hy = h / BHW, hx = h - hy * BHW;
-        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
-        return (h < BHN && y >= 0 && y < Hh && x >= 0 && x < Ww) ? (unsigned)(((size_t)y * Ww + x) * ld * 4) + (unsigned)lh * 16u : kOobB;
-    };
-    auto load_tile = [&](int tl, i32x4 (&fa)[4], i32x4 (&fb)[4]) {
-        const int pt = tl / 6, lt = tl - pt * 6;
-        const unsigned mo = row_off(32 * pt + li, py0, px0, p.Hp, p.Wp, p.ldm);
-        const unsigned ro = row_off(32 * lt + li, ly0, lx0, p.Hl, p.Wl, p.ldr);
+    if (wv < 4) {
+        // ---- producers.  Halo index h = hy * 18 + hx -> map pixel (y0 - 1 + hy, x0 - 1 + hx), zero (out-of-range offset) outside.
+        // Operand fragments (32 rows x 32 channels): lane (li, lh) holds channels 8 j + 4 lh .. + 3, j = 0..3 -- the k index inside a
+        // fragment may be permuted consistently on both operands.
+        const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.M), 0, p.m_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.R), 0, p.r_bytes, 0x00020000);
+        auto row_off = [&](int h, int hn, int y0, int x0, int Hh, int Ww, int ld) -> unsigned {
+            const int hy = h / BHW, hx = h - hy * BHW;
+            const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+            return (h < hn && y >= 0 && y < Hh && x >= 0 && x < Ww) ? (unsigned)(((size_t)y * Ww + x) * ld * 4) + (unsigned)lh * 16u : kOobB;
+        };
+        i32x4 fa[6][4];                                              // query-halo tiles: resident per query block
+        i32x4 fbc[4], fbn[4];                                        // this wave's key-halo tile of the current / next item
+        auto load_a = [&](int pb) {
+            const int py0 = (pb / p.pbx) * BSH, px0 = (pb % p.pbx) * BSW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            fa[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, mo == kOobB ? (int)kOobB : (int)(mo + 32u * j), 0, 0);
-            fb[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro == kOobB ? (int)kOobB : (int)(ro + 32u * j), 0, 0);
-        }
-    };
-    i32x4 fa[2][4], fb[2][4];
-    load_tile(w, fa[0], fb[0]);
+            for (int pt = 0; pt < 6; ++pt) {
+                const unsigned mo = row_off(32 * pt + li, BPN, py0, px0, p.Hp, p.Wp, p.ldm);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int tl = w + 4 * k;
-        if (k + 1 < 9) load_tile(tl + 4, fa[(k + 1) & 1], fb[(k + 1) & 1]);
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        // A operand = query rows (m = p'), B operand = key rows (n = l'): a lane owns key column li and 16 query rows
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const i32x4 a = fa[k & 1][j], b = fb[k & 1][j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.x), __int_as_float(b.x), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.y), __int_as_float(b.y), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.z), __int_as_float(b.z), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.w), __int_as_float(b.w), acc, 0, 0, 0);
-        }
-        const int pt = tl / 6, lt = tl - pt * 6;
-        const int lcol = 32 * lt + li;
-        if (lcol < BHN) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int prow = 32 * pt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (prow < BHN) Dl[prow * BDP + lcol] = acc[r];
+                for (int j = 0; j < 4; ++j) fa[pt][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_m, mo == kOobB ? (int)kOobB : (int)(mo + 32u * j), 0, 0);
             }
+        };
+        auto load_b = [&](int lb, i32x4 (&f)[4]) {
+            const int ly0 = (lb / p.lbx) * BLH, lx0 = (lb % p.lbx) * BLW;
+            const unsigned ro = row_off(32 * wv + li, BLN, ly0, lx0, p.Hl, p.Wl, p.ldr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro == kOobB ? (int)kOobB : (int)(ro + 32u * j), 0, 0);
+        };
+        int cur_pb = item_pb(i0);
+        load_a(cur_pb);
+        load_b(item_lb(i0), fbc);
+#pragma unroll 1
+        for (int it = i0; it <= i1; ++it) {                          // iteration `it` produces item `it` (none in the last one)
+            if (it < i1) {
+                const int k = (it - i0) & 1;
+                if (it + 1 < i1) load_b(item_lb(it + 1), fbn);     // next item's key tile (its query tiles: below, when the query block changes)
+                float* D = Dl + k * (BDB / 4);
+                const int lcol = 32 * wv + li;
+#pragma unroll
+                for (int pt = 0; pt < 6; ++pt) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const i32x4 a = fa[pt][j], b = fbc[j];
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.x), __int_as_float(b.x), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.y), __int_as_float(b.y), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.z), __int_as_float(b.z), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.w), __int_as_float(b.w), acc, 0, 0, 0);
+                    }
+                    if (lcol < BLN) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int prow = 32 * pt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (prow < BPN) D[prow * BDP + lcol] = acc[r];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fbc[j] = fbn[j];
+                if (it + 1 < i1 && item_pb(it + 1) != cur_pb) {      // wave-uniform: the next item starts a new query block
+                    cur_pb = item_pb(it + 1);
+                    load_a(cur_pb);
+                }
+            }
+            __syncthreads();
         }
-    }
-    __syncthreads();
-
-    // ---- B: box sums.  Thread -> key pixel l = t % 128 of the block, query pixels 64 (t / 128) .. + 63
-    const int ll = t & 127, lyy = ll >> 4, lxx = ll & 15;
-    const int ly = ly0 + lyy, lx = lx0 + lxx;
-    const bool l_ok = ly < p.Hl && lx < p.Wl;
-    int lcol9[9];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) lcol9[3 * a + b] = (lyy + a) * BHW + lxx + b;         // halo index of l + (a - 1, b - 1)
-    const float sc = l_ok ? p.nrm[(size_t)ly * p.Wl + lx] : 0.f;
-    const int q0 = 64 * (t >> 7);
-#pragma unroll 4
-    for (int q = 0; q < 64; ++q) {
-        const int pl = q0 + q, pyy = pl >> 4, pxx = pl & 15;             // wave-uniform
-        float s = 0.f;
+    } else {
+        // ---- consumers.  Thread -> key pixel l = lane of the 4 x 16 block, query pixels 32 (wave - 4) .. + 31 of the 8 x 16 block
+        const int lyy = lane >> 4, lxx = lane & 15;
+        int lcol9[9];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) s += Dl[((pyy + a) * BHW + pxx + b) * BDP + lcol9[3 * a + b]];
-        const int py = py0 + pyy, px = px0 + pxx;
-        if (l_ok && py < p.Hp && px < p.Wp) p.S[((size_t)py * p.Wp + px) * p.lds_ + (size_t)ly * p.Wl + lx] = s * sc;
+            for (int b = 0; b < 3; ++b) lcol9[3 * a + b] = (lyy + a) * BHW + lxx + b;     // halo index of l + (a - 1, b - 1)
+        const int q0 = 32 * (wv - 4);
+#pragma unroll 1
+        for (int it = i0; it <= i1; ++it) {                          // iteration `it` consumes item `it - 1`
+            if (it > i0) {
+                const int ci = it - 1, k = (ci - i0) & 1;
+                const int pb = item_pb(ci), lb = item_lb(ci);
+                const int py0 = (pb / p.pbx) * BSH, px0 = (pb % p.pbx) * BSW;
+                const int ly = (lb / p.lbx) * BLH + lyy, lx = (lb % p.lbx) * BLW + lxx;
+                const bool l_ok = ly < p.Hl && lx < p.Wl;
+                const float sc = l_ok ? p.nrm[(size_t)ly * p.Wl + lx] : 0.f;
+                const float* D = Dl + k * (BDB / 4);
+                float* srow = p.S + (size_t)ly * p.Wl + lx;
+#pragma unroll 8
+                for (int q = 0; q < 32; ++q) {
+                    const int pl = q0 + q, pyy = pl >> 4, pxx = pl & 15;     // wave-uniform
+                    float s = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a)
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) s += D[((pyy + a) * BHW + pxx + b) * BDP + lcol9[3 * a + b]];
+                    const int py = py0 + pyy, px = px0 + pxx;
+                    if (l_ok && py < p.Hp && px < p.Wp) srow[((size_t)py * p.Wp + px) * p.lds_] = s * sc;
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
@@ -152,12 +192,14 @@ int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, 
     p.M = M; p.ldm = ldm; p.m_bytes = (unsigned)mb; p.Hp = Hp; p.Wp = Wp;
     p.R = R; p.ldr = ldr; p.r_bytes = (unsigned)rb; p.Hl = Hl; p.Wl = Wl;
     p.nrm = nrm; p.S = S; p.lds_ = ld_s;
-    p.pbx = ceil_div(Wp, BSW); p.lbx = ceil_div(Wl, BSW);
-    p.n_lb = ceil_div(Hl, BSH) * p.lbx;
-    const int n_pb = ceil_div(Hp, BSH) * p.pbx;
+    p.pbx = ceil_div(Wp, BSW); p.lbx = ceil_div(Wl, BLW);
+    p.n_lb = ceil_div(Hl, BLH) * p.lbx;
+    const long n_items = (long)ceil_div(Hp, BSH) * p.pbx * p.n_lb;
+    CIAOSR_CHECK_ARG(n_items < 0x7FFFFFFF);
+    p.n_items = (int)n_items;
     CIAOSR_BIG_LDS(csa_scores_box_f32_kernel, kBoxLds);
     ProfScope prof("csa_scores", s);
-    hipLaunchKernelGGL(csa_scores_box_f32_kernel, dim3((unsigned)n_pb * (unsigned)p.n_lb), dim3(256), kBoxLds, s, p);
+    hipLaunchKernelGGL(csa_scores_box_f32_kernel, dim3(p.n_items < 256 ? p.n_items : 256), dim3(512), kBoxLds, s, p);
     return launch_status("csa_scores_box_f32");
 }
 
