@@ -121,10 +121,14 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__int_as_float(a.w), __int_as_float(b.w), acc, 0, 0, 0);
                     }
                     if (lcol < BLN) {
+                        // row 32 pt + (r & 3) + 8 (r >> 2) + 4 lh: per-lane base + compile-time offset (ds_write immediates)
+                        float* dcol = D + (4 * lh) * BDP + lcol;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int prow = 32 * pt + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                            if (prow < BPN) D[prow * BDP + lcol] = acc[r];
+                            constexpr int kLast = BPN - 1;
+                            const int rr = 32 * pt + (r & 3) + 8 * (r >> 2);           // + 4 lh
+                            if (rr + 4 <= kLast) dcol[rr * BDP] = acc[r];
+                            else if (rr <= kLast && lh == 0) dcol[rr * BDP] = acc[r];
                         }
                     }
                 }
@@ -155,18 +159,22 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
                 const int ly = (lb / p.lbx) * BLH + lyy, lx = (lb % p.lbx) * BLW + lxx;
                 const bool l_ok = ly < p.Hl && lx < p.Wl;
                 const float sc = l_ok ? p.nrm[(size_t)ly * p.Wl + lx] : 0.f;
-                const float* D = Dl + k * (BDB / 4);
-                float* srow = p.S + (size_t)ly * p.Wl + lx;
-#pragma unroll 8
+                // the query pixel of output q is wave-uniform and q is a compile-time index: every LDS address is a per-lane base
+                // (this lane's nine halo columns, on this wave's first halo row) + an immediate
+                const float* D = Dl + k * (BDB / 4) + (q0 >> 4) * BHW * BDP;
+                float* srow = p.S + ((size_t)(py0 + (q0 >> 4)) * p.Wp + px0) * p.lds_ + (size_t)ly * p.Wl + lx;
+                const float* dk[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dk[e] = D + lcol9[e];
+#pragma unroll
                 for (int q = 0; q < 32; ++q) {
-                    const int pl = q0 + q, pyy = pl >> 4, pxx = pl & 15;     // wave-uniform
+                    const int pyy = q >> 4, pxx = q & 15;                    // relative to this wave's two query rows
                     float s = 0.f;
 #pragma unroll
                     for (int a = 0; a < 3; ++a)
 #pragma unroll
-                        for (int b = 0; b < 3; ++b) s += D[((pyy + a) * BHW + pxx + b) * BDP + lcol9[3 * a + b]];
-                    const int py = py0 + pyy, px = px0 + pxx;
-                    if (l_ok && py < p.Hp && px < p.Wp) srow[((size_t)py * p.Wp + px) * p.lds_] = s * sc;
+                        for (int b = 0; b < 3; ++b) s += dk[3 * a + b][((pyy + a) * BHW + pxx + b) * BDP];
+                    if (l_ok && py0 + (q0 >> 4) + pyy < p.Hp && px0 + pxx < p.Wp) srow[((size_t)pyy * p.Wp + pxx) * p.lds_] = s * sc;
                 }
             }
             __syncthreads();
