@@ -214,6 +214,14 @@ def test_csattn_big_map_composed_tail_vs_reference(dev, tag):
         y2 = att(x, options=hip_ops.Options(csa_composed_min=-1)).cpu()
     assert 'csa_down' in hip_ops.profile.results() and 'csa_attn_v_edge' not in hip_ops.profile.results()
     assert (y2[0] - want).abs().max().item() < TOL
+    # the correlation scores: default = 3x3 diagonal box sum of the per-pixel correlation (csa_scores_f32.hip, no patch rows);
+    # csa_scores_gemm = 1 = the 288-wide patch-row GEMM.  Both against the reference, and against each other
+    assert 'csa_key_norms' in prof and 'csa_patch_q' not in prof, sorted(prof)
+    with hip_ops.profile():
+        y3 = att(x, options=hip_ops.Options(csa_scores_gemm=1)).cpu()
+    prof3 = hip_ops.profile.results()
+    assert 'csa_patch_q' in prof3 and 'csa_key_norms' not in prof3, sorted(prof3)
+    assert (y3[0] - want).abs().max().item() < TOL and (y3 - y).abs().max().item() < TOL
 
 
 @pytest.mark.parametrize('tag', ['48', '45x51'])
