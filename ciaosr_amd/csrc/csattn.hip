@@ -177,6 +177,27 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     else
         RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
                      CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
+    if (composed && (size_t)HWp * 2 <= p.n_Qp) {
+        // composed fold + down with the row softmax applied in the attn.V operand staging (statistics-only pass over S: the in-place
+        // rewrite of the 1.36-GB logit matrix is gone; probabilities = exp2(x log2 e - max log2 e) / sum, equal to softmax_rows' to rounding)
+        const int Hh = p.Hp / 2, Wh = p.Wp / 2;
+        float* st = Qp;                                       // [HWp] (max x log2 e, 1 / sum); the patch rows are consumed (or were never built)
+        float* Otop = Ov;
+        float* Oleft = Ov + (size_t)p.Wp * 4 * C;
+        float* Otl = Oleft + (size_t)p.Hp * 4 * C;
+        RUN(softmax_stats_rows(S, HWp, p.L, p.Lld, st, s));
+        RUN(patch_rows(E, C, p.Hp, p.Wp, C, 3, 2, 3, Hh + 3, Wh + 3, PE, 9 * C, 0, 0.f, s, "csa_patch_down"));
+        RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
+                     CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));
+        RUN(csa_gather_vprime(Pc, Hh, Wh, C, Vp, s));
+        RUN(gemm_f32_softmax_a(S, p.Lld, st, 1, Vp, 25 * C, true, O, 16 * C, HWp, 16 * C, p.L, nullptr, 0, s, "csa_attn_v"));
+        RUN(gemm_f32_softmax_a(S, p.Lld, st, 1, Vp + 16 * C, 25 * C, true, Otop, 4 * C, p.Wp, 4 * C, p.L, Y, p.n_Y, s, "csa_attn_v_edge"));
+        RUN(gemm_f32_softmax_a(S, p.Wp * p.Lld, st, p.Wp, Vp + 20 * C, 25 * C, true, Oleft, 4 * C, p.Hp, 4 * C, p.L, Y, p.n_Y, s,
+                               "csa_attn_v_edge"));
+        RUN(gemm_f32_softmax_a(S, p.Lld, st, 1, Vp + 24 * C, 25 * C, true, Otl, C, 1, C, p.L, Y, p.n_Y, s, "csa_attn_v_edge"));
+        RUN(csa_gather_out(O, Otop, Oleft, Otl, w->b_down, H, W, p.Hp, p.Wp, C, out, ld_out, 16L * C, 4L * C, 4L * C, s));
+        return CIAOSR_OK;
+    }
     RUN(softmax_rows(S, HWp, p.L, p.Lld, s));
     if (composed) {
         // composed fold + down (patch_ops.hip): attn.V with N = 16C instead of 36C, no 2x map, no separate down conv

@@ -37,6 +37,8 @@ struct GemmP {
     unsigned a_bytes, b_bytes;   // buffer-descriptor extents (< 4 GiB)
     int splitk, kt_per_split;    // skinny problems: the K loop is split over blockIdx.y into partial slabs
     float* partial;              // [splitk][M][N]
+    const float2* a_stats;       // optional: A holds logits; a_stats[row * a_stats_stride] = (row max x log2 e, 1 / sum of exp): the staging
+    int a_stats_stride;          // writes exp2(a log2 e - max log2 e) / sum into LDS (row softmax applied on the fly)
     int tn_per_wg, groups_n;     // short K: a workgroup walks tn_per_wg consecutive column tiles of one row tile as ONE software
                                  // pipeline (the first k-tile of the next column tile is prefetched under the last of the current)
 };
@@ -115,6 +117,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             }
         }
     };
+    // row-softmax statistics of this thread's four A rows (rows t / 8 + 32 s), when A holds logits
+    float2 ast[4];
+    if (p.a_stats) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int gm = m0 + ((t + 256 * s) >> 3);
+            ast[s] = gm < p.M ? p.a_stats[(size_t)gm * p.a_stats_stride] : make_float2(0.f, 0.f);
+        }
+    }
     auto store_tiles = [&](int buf, int kt, int n0) {
         float* a = As + buf * A_TILE;
         float* b = Bs + buf * B_TILE;
@@ -123,7 +134,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
         for (int s = 0; s < 4; ++s) {
             const int idx = t + 256 * s;
             const int r = idx >> 3, c4 = (idx & 7) * 4;
-            *reinterpret_cast<float4*>(a + r * LDS_A + c4) = mask4(ra[s], k0 + c4, p.K);
+            float4 v = ra[s];
+            if (p.a_stats) {                                          // uniform; 3 VALU per element: one FMA, v_exp_f32, one multiply
+                constexpr float kL2e = 1.4426950408889634f;
+                v.x = __builtin_amdgcn_exp2f(__builtin_fmaf(v.x, kL2e, -ast[s].x)) * ast[s].y;
+                v.y = __builtin_amdgcn_exp2f(__builtin_fmaf(v.y, kL2e, -ast[s].x)) * ast[s].y;
+                v.z = __builtin_amdgcn_exp2f(__builtin_fmaf(v.z, kL2e, -ast[s].x)) * ast[s].y;
+                v.w = __builtin_amdgcn_exp2f(__builtin_fmaf(v.w, kL2e, -ast[s].x)) * ast[s].y;
+            }
+            *reinterpret_cast<float4*>(a + r * LDS_A + c4) = mask4(v, k0 + c4, p.K);
         }
         if (!B_KN) {
 #pragma unroll
@@ -276,6 +295,7 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.slope = slope; p.act = act;
+    p.a_stats = nullptr; p.a_stats_stride = 0;
     {
         const size_t ab = ((size_t)(M - 1) * lda + K) * sizeof(float);
         const size_t bb = (b_kn ? ((size_t)(K - 1) * ldb + N) : ((size_t)(N - 1) * ldb + K)) * sizeof(float);
@@ -337,6 +357,7 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
     p.A = A; p.B = B; p.C = C; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.slope = slope; p.act = act;
+    p.a_stats = nullptr; p.a_stats_stride = 0;
     const size_t ab = ((size_t)(M - 1) * lda + K) * sizeof(float);
     const size_t bb = (b_kn ? ((size_t)(K - 1) * ldb + N) : ((size_t)(N - 1) * ldb + K)) * sizeof(float);
     CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
@@ -352,6 +373,37 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
     p.kt_per_split = ceil_div(nk, splits);
     p.splitk = ceil_div(nk, p.kt_per_split);
     p.partial = partial;
+    return gemm_launch(p, b_kn, stream, tag);
+}
+
+int gemm_f32_softmax_a(const float* A, int lda, const float* a_stats2, int a_stats_stride, const float* B, int ldb, bool b_kn, float* C, int ldc,
+                       int M, int N, int K, float* partial, size_t partial_floats, hipStream_t stream, const char* tag) {
+    if (M <= 0 || N <= 0) return CIAOSR_OK;
+    CIAOSR_CHECK_ARG(K > 0 && A && B && C && a_stats2 && a_stats_stride >= 1);
+    CIAOSR_CHECK_ARG((lda & 3) == 0 && (ldb & 3) == 0 && aligned16(A) && aligned16(B) && (reinterpret_cast<uintptr_t>(a_stats2) & 7u) == 0);
+    GemmP p;
+    p.A = A; p.B = B; p.C = C; p.bias = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = 1.f; p.slope = 0.f; p.act = CIAOSR_ACT_NONE;
+    p.a_stats = reinterpret_cast<const float2*>(a_stats2); p.a_stats_stride = a_stats_stride;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * sizeof(float);
+    const size_t bb = (b_kn ? ((size_t)(K - 1) * ldb + N) : ((size_t)(N - 1) * ldb + K)) * sizeof(float);
+    CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    p.tiles_n = ceil_div(N, BN);
+    p.tn_per_wg = 1; p.groups_n = p.tiles_n;
+    p.n_wg = ceil_div(M, BM) * p.tiles_n;
+    const int nk = (K + BK - 1) / BK;
+    p.splitk = 1; p.kt_per_split = nk; p.partial = nullptr;
+    if (partial) {                                                   // skinny problem: the split of gemm_f32_splitk
+        int splits = ceil_div(512, p.n_wg);
+        if (splits > nk / 4) splits = nk / 4 > 0 ? nk / 4 : 1;
+        if ((size_t)splits * M * N > partial_floats) splits = (int)(partial_floats / ((size_t)M * N));
+        if (splits < 1) splits = 1;
+        p.kt_per_split = ceil_div(nk, splits);
+        p.splitk = ceil_div(nk, p.kt_per_split);
+        p.partial = partial;
+    }
     return gemm_launch(p, b_kn, stream, tag);
 }
 

@@ -52,6 +52,12 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
 int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn, float* C, int ldc, const float* bias,
                     int M, int N, int K, float alpha, int act, float slope, float* partial, size_t partial_floats,
                     hipStream_t stream, const char* tag);
+// The same two contractions with A = row_softmax(logits) formed in the operand staging: A holds the LOGITS, a_stats[row * a_stats_stride]
+// = (row max x log2 e, 1 / sum of exp) from softmax_stats_rows; element (m, k) enters the MFMA as exp2(A[m][k] log2 e - max log2 e) / sum
+// (one FMA, v_exp_f32, one multiply: the probabilities agree with softmax_rows' to fp32 rounding, not bitwise).  partial == nullptr:
+// the plain kernel, else split-K.
+int gemm_f32_softmax_a(const float* A, int lda, const float* a_stats2, int a_stats_stride, const float* B, int ldb, bool b_kn, float* C, int ldc,
+                       int M, int N, int K, float* partial, size_t partial_floats, hipStream_t stream, const char* tag);
 // gemm_small_f32.hip: few-MFLOP problems (no staging, K-sliced waves); gemm_small_ok tells whether a problem qualifies
 bool gemm_small_ok(int M, int N, int K, int lda, int ldw);
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,
@@ -80,6 +86,7 @@ int avgpool2(const float* src, int Hp, int Wp, int C, float* dst, hipStream_t s)
 int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int stride, int pad, int OH, int OW,
                float* out, int ld_out, int normalize, float floor_, hipStream_t s, const char* tag);
 int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s);
+int softmax_stats_rows(const float* S, long rows, int L, int ld, float* stats2 /* [rows] (max * log2 e, 1 / sum) */, hipStream_t s);
 int fold(const float* O, int ldo, int Hp, int Wp, int C, float* Y, hipStream_t s);
 int fold_s(const float* O, int ldo, int Hp, int Wp, int C, int scale, float* Y, hipStream_t s);
 int downsample(const float* src, int Hp, int Wp, int C, int scale, float* dst, hipStream_t s);

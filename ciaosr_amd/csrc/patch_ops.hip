@@ -486,6 +486,77 @@ int patch_rows(const float* src, int ld_src, int Hs, int Ws, int Cs, int k, int 
     return launch_status("patch_rows");
 }
 
+// Row statistics only: stats[row] = (row max x log2 e, 1 / sum of exp2(v log2 e - max log2 e)) -- what the attn.V GEMM's operand
+// staging (gemm_f32.hip) needs to form the probabilities on the fly with one FMA, one v_exp_f32 and one multiply per element; the
+// sum uses the same expression, so every row still sums to 1 to rounding.  The in-place rewrite of S (one 1.36-GB write and one
+// read per 192x192 tile) disappears.  Single pass, the whole row in registers when it fits (rows of up to 64 x SMV float4).
+constexpr float kLog2eP = 1.4426950408889634f;
+__global__ __launch_bounds__(256) void softmax_stats_kernel(const float* __restrict__ S, long rows, int L, int ld, float2* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* s = S + (size_t)row * ld;
+    const int n4 = ld >> 2;
+    float m = -INFINITY;
+    for (int t = lane; t < n4; t += 64) {
+        const float4 v = reinterpret_cast<const float4*>(s)[t];
+        const int c = 4 * t;
+        if (c < L) m = fmaxf(m, v.x);
+        if (c + 1 < L) m = fmaxf(m, v.y);
+        if (c + 2 < L) m = fmaxf(m, v.z);
+        if (c + 3 < L) m = fmaxf(m, v.w);
+    }
+    m = wave_max(m) * kLog2eP;
+    float sum = 0.f;
+    for (int t = lane; t < n4; t += 64) {
+        const float4 v = reinterpret_cast<const float4*>(s)[t];
+        const int c = 4 * t;
+        if (c < L) sum += __builtin_amdgcn_exp2f(__builtin_fmaf(v.x, kLog2eP, -m));
+        if (c + 1 < L) sum += __builtin_amdgcn_exp2f(__builtin_fmaf(v.y, kLog2eP, -m));
+        if (c + 2 < L) sum += __builtin_amdgcn_exp2f(__builtin_fmaf(v.z, kLog2eP, -m));
+        if (c + 3 < L) sum += __builtin_amdgcn_exp2f(__builtin_fmaf(v.w, kLog2eP, -m));
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) stats[row] = make_float2(m, 1.f / sum);
+}
+__global__ __launch_bounds__(256) void softmax_stats_reg_kernel(const float* __restrict__ S, long rows, int L, int ld, float2* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4* s = reinterpret_cast<const float4*>(S + (size_t)row * ld);
+    const int n4 = ld >> 2;
+    float4 v[SMV];
+#pragma unroll
+    for (int i = 0; i < SMV; ++i) {
+        const int t = lane + 64 * i, c = 4 * t;
+        v[i] = (t < n4 && c < L) ? s[t] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (c + 1 >= L) v[i].y = -INFINITY;
+        if (c + 2 >= L) v[i].z = -INFINITY;
+        if (c + 3 >= L) v[i].w = -INFINITY;
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SMV; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    m = wave_max(m) * kLog2eP;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SMV; ++i)                        // exp2(-inf) = 0 for the masked tail
+        sum += (__builtin_amdgcn_exp2f(__builtin_fmaf(v[i].x, kLog2eP, -m)) + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i].y, kLog2eP, -m))) +
+               (__builtin_amdgcn_exp2f(__builtin_fmaf(v[i].z, kLog2eP, -m)) + __builtin_amdgcn_exp2f(__builtin_fmaf(v[i].w, kLog2eP, -m)));
+    sum = wave_sum(sum);
+    if (lane == 0) stats[row] = make_float2(m, 1.f / sum);
+}
+
+int softmax_stats_rows(const float* S, long rows, int L, int ld, float* stats2, hipStream_t s) {
+    ProfScope prof("softmax_stats", s);
+    float2* st = reinterpret_cast<float2*>(stats2);
+    if ((ld >> 2) <= 64 * SMV && (ld >> 2) > 64 * 8)
+        hipLaunchKernelGGL(softmax_stats_reg_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, st);
+    else
+        hipLaunchKernelGGL(softmax_stats_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, S, rows, L, ld, st);
+    return launch_status("softmax_stats");
+}
+
 int softmax_rows(float* S, long rows, int L, int ld, hipStream_t s) {
     ProfScope prof("softmax_rows", s);
     if ((ld >> 2) <= 64 * SMV && (ld >> 2) > 64 * 8)       // long rows that still fit the register file: one pass
