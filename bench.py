@@ -101,6 +101,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'mlp_hidden_q': (3 * 2.0 * Q * hidden * hidden, 'flop'),
         'head_table': (2.0 * HW * hidden * (D + Dv), 'flop'),
         'head_table_bf16': (2.0 * HW * hidden * (D + Dv), 'flop16'),
+        # fp32: computed as a 3x3 diagonal box sum of a K = C/2 per-pixel correlation (csa_scores_f32.hip): the ALGORITHMIC flops are the
+        # reference's patch correlation (the kernel executes ~1/3.4 of them)
         'csa_scores': (2.0 * HW * (HW / 4) * 4.5 * C, 'flop'),
         # >= 64x64 maps run the composed fold+down tail (DESIGN 'cs_attn tail'): 16C value columns instead of 36C
         'csa_attn_v': (2.0 * HW * (HW / 4) * (16 if HW >= 4096 else 36) * C, 'flop'),
@@ -119,6 +121,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),
         # the blocks' local feature fusion in f16 mode: memory-bound (16-bit rows in, fp32 residual in, two fp32 + one 16-bit rows out)
         'enc_conv1x1_bf16': (blocks * HW * ((C + C * layers) * 2.0 + C * 4.0 + 2 * C * 4.0 + C * 2.0), 'byte'),
+        'softmax_stats': (4.0 * HW * (HW / 4), 'byte'),       # one read of the fp32 logit matrix
         'local_attention': (Q * (4.0 * J * D + 4.0 * J * Dv + 4.0 * Dv + 16) + 2.0 * C * 4 * HW, 'byte'),
         'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),
     }
