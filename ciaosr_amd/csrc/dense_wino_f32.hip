@@ -20,9 +20,20 @@
 //   * per 8-channel step a wave reads the 2 x 4 window pixels its row needs (8 ds_read_b128), forms its four transformed values
 //     with 32 additions, and issues 16 MFMAs against 4 pre-packed 1-KB weight fragments from L2 (the transformed weights
 //     U[p] = (G g G^T)[p] as 16 separate [64][cin] matrices in ciaosr_pack_fragments_f32 order).
+#include <cstdlib>
+
 #include "ops.h"
 
 namespace ciaosr {
+
+#ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/wino_probe.py): per-wave stamps of the launches with g_wprobe_groups input groups
+__device__ unsigned long long g_wprobe[1024 * 8 * 32];
+__device__ int g_wprobe_groups = 2;
+#define WPROBE(slot) do { if (!TABLE && lane == 0 && blockIdx.y == gridDim.y / 2 && blockIdx.x < 1024 && p.groups == g_wprobe_groups) \
+        g_wprobe[(blockIdx.x * 8 + wv) * 32 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WPROBE(slot) do { } while (0)
+#endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -35,8 +46,11 @@ constexpr size_t kWinoLds = 2 * (size_t)WPATCH;  // 92 160 B >= the 64-KB output
 constexpr unsigned kOobW = 0xFFFFFFF0u;
 
 struct DenseWinoP {
-    float* x; int ldx;
-    unsigned x_bytes;
+    float* x; int ldx;                           // output map [H*W][ldx] (dense layers: also the input)
+    const float* in; int ld_in;                  // input maps, back to back: image (dense) / key offset (logit table) blockIdx.y
+    unsigned x_bytes;                            // extent of `in`
+    int n_blk;                                   // 64-channel output blocks per workgroup (dense layers: 1; logit table: 4)
+    int out_y_stride;                            // floats added to the output address per blockIdx.y within a pixel row (logit table: ldg)
     int H, W, tiles_x;
     int groups;
     const float4* wf;                            // 16 fragment arrays [2][nj][64 lanes] float4, one per transformed position, back to back
@@ -47,6 +61,10 @@ struct DenseWinoP {
 
 __device__ __forceinline__ int wino_swz(int py, int px) { return ((px >> 1) & 7) | (((py >> 1) & 1) << 3); }
 
+// TABLE = false: a dense layer (input = output buffer, bias + ReLU, one output block, blockIdx.y = image).
+// TABLE = true : the logit table of the fused head as nine 3x3 convolutions 64 -> 256 (head.hip): blockIdx.y = key offset o, input map
+//                Pi_o, four output blocks from the ONE resident patch (the output-transform scratch sits behind it), no bias, no ReLU.
+template <bool TABLE>
 __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsw[];
     // 8 waves = 4 rows i of the transformed domain x 2 output-channel halves: two waves per SIMD cover each other's LDS round trips,
@@ -55,8 +73,9 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
     const int w = wv & 3, nth = wv >> 2;
     const int ty0 = (blockIdx.x / p.tiles_x) * WTH, tx0 = (blockIdx.x % p.tiles_x) * WTW;
     const int img = blockIdx.y;
-    const unsigned img_off = (unsigned)((size_t)img * p.H * p.W * p.ldx * 4);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
+    WPROBE(0);
+    const int blk0 = TABLE ? (int)blockIdx.z * p.n_blk : 0;     // logit table: first of this workgroup's 64-channel output blocks
+    const unsigned img_off = (unsigned)((size_t)img * p.H * p.W * p.ld_in * 4);
 
     // patch staging by LDS-DMA (`buffer_load_dwordx4 ... lds`, no staging registers): piece i = wv + 8 s (i < 45) fills LDS bytes
     // [1024 i, 1024 i + 1024) of a patch buffer; lane -> LDS chunk c = 64 i + lane = (pixel c / 16, slot c % 16), which holds the
@@ -72,19 +91,21 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
         const int py = px_ / WPW, pxx = px_ - py * WPW;
         const int gy = ty0 - 1 + py, gx = tx0 - 1 + pxx;
         const bool ok = px_ < WPH * WPW && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        goff[s] = ok ? (img_off + (unsigned)(gy * p.W + gx) * (unsigned)p.ldx * 4u + (unsigned)(slot ^ wino_swz(py, pxx)) * 16u) : kOobW;
+        goff[s] = ok ? (img_off + (unsigned)(gy * p.W + gx) * (unsigned)p.ld_in * 4u + (unsigned)(slot ^ wino_swz(py, pxx)) * 16u) : kOobW;
     }
     const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
     auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
-    const i32x4 desc = {(int)(unsigned)(size_t)p.x, (int)(((size_t)p.x >> 32) & 0xFFFFu), (int)p.x_bytes, 0x00020000};
+    const i32x4 desc = {(int)(unsigned)(size_t)p.in, (int)(((size_t)p.in >> 32) & 0xFFFFu), (int)p.x_bytes, 0x00020000};
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)ldsw;
     auto dma_piece = [&](int s, int buf, int g) {
         if (wv + 8 * s < WPIECES) {                  // wave-uniform
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * WPATCH) + 1024u * (unsigned)(wv + 8 * s));
-            const unsigned voff = goff[s] == kOobW ? kOobW : goff[s] + (unsigned)phys(g) * 256u;
+            // the group's 256-byte channel slice enters as the SCALAR offset (not part of the range check: a halo lane's
+            // out-of-range per-lane offset stays out of range and its LDS bytes are written as zeros)
+            const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)phys(g) * 256u);
             unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(dst), "s"(desc) : "memory");
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(goff[s]), "s"(dst), "s"(desc), "s"(soff) : "memory");
         }
     };
 
@@ -103,14 +124,16 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
             pswz[r][b] = wino_swz(py, px);
         }
     // weights: fragment (position 4 w + j, nt) of k-chunk jc = 8 g + jj
-    const float4* wl = p.wf + (size_t)(4 * w) * p.pos_stride + lane;
-    auto frag = [&](int j, int jc) -> float4 { return wl[(size_t)j * p.pos_stride + (size_t)(nth * p.nj + jc) * 64]; };
-
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    // (through a buffer descriptor: the lane part of the address is ONE constant VGPR, the fragment index a scalar offset -- no
+    // 64-bit VALU address arithmetic in the loop)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(p.wf), 0, 0xFFFFFFFFu, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned pos_bytes = (unsigned)p.pos_stride * 16u;
+    auto frag = [&](int j, int jc, int blk) -> float4 {
+        const unsigned so = (unsigned)(4 * w + j) * pos_bytes + (unsigned)((nth + 2 * (blk0 + blk)) * p.nj + jc) * 1024u;
+        const i32x4 x = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)lane16, (int)so, 0);
+        return make_float4(__int_as_float(x.x), __int_as_float(x.y), __int_as_float(x.z), __int_as_float(x.w));
+    };
 
 #pragma unroll
     for (int s = 0; s < WDS; ++s) dma_piece(s, 0, 0);
@@ -120,10 +143,13 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
 #pragma unroll
     for (int s0 = 0; s0 < WPF; ++s0)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wr[s0][j] = frag(j, 8 * phys(0) + s0);
+        for (int j = 0; j < 4; ++j) wr[s0][j] = frag(j, 8 * phys(0) + s0, 0);
+    WPROBE(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WPROBE(2);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    WPROBE(3);
 
     const int G = p.groups;
     int pbuf = 0;
@@ -138,21 +164,38 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) d[r][b] = *reinterpret_cast<const float4*>(pb + pbase[r][b] + ((ch ^ pswz[r][b]) << 4));
     };
+    // the transform in PACKED fp32 (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue slot): every VALU instruction of a SIMD takes
+    // ~4 cycles from its fp32 matrix pipe whichever wave issues it (tools/ubench/mfma_valu.hip), so the 32 scalar operations of a
+    // step were 12 % of its 1024 MFMA cycles; written on 2-vectors because the library is built without the SLP vectoriser
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 s2v = {s2, s2};
+    auto lo = [](const float4& a) -> f32x2 { return f32x2{a.x, a.y}; };
+    auto hi = [](const float4& a) -> f32x2 { return f32x2{a.z, a.w}; };
+    auto join = [](f32x2 a, f32x2 b) -> float4 { return make_float4(a.x, a.y, b.x, b.y); };
     auto rows = [&](const float4 (&d)[2][4], float4 (&r)[4]) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            r[b] = make_float4(d[0][b].x + s2 * d[1][b].x, d[0][b].y + s2 * d[1][b].y, d[0][b].z + s2 * d[1][b].z, d[0][b].w + s2 * d[1][b].w);
+            r[b] = join(__builtin_elementwise_fma(s2v, lo(d[1][b]), lo(d[0][b])), __builtin_elementwise_fma(s2v, hi(d[1][b]), hi(d[0][b])));
     };
     auto cols = [&](const float4 (&r)[4], float4 (&v)[4]) {
-        v[0] = make_float4(r[0].x - r[2].x, r[0].y - r[2].y, r[0].z - r[2].z, r[0].w - r[2].w);
-        v[1] = make_float4(r[1].x + r[2].x, r[1].y + r[2].y, r[1].z + r[2].z, r[1].w + r[2].w);
-        v[2] = make_float4(r[2].x - r[1].x, r[2].y - r[1].y, r[2].z - r[1].z, r[2].w - r[1].w);
-        v[3] = make_float4(r[1].x - r[3].x, r[1].y - r[3].y, r[1].z - r[3].z, r[1].w - r[3].w);
+        v[0] = join(lo(r[0]) - lo(r[2]), hi(r[0]) - hi(r[2]));
+        v[1] = join(lo(r[1]) + lo(r[2]), hi(r[1]) + hi(r[2]));
+        v[2] = join(lo(r[2]) - lo(r[1]), hi(r[2]) - hi(r[1]));
+        v[3] = join(lo(r[1]) - lo(r[3]), hi(r[1]) - hi(r[3]));
     };
     float4 v[2][4];                                                  // transformed inputs of the current / next step
+    const int n_blk = TABLE ? p.n_blk : 1;
+#pragma unroll 1
+    for (int blk = 0; blk < n_blk; ++blk) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
-        const bool more = g + 1 < G;
+        const bool more = g + 1 < G;                                 // another input group of this block follows
+        const bool more_w = more || blk + 1 < n_blk;                 // ... or another output block: its first weights are requested ahead too
         const unsigned char* pb = ldsw + pbuf * WPATCH;
         {
             float4 d[2][4], r[4];
@@ -166,17 +209,23 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
                                                                          // requests (vmcnt retires in order: they give it two steps to land)
             {   // weights WPF steps ahead (a step is 16 MFMAs of this wave = 2048 cycles of the shared pipe; every workgroup of the
                 // launch walks the same fragments, so the L2 round trip under load is longer than one step)
-                int jc = 8 * phys(g) + jj + WPF;
+                int jc = 8 * phys(g) + jj + WPF, nb = blk;
                 bool have = true;
-                if (jj + WPF >= 8) { have = more; jc = more ? 8 * phys(g + 1) + jj + WPF - 8 : 0; }
+                if (jj + WPF >= 8) {
+                    have = more_w;
+                    jc = (more ? 8 * phys(g + 1) : 8 * phys(0)) + jj + WPF - 8;
+                    nb = more ? blk : blk + 1;
+                }
                 if (have) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) wr[(jj + WPF) & 3][j] = frag(j, jc);
+                    for (int j = 0; j < 4; ++j) wr[(jj + WPF) & 3][j] = frag(j, jc, nb);
                 }
             }
             float4 d[2][4], r[4];
             if (jj < 7) load_d(pb, jj + 1, d);
             __builtin_amdgcn_sched_barrier(0);                       // keep the requests at the top of the step (hipcc sinks them otherwise)
+            // (hipcc sinks the transform of step jj + 1 -- its only uses are in the next step's basic block -- in front of that step's
+            // MFMAs; pinning one float4 of it behind each MFMA pair with empty asm statements was measured: 54.5 -> 55.8 ms per 8 tiles)
             const float4 (&vc)[4] = v[jj & 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[jj & 3][j].x, vc[j].x, acc[j], 0, 0, 0);
@@ -191,6 +240,7 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[jj & 3][j].w, vc[j].w, acc[j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            WPROBE(4 + 8 * g + jj);
         }
         if (more) {
             // every DMA piece of the next patch is older than the last 2 x 4 weight requests of this wave
@@ -199,12 +249,14 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        WPROBE(20 + g);
     }
 
     // Output transform.  Column half (A^T along j) in registers: t_x = m_0 + m_1 + m_2 (x = 0), m_1 - m_2 - m_3 (x = 1); row half
     // (A^T along i = wave) through LDS in a fixed order: Y_0 = t[0] + t[1] + t[2], Y_1 = t[1] - t[2] - t[3].
     //   red[i][x][nt][q][lane] = float4 of registers 4 q .. 4 q + 3 (channels 32 nt + 8 q + 4 lh .. + 3 of Winograd tile li)
-    float4* red = reinterpret_cast<float4*>(ldsw);
+    // Dense layer: the scratch overlays the patch buffers (all groups are done); logit table: behind the resident patch.
+    float4* red = reinterpret_cast<float4*>(ldsw + (TABLE ? WPATCH : 0));
     {
         const int nt = nth;
 #pragma unroll
@@ -222,34 +274,43 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
             red[(((w * 2 + 1) * 2 + nt) * 4 + q) * 64 + lane] = t1;
         }
     }
+    WPROBE(28);
     __syncthreads();
-    float* const xi = p.x + (size_t)img * p.H * p.W * p.ldx;
+    WPROBE(29);
+    float* const xi = TABLE ? p.x + (size_t)img * p.out_y_stride : p.x + (size_t)img * p.H * p.W * p.ldx;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int unit = t + 512 * u;                  // (y, x, nt, q, lane): 2 x 2 x 2 x 4 x 64
         const int ul = unit & 63, q = (unit >> 6) & 3, nt = (unit >> 8) & 1, xx = (unit >> 9) & 1, yy = unit >> 10;
         auto rd = [&](int i) -> float4 { return red[(((i * 2 + xx) * 2 + nt) * 4 + q) * 64 + ul]; };
-        float4 v;
+        float4 o;
         if (yy == 0) {
             const float4 a = rd(0), b = rd(1), c = rd(2);
-            v = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
+            o = make_float4(a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w);
         } else {
             const float4 a = rd(1), b = rd(2), c = rd(3);
-            v = make_float4(a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w);
+            o = make_float4(a.x - b.x - c.x, a.y - b.y - c.y, a.z - b.z - c.z, a.w - b.w - c.w);
         }
         const int tl = ul & 31;
         const int y = ty0 + 2 * (tl >> 3) + yy, x = tx0 + 2 * (tl & 7) + xx;
         if (y < p.H && x < p.W) {
             const int co = 32 * nt + 8 * q + 4 * (ul >> 5);
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
-            v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
-            v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
-            *reinterpret_cast<float4*>(xi + ((size_t)y * p.W + x) * p.ldx + p.col_out + co) = v;
+            if constexpr (!TABLE) {
+                const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                o.x = fmaxf(o.x + b.x, 0.f); o.y = fmaxf(o.y + b.y, 0.f);
+                o.z = fmaxf(o.z + b.z, 0.f); o.w = fmaxf(o.w + b.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(xi + ((size_t)y * p.W + x) * p.ldx + p.col_out + 64 * (blk0 + blk) + co) = o;
         }
     }
+    if (TABLE && blk + 1 < n_blk) __syncthreads();      // the scratch is rewritten by the next block's output transform
+    }
+    WPROBE(30);
 }
 
 int dense_wino_tiles(int H, int W) { return ceil_div(H, WTH) * ceil_div(W, WTW); }
+
+constexpr size_t kWinoTableLds = (size_t)WPATCH + 65536;      // the resident patch + the 64-KB output-transform scratch behind it
 
 // dense layer l of a block in Winograd form; frag_wino = 16 fragment arrays of the transformed weights (encoder_hip.py packs them)
 int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino, const float* bias, int n_img, hipStream_t s) {
@@ -258,6 +319,7 @@ int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* fr
     CIAOSR_CHECK_ARG(n_img >= 1 && n_img <= 65535 && x_bytes < 0xFFFFFF00ull);
     DenseWinoP p;
     p.x = X; p.ldx = ldx; p.x_bytes = (unsigned)x_bytes;
+    p.in = X; p.ld_in = ldx; p.n_blk = 1; p.out_y_stride = 0;
     p.H = H; p.W = W; p.tiles_x = ceil_div(W, WTW);
     p.groups = l + 1;
     p.wf = reinterpret_cast<const float4*>(frag_wino);
@@ -265,10 +327,42 @@ int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* fr
     p.pos_stride = (long)2 * p.nj * 64;
     p.bias = bias;
     p.col_out = 64 * (l + 1);
-    CIAOSR_BIG_LDS(dense_wino_f32_kernel, kWinoLds);
+    CIAOSR_BIG_LDS(dense_wino_f32_kernel<false>, kWinoLds);
     ProfScope prof("enc_dense_wino", s);
-    hipLaunchKernelGGL(dense_wino_f32_kernel, dim3(dense_wino_tiles(H, W), n_img), dim3(512), kWinoLds, s, p);
+    hipLaunchKernelGGL(dense_wino_f32_kernel<false>, dim3(dense_wino_tiles(H, W), n_img), dim3(512), kWinoLds, s, p);
     return launch_status("dense_wino_f32");
 }
 
+// Nine 3x3 convolutions 64 -> 64 n_blk channels without bias: out[(pix * 9 + o) * ldg + n] = sum_{k, c} Pi[o][pix + k][c] w[n][c][k]
+// (the logit table of the fused head: Pi_o = F . shift_o(F), head.hip).  Pi: [9][H*W][64]; frag_wino: 16 arrays of the transformed
+// [64 n_blk][64] weights in fragment order.
+int wino_table_f32(const float* Pi, int H, int W, const float* frag_wino, int n_blk, float* out, int ldg, hipStream_t s) {
+    static const int per_wg = [] { const char* e = getenv("CIAOSR_TABLE_BLK"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
+    CIAOSR_CHECK_ARG(Pi && frag_wino && out && n_blk >= 1 && (ldg & 3) == 0 && aligned16(Pi) && aligned16(frag_wino) && aligned16(out));
+    const size_t in_bytes = (size_t)9 * H * W * 64 * 4;
+    CIAOSR_CHECK_ARG(in_bytes < 0xFFFFFF00ull);
+    DenseWinoP p;
+    p.x = out; p.ldx = 9 * ldg; p.x_bytes = (unsigned)in_bytes;
+    CIAOSR_CHECK_ARG(n_blk % per_wg == 0);
+    p.in = Pi; p.ld_in = 64; p.n_blk = per_wg; p.out_y_stride = ldg;
+    p.H = H; p.W = W; p.tiles_x = ceil_div(W, WTW);
+    p.groups = 1;
+    p.wf = reinterpret_cast<const float4*>(frag_wino);
+    p.nj = 8;
+    p.pos_stride = (long)2 * n_blk * p.nj * 64;
+    p.bias = nullptr;
+    p.col_out = 0;
+    CIAOSR_BIG_LDS(dense_wino_f32_kernel<true>, kWinoTableLds);
+    ProfScope prof("head_logit_table", s);
+    hipLaunchKernelGGL(dense_wino_f32_kernel<true>, dim3(dense_wino_tiles(H, W), 9, n_blk / per_wg), dim3(512), kWinoTableLds, s, p);
+    return launch_status("wino_table_f32");
+}
+
 }  // namespace ciaosr
+
+#ifdef CIAOSR_PROBE
+extern "C" int ciaosr_debug_wino_probe_read(unsigned long long* host, int n_words, int next_groups) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::g_wprobe), (size_t)n_words * 8) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(ciaosr::g_wprobe_groups), &next_groups, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+#endif

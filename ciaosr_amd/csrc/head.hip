@@ -223,7 +223,16 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         // and changes nothing -- max |delta| 1.04e-3 -> 1.14e-3 on the full-tile vector, +0.9 ms: W5's rounding is not what limits it.)
         const bool table16 = bf16 && (p.D & 7) == 0;
         if (table16) RUN(transpose_cast_h16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, prec == kF16, s));
-        for (long r0 = 0; r0 < total; r0 += kQkChunk) {
+        // fp32, C = 64: nine Winograd convolutions of the product maps Pi_o = F . shift_o(F) (same sums as the GEMM rows below,
+        // re-associated through the transform; 20x fewer multiplies).  The maps live where the GEMM would keep its row chunk.
+        const bool table_wino = prec == kF32 && w->k_out_wino && !(route & CIAOSR_HEAD_TABLE_GEMM) && p.C == 64 && !w->no_unfold &&
+                                p.HW >= 512 && p.HW <= kQkChunk;
+        if (table_wino) {
+            RUN(qk_maps(feat_hwc, p.C, p.C, H, W, QK, s));
+            RUN(wino_table_f32(QK, H, W, w->k_out_wino, 4, G, kLdG, s));
+            RUN(qk_rows(U, p.Dv, p.D, H, W, 0, (int)total, w->k.bias[last], nullptr, G, kLdG, 3, s));
+        }
+        for (long r0 = 0; r0 < total && !table_wino; r0 += kQkChunk) {
             const int nr = (int)((total - r0) < kQkChunk ? (total - r0) : kQkChunk);
             RUN(qk_rows(U, p.Dv, p.D, H, W, r0, nr, w->k.bias[last], QK, G, kLdG, table16 ? (int)prec : 0, s));
             if (table16) {

@@ -121,6 +121,56 @@ __device__ __forceinline__ void mma_pass(const float* xa, const float4* __restri
     }
 }
 
+// The same pass for a compile-time number NJ of k-chunks, fully unrolled over STATIC register stages (round 3).  The VALU and the
+// fp32 MFMA of a gfx950 SIMD share their issue time -- tools/ubench/mfma_valu.hip: every VALU instruction between two
+// v_mfma_f32_32x32x2_f32 costs ~4 cycles of matrix-pipe time whichever wave of the SIMD issues it (4 VALU per MFMA: 80 cycles per MFMA
+// instead of 64, with one, two or four waves per SIMD) -- and the rolled loop above spends 14 VALU per 8 MFMAs on register rotation
+// (fb = fbn, fa = fan) and 64-bit address arithmetic, and waits for the requests of step j + 1 (vmcnt(0): the rotation moves read
+// them) before the MFMAs of step j.  Here: weights through a buffer descriptor with a SCALAR offset (lane part in one constant
+// VGPR), requested two steps ahead into a ring of three stages, activation fragments one step ahead into two, no moves, counted waits.
+//   wrs: descriptor of the fragment array; lane16 = lane * 16; s_off: byte offset of this wave's first fragment (wave-uniform)
+__device__ __forceinline__ float4 wload4(__amdgpu_buffer_rsrc_t rsrc, unsigned lane16, unsigned s_off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane16, (int)s_off, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
+template <int MT, int NT, int NJ>
+__device__ __forceinline__ void mma_pass_u(const float* xa, __amdgpu_buffer_rsrc_t wrs, unsigned lane16, unsigned s_off,
+                                           unsigned tile_stride_bytes, f32x16 (&acc)[MT][NT]) {
+    static_assert(NJ >= 2, "at least two k-chunks");
+    float4 fb[3][NT], fa[2][MT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        fb[0][ni] = wload4(wrs, lane16, s_off + ni * tile_stride_bytes);
+        fb[1][ni] = wload4(wrs, lane16, s_off + ni * tile_stride_bytes + 1024u);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *reinterpret_cast<const float4*>(xa + mi * 32 * FLD);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (j + 2 < NJ) {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fb[(j + 2) % 3][ni] = wload4(wrs, lane16, s_off + ni * tile_stride_bytes + (unsigned)(j + 2) * 1024u);
+        }
+        if (j + 1 < NJ) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) fa[(j + 1) & 1][mi] = *reinterpret_cast<const float4*>(xa + mi * 32 * FLD + 8 * (j + 1));
+        }
+        // component-major: consecutive MFMAs go to different accumulators wherever the pass has more than one
+#define CIAOSR_MMA_C(c)                                                                                                          \
+        _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                                                                        \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                                                    \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j % 3][ni].c, fa[j & 1][mi].c, acc[mi][ni], 0, 0, 0);
+        CIAOSR_MMA_C(x) CIAOSR_MMA_C(y) CIAOSR_MMA_C(z) CIAOSR_MMA_C(w)
+#undef CIAOSR_MMA_C
+        __builtin_amdgcn_sched_barrier(0);       // the requests stay at the top of their step
+    }
+}
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t frag_rsrc(const void* frag) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(frag), 0, 0xFFFFFFFFu, 0x00020000);
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -158,8 +208,7 @@ __device__ __forceinline__ void hidden_layer(float* X, const void* __restrict__ 
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[MT][2];
     zero_acc<MT, 2>(acc);
-    mma_pass<MT, 2>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(frag) + (size_t)(2 * w) * FNJ * 64 + lane, FNJ,
-                (long)FNJ * 64, acc);
+    mma_pass_u<MT, 2, FNJ>(X + li * FLD + 4 * lh, frag_rsrc(frag), (unsigned)lane * 16u, (unsigned)(2 * w) * (FNJ * 1024u), FNJ * 1024u, acc);
     __syncthreads();   // every wave has finished reading X
     store_relu_tile<MT>(X, acc, bias, w, li, lh);
     __syncthreads();
@@ -201,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
     int* s_qpix = s_kpix + BM;                        // [16]
     int* s_goff = s_qpix + BM / 4;                    // [64]  logit-table row of each (query, sample) row
 
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (BM / 4);          // local query index of row 0
     HPROBE(0);
@@ -299,8 +348,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
         for (int u = w; u < n_units; u += 4) {
             f32x16 acc[MT][1];
             zero_acc<MT, 1>(acc);
-            mma_pass<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.k.frag_out) + (size_t)u * FNJ * 64 + lane,
-                        FNJ, 0, acc);
+            mma_pass_u<MT, 1, FNJ>(X + li * FLD + 4 * lh, frag_rsrc(p.k.frag_out), (unsigned)lane * 16u, (unsigned)u * (FNJ * 1024u), 0u, acc);
             // logit += sum_d q[d] * (key[d] * (w_k[d] + b[d]))   (ciaosr_net.py:203,214)
             float4 bv[4], kv[MT][4], qv[MT][4];
 #pragma unroll
@@ -390,8 +438,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
             }
             f32x16 acc[MT][1];
             zero_acc<MT, 1>(acc);
-            mma_pass<MT, 1>(X + li * FLD + 4 * lh, reinterpret_cast<const float4*>(p.v.frag_out) + (size_t)u * FNJ * 64 + lane,
-                        FNJ, 0, acc);
+            mma_pass_u<MT, 1, FNJ>(X + li * FLD + 4 * lh, frag_rsrc(p.v.frag_out), (unsigned)lane * 16u, (unsigned)u * (FNJ * 1024u), 0u, acc);
             // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
             // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
 #pragma unroll
@@ -428,7 +475,7 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     constexpr int BM = 32 * MT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* X = smem;   // [64][260]
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * BM;
 
@@ -453,9 +500,15 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
             for (int i = 0; i < BM / 4; ++i) *reinterpret_cast<float4*>(X + ((t >> 6) + 4 * i) * FLD + c4) = zv[i];
         }
         __syncthreads();
-        mma_pass<MT, 2>(X + li * FLD + 4 * lh,
-                    reinterpret_cast<const float4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 3)) * 64 + lane,
-                    kc >> 3, (long)p.nj_in * 64, acc);
+        const unsigned s_in = ((unsigned)(2 * w) * (unsigned)p.nj_in + (unsigned)(k0 >> 3)) * 1024u;
+        if (kc == FH)
+            mma_pass_u<MT, 2, FNJ>(X + li * FLD + 4 * lh, frag_rsrc(p.frag_in), (unsigned)lane * 16u, s_in, (unsigned)p.nj_in * 1024u, acc);
+        else if (kc == FH / 2)
+            mma_pass_u<MT, 2, FNJ / 2>(X + li * FLD + 4 * lh, frag_rsrc(p.frag_in), (unsigned)lane * 16u, s_in, (unsigned)p.nj_in * 1024u, acc);
+        else
+            mma_pass<MT, 2>(X + li * FLD + 4 * lh,
+                        reinterpret_cast<const float4*>(p.frag_in) + ((size_t)(2 * w) * p.nj_in + (k0 >> 3)) * 64 + lane,
+                        kc >> 3, (long)p.nj_in * 64, acc);
     }
     __syncthreads();
     store_relu_tile<MT>(X, acc, p.bias_in, w, li, lh);

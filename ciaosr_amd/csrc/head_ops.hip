@@ -257,11 +257,11 @@ __global__ __launch_bounds__(256) void decode_residual_kernel(DecodeP p) {
 //   pixel one of the 3x3 neighbours of the query pixel: 9 rows per LR pixel instead of one 576-wide output
 //   layer per (query, sample) row.  Row r = p*9 + (oy+1)*3 + (ox+1): A[r][d] = U[p][d] * U[p+o][d].
 // ---------------------------------------------------------------------------------------------
-template <int OUT>        // OUT: 0 = fp32 rows; 1 / 2 = rows written as bf16 / half (operand of the 16-bit GEMM)
+template <int OUT>        // OUT: 0 = fp32 rows; 1 / 2 = rows written as bf16 / half (operand of the 16-bit GEMM); 3 = no rows, the bias term c only
 __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ U, int ldu, int D, int H, int W, long row0,
                                                       int nrows, const float* __restrict__ b5, float* __restrict__ A,
                                                       float* __restrict__ G, int ldg) {
-    constexpr bool B16 = OUT != 0;
+    constexpr bool B16 = OUT == 1 || OUT == 2;
     const int lane = threadIdx.x & 63;
     const long rl = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rl >= nrows) return;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
     uint2* a16 = reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(A) + (size_t)rl * D);
     float c = 0.f;
     if (ky < 0 || ky >= H || kx < 0 || kx >= W) {          // this (query pixel, key pixel) pair cannot occur
-        for (int t = lane; t < (D >> 2); t += 64) {
+        for (int t = lane; OUT != 3 && t < (D >> 2); t += 64) {
             if (B16) a16[t] = make_uint2(0u, 0u);
             else a[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -284,13 +284,35 @@ __global__ __launch_bounds__(256) void qk_rows_kernel(const float* __restrict__ 
         for (int t = lane; t < (D >> 2); t += 64) {
             const float4 qv = q[t], kv = k[t], bv = b[t];
             const float4 v = make_float4(qv.x * kv.x, qv.y * kv.y, qv.z * kv.z, qv.w * kv.w);
-            if (B16) a16[t] = pack_h16x4<OUT == 2>(v.x, v.y, v.z, v.w);
+            if (OUT == 3) {}
+            else if (B16) a16[t] = pack_h16x4<OUT == 2>(v.x, v.y, v.z, v.w);
             else a[t] = v;
             c += v.x * bv.x + v.y * bv.y + v.z * bv.z + v.w * bv.w;
         }
         c = wsum(c);
     }
     if (lane == 0) G[(size_t)r * ldg + 256] = c;
+}
+
+// The same table as nine 3x3 CONVOLUTIONS (Winograd route, dense_wino_f32.hip wino_table_f32): with U[p][c*9 + k] = F[p + k][c] (the
+// unfold, zero padded), G[p, o][n] = sum_k sum_c Pi_o[p + k][c] W5[c*9 + k][n], Pi_o[x][c] = F[x][c] F[x + o][c] -- a 64 -> 256
+// convolution of the product map Pi_o, which a 576-deep GEMM row per (p, o) recomputes nine times over.  Maps: Pi[o][pix][C].
+__global__ __launch_bounds__(256) void qk_maps_kernel(const float* __restrict__ F, int ldf, int C4, int H, int W, float* __restrict__ Pi) {
+    const long HW = (long)H * W, per = HW * C4;
+    const long i = blockIdx.x * 256L + threadIdx.x;
+    if (i >= 9 * per) return;
+    const int o = (int)(i / per);
+    const long r = i - o * per;
+    const int pix = (int)(r / C4), c4 = (int)(r - (long)pix * C4);
+    const int y = pix / W, x = pix - y * W;
+    const int ky = y + o / 3 - 1, kx = x + o % 3 - 1;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ky >= 0 && ky < H && kx >= 0 && kx < W) {
+        const float4 a = reinterpret_cast<const float4*>(F + (size_t)pix * ldf)[c4];
+        const float4 b = reinterpret_cast<const float4*>(F + ((size_t)ky * W + kx) * ldf)[c4];
+        v = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+    }
+    reinterpret_cast<float4*>(Pi)[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -328,6 +350,9 @@ int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, 
     if (rows_h16 == 2)
         hipLaunchKernelGGL(qk_rows_kernel<2>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
                            A, G, ldg);
+    else if (rows_h16 == 3)
+        hipLaunchKernelGGL(qk_rows_kernel<3>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
+                           A, G, ldg);
     else if (rows_h16 == 1)
         hipLaunchKernelGGL(qk_rows_kernel<1>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
                            A, G, ldg);
@@ -335,6 +360,14 @@ int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, 
         hipLaunchKernelGGL(qk_rows_kernel<0>, dim3(ceil_div(nrows, 4)), dim3(256), 0, s, U, ldu, D, H, W, row0, nrows, bias_out,
                            A, G, ldg);
     return launch_status("qk_rows");
+}
+
+int qk_maps(const float* F, int ldf, int C, int H, int W, float* Pi, hipStream_t s) {
+    CIAOSR_CHECK_ARG(F && Pi && (C & 3) == 0 && (ldf & 3) == 0 && aligned16(F) && aligned16(Pi));
+    ProfScope prof("head_qk_maps", s);
+    const long n = 9L * H * W * (C / 4);
+    hipLaunchKernelGGL(qk_maps_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, F, ldf, C / 4, H, W, Pi);
+    return launch_status("qk_maps");
 }
 
 // out[n][k] (bf16 or half, row stride K) = W[k][n] (fp32, row stride ld): the [N][K] operand of the 16-bit NT GEMM

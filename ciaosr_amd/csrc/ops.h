@@ -65,6 +65,8 @@ int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float
 // dense_wino_f32.hip: fp32 dense layers of big maps in Winograd F(2x2, 3x3) form
 int dense_wino_tiles(int H, int W);
 int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino, const float* bias, int n_img, hipStream_t s);
+// nine 3x3 convolutions 64 -> 64 n_blk of the maps Pi[9][H*W][64] into out[(pix * 9 + o) * ldg + n] (logit table of the fused head)
+int wino_table_f32(const float* Pi, int H, int W, const float* frag_wino, int n_blk, float* out, int ldg, hipStream_t s);
 // csa_scores_f32.hip: fp32 cs_attn correlation scores as a 3x3 diagonal box sum of the per-pixel correlation (Ch = 32)
 bool csa_scores_box_ok(int Ch, int ldm, int ldr);
 int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, int ldr, int Hl, int Wl, int Ch, float alpha, float floor_,
@@ -99,7 +101,8 @@ int head_indices(const float* coord, const float* cell, long q0, int nq, int chu
                  int* q_idx, int* k_idx, float* rel, hipStream_t s);
 int head_rows(const HeadRowsP& p, hipStream_t s);
 int qk_rows(const float* U, int ldu, int D, int H, int W, long row0, int nrows, const float* bias_out, float* A, float* G,
-            int ldg, int rows_h16 /* 0 fp32 rows, 1 bf16, 2 half */, hipStream_t s);
+            int ldg, int rows_h16 /* 0 fp32 rows, 1 bf16, 2 half, 3 no rows (the bias term only) */, hipStream_t s);
+int qk_maps(const float* F, int ldf, int C, int H, int W, float* Pi, hipStream_t s);
 int transpose_cast_h16(const float* W, int ld, int K, int N, unsigned short* out, bool f16, hipStream_t s);
 int local_attention(const LocalAttnP& p, hipStream_t s);
 int decode_residual(const DecodeP& p, hipStream_t s);

@@ -135,6 +135,20 @@ class PackedHead:
         keep = []
         nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
         st.k, kk, sk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
+        st.k_out_wino = None
+        w5 = self._last_wb[0]                                   # imnet_k's output layer [9C][256], rows in device order (tap, c)
+        if unfold and Cc == 64 and tuple(w5.shape) == (576, 256):
+            # the logit table as nine 3x3 convolutions (head.hip): g[n][c][a][b] = W5[(3a+b) C + c][n] in Winograd F(2x2, 3x3) form,
+            # U = G g G^T in fp64, rounded once; position p = 4 i + j as its own [256][64] matrix in MFMA fragment order
+            Gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=dev)
+            Uw = torch.einsum('ia,abcn,jb->ijnc', Gm, w5.view(3, 3, 64, 256).double(), Gm).float().contiguous()   # [4][4][256][64]
+            nfl = _lib.load().ciaosr_fragment_floats(256, 64)
+            fw = torch.empty(16 * nfl, dtype=torch.float32, device=dev)
+            for pos in range(16):
+                _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(Uw[pos // 4, pos % 4]), 64, 256, 64,
+                          C.c_void_p(fw.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
+            kk = kk + [fw]
+            st.k_out_wino = fw.data_ptr()
         st.v, kv, sv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
         st.q, kq, sq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
         self._q_last = self._last_wb

@@ -62,6 +62,8 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
  * _f32 / _bf16 / _f16 suffix, and every route choice is an argument.  `opt` may be NULL (all defaults); a zero field means
  * "default".  The struct only selects between result-equivalent evaluation routes (tests force each of them). */
 #define CIAOSR_HEAD_STAGED 1          /* head_route bit 0: per-layer GEMM path instead of the fused kernels */
+#define CIAOSR_HEAD_TABLE_GEMM 4      /* head_route bit 2: _f32 logit table as the 576-deep GEMM of (q*key) rows even when
+                                       * ciaosr_head_weights_t.k_out_wino is given */
 #define CIAOSR_HEAD_NO_LOGIT_TABLE 2  /* head_route bit 1: fused path, imnet_k output layer on the MFMA per (query, sample)
                                        * row instead of the exact 9-rows-per-LR-pixel fold */
 typedef struct ciaosr_options {
@@ -213,6 +215,12 @@ typedef struct ciaosr_head_weights {
      * imnet_q: in = 9C + Cn, out = 3.                                             net:62,74
      * Layer-0 columns and last-layer rows are in device channel order. */
     ciaosr_mlp_t q, k, v;
+    /* optional (C = 64, feat_unfold, 256-wide last hidden layer of imnet_k): imnet_k's OUTPUT layer W5 [9C][256] read as the 3x3
+     * convolution g[n][c][a][b] = W5[(3 a + b) C + c][n] (rows in device order) in Winograd F(2x2, 3x3) form, U[p] = (G g G^T)[p], p = 4 i + j = 0..15,
+     * each [256][64] matrix packed by ciaosr_pack_fragments_f32, the 16 arrays back to back.  Lets the _f32 entry build the logit
+     * table of maps of 512 .. 65536 LR pixels as nine convolutions of product maps instead of a 576-deep GEMM row per
+     * (pixel, key offset): 9 x 2.25 fewer multiplies (head_ops.hip qk_maps, dense_wino_f32.hip).  NULL = the GEMM */
+    const float* k_out_wino;
 } ciaosr_head_weights_t;
 
 /* Grid-centre coordinates and cells of an Ht x Wt target: coord[q] = (seq_y[i], seq_x[j]) with

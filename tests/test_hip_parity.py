@@ -380,16 +380,20 @@ def test_fused_and_staged_head_paths_agree(dev):
     ht, wt = 59, 83                         # Q = 4897: not a multiple of 16 or 64
     coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
     x = (randn((1, 3, 21, 30), 12) * 0.3).to(dev)
-    from ciaosr_amd._lib import HEAD_STAGED, HEAD_NO_LOGIT_TABLE
+    from ciaosr_amd._lib import HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM
     staged = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(head_route=HEAD_STAGED)).cpu()
+    with hip_ops.profile():                  # logit table as the 576-deep GEMM of (q*key) rows
+        fused_gemm = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(head_route=HEAD_TABLE_GEMM)).cpu()
+    assert 'head_qk_maps' not in hip_ops.profile.results()
     # fused kernels, imnet_k output layer on the MFMA per row
     fused_mfma = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(head_route=HEAD_NO_LOGIT_TABLE)).cpu()
-    with hip_ops.profile():                  # default route: fused kernels + exact logit table (9 rows per LR pixel)
-        fused = g._predict([feat], coord, cell, 30000, x).cpu()
+    with hip_ops.profile():                  # default route: fused kernels + logit table (9 rows per LR pixel) as nine Winograd
+        fused = g._predict([feat], coord, cell, 30000, x).cpu()     # convolutions of the product maps (C = 64; ragged 8x16 tiles here)
     prof = hip_ops.profile.results()
-    assert 'head_kv_fused' in prof and 'head_logit_table' in prof, 'fused kernels / logit table did not run'
+    assert 'head_kv_fused' in prof and 'head_logit_table' in prof and 'head_qk_maps' in prof, 'fused kernels / logit table did not run'
     tol = 5e-5 * max(1.0, staged.abs().max().item())
-    assert (fused - staged).abs().max() < tol and (fused_mfma - staged).abs().max() < tol
+    print('fused - staged', (fused - staged).abs().max().item(), 'gemm table - staged', (fused_gemm - staged).abs().max().item(), 'tol', tol)
+    assert (fused - staged).abs().max() < tol and (fused_mfma - staged).abs().max() < tol and (fused_gemm - staged).abs().max() < tol
 
 
 def test_as_written_staged_route_vs_golden_and_fused(dev):

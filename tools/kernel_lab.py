@@ -26,7 +26,7 @@ for v in variants:
         model.restore(lq, options=opt)
         torch.cuda.synchronize()
     prof = hip_ops.profile.results()
-    top = sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])[:9]
+    top = sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])[:16]
     if ref is None:
         ref = out
     d = (out - ref).abs()
