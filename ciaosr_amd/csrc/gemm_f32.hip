@@ -19,7 +19,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CIAOSR_GEMM32_TNK
 #define CIAOSR_GEMM32_TNK 24
 #endif
-constexpr int BM = 128, BN = 128, BK = 32;
+#ifndef CIAOSR_GEMM32_BK
+#define CIAOSR_GEMM32_BK 32
+#endif
+constexpr int BM = 128, BN = 128, BK = CIAOSR_GEMM32_BK;   // BK = 32 or 16
+constexpr int F4R = BK / 4;              // float4 per tile row
+constexpr int NSA = BM * F4R / 256;      // tile float4 per thread (A, and B of the NT form)
+constexpr int NSB = BK * (BN / 4) / 256; // ... of the [k][n] image of B
 constexpr int LDS_A = BK + 4;   // 36 floats / row (NT layouts)
 constexpr int LDS_BKN = BN + 4; // 132 floats / row for the [k][n] image
 constexpr int A_TILE = BM * LDS_A;                                        // 4608 floats
@@ -93,23 +99,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     auto load_tiles = [&](int kt, int n0) {
         const int k0 = kt * BK;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NSA; ++s) {
             const int idx = t + 256 * s;
-            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int r = idx / F4R, c4 = (idx % F4R) * 4;
             const int gm = m0 + r, gk = k0 + c4;
             ra[s] = buf_ld4(rs_a, (gm < p.M && gk < p.K) ? ((unsigned)gm * (unsigned)p.lda + (unsigned)gk) * 4u : kOobG);
         }
         if (!B_KN) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NSA; ++s) {
                 const int idx = t + 256 * s;
-                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                const int r = idx / F4R, c4 = (idx % F4R) * 4;
                 const int gn = n0 + r, gk = k0 + c4;
                 rb[s] = buf_ld4(rs_b, (gn < p.N && gk < p.K) ? ((unsigned)gn * (unsigned)p.ldb + (unsigned)gk) * 4u : kOobG);
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NSB; ++s) {
                 const int idx = t + 256 * s;
                 const int kr = idx >> 5, n4 = (idx & 31) * 4;
                 const int gk = k0 + kr, gn = n0 + n4;
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     float2 ast[4];
     if (p.a_stats) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int gm = m0 + ((t + 256 * s) >> 3);
+        for (int s = 0; s < NSA; ++s) {
+            const int gm = m0 + ((t + 256 * s) / F4R);
             ast[s] = gm < p.M ? p.a_stats[(size_t)gm * p.a_stats_stride] : make_float2(0.f, 0.f);
         }
     }
@@ -131,9 +137,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
         float* b = Bs + buf * B_TILE;
         const int k0 = kt * BK;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NSA; ++s) {
             const int idx = t + 256 * s;
-            const int r = idx >> 3, c4 = (idx & 7) * 4;
+            const int r = idx / F4R, c4 = (idx % F4R) * 4;
             float4 v = ra[s];
             if (p.a_stats) {                                          // uniform; 3 VALU per element: one FMA, v_exp_f32, one multiply
                 constexpr float kL2e = 1.4426950408889634f;
@@ -146,14 +152,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
         }
         if (!B_KN) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NSA; ++s) {
                 const int idx = t + 256 * s;
-                const int r = idx >> 3, c4 = (idx & 7) * 4;
+                const int r = idx / F4R, c4 = (idx % F4R) * 4;
                 *reinterpret_cast<float4*>(b + r * LDS_A + c4) = mask4(rb[s], k0 + c4, p.K);
             }
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NSB; ++s) {
                 const int idx = t + 256 * s;
                 const int kr = idx >> 5, n4 = (idx & 31) * 4;
                 *reinterpret_cast<float4*>(b + kr * LDS_BKN + n4) = mask4(rb[s], n0 + n4, p.N);
@@ -217,32 +223,38 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
         const float* a = As + cur * A_TILE + (wm * 64 + li) * LDS_A + 4 * lh;
         const float* b = B_KN ? (Bs + cur * B_TILE + (4 * lh) * LDS_BKN + wn * 64 + li)
                               : (Bs + cur * B_TILE + (wn * 64 + li) * LDS_A + 4 * lh);
+        // Fragments of chunk j + 1 are requested BEFORE the 16 MFMAs of chunk j, into the other of two static register stages, and a
+        // scheduling barrier keeps them there: left alone hipcc reads a chunk's fragments right in front of its MFMAs (or sinks the
+        // requests into the MFMA stream to shorten live ranges), and every 8 MFMAs then wait for an LDS round trip that only the
+        // SIMD's other wave can cover (ablation, 192x192 tile: MFMAs + fragment reads alone ran at 0.82 of the matrix peak).
+        // Component-major MFMA order: consecutive instructions go to different accumulators.
+        float4 fa[2][2], fb[2][2];
+        auto read_frags = [&](int j, float4 (&xa)[2], float4 (&xb)[2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < BK / 8; ++j) {
-            float4 fa[2], fb[2];
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                fa[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * LDS_A + 8 * j);
+            for (int mi = 0; mi < 2; ++mi) xa[mi] = *reinterpret_cast<const float4*>(a + mi * 32 * LDS_A + 8 * j);
             if (!B_KN) {
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    fb[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * LDS_A + 8 * j);
+                for (int ni = 0; ni < 2; ++ni) xb[ni] = *reinterpret_cast<const float4*>(b + ni * 32 * LDS_A + 8 * j);
             } else {
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const float* bb = b + (8 * j) * LDS_BKN + ni * 32;
-                    fb[ni] = make_float4(bb[0], bb[LDS_BKN], bb[2 * LDS_BKN], bb[3 * LDS_BKN]);
+                    xb[ni] = make_float4(bb[0], bb[LDS_BKN], bb[2 * LDS_BKN], bb[3 * LDS_BKN]);
                 }
             }
+        };
+        read_frags(0, fa[0], fb[0]);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].x, fb[ni].x, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].y, fb[ni].y, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].z, fb[ni].z, acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi].w, fb[ni].w, acc[mi][ni], 0, 0, 0);
-                }
+        for (int j = 0; j < BK / 8; ++j) {
+            if (j + 1 < BK / 8) read_frags(j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#define CIAOSR_GEMM_C(c)                                                                                                  \
+            _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                              \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                          \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][mi].c, fb[j & 1][ni].c, acc[mi][ni], 0, 0, 0);
+            CIAOSR_GEMM_C(x) CIAOSR_GEMM_C(y) CIAOSR_GEMM_C(z) CIAOSR_GEMM_C(w)
+#undef CIAOSR_GEMM_C
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (i + 1 < total) store_tiles(cur ^ 1, n_kt, n_tile * BN);
         if constexpr (MULTI) {

@@ -584,7 +584,10 @@ constexpr size_t fused_kv_lds() {
 int head_kv_fused(const FusedKVP& p, hipStream_t s) {
     CIAOSR_BIG_LDS(head_kv_fused_kernel<1>, fused_kv_lds<1>());
     CIAOSR_BIG_LDS(head_kv_fused_kernel<2>, fused_kv_lds<2>());
-    const int rows = p.rows_per_wg == 64 ? 64 : 32;   // 64: experiments (ciaosr_options_t.kv_rows)
+    // 64-row workgroups (two per CU) once they fill the chip a few times over: every weight fragment feeds two row tiles, and since
+    // the k loop stopped waiting per step (mma_pass_u) that outweighs the fourth resident workgroup of the 32-row form
+    // (C3 tile: 19.9 -> 18.9 ms; before the unrolled pass the 64-row form measured 3-14 % slower).  Same result bit for bit.
+    const int rows = p.rows_per_wg == 64 || (p.rows_per_wg != 32 && ceil_div(p.nq, 16) >= 2048) ? 64 : 32;
     ProfScope prof("head_kv_fused", s);
     if (rows == 64)
         hipLaunchKernelGGL(head_kv_fused_kernel<2>, dim3(ceil_div(p.nq, 16)), dim3(256), fused_kv_lds<2>(), s, p);

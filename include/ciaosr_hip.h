@@ -74,7 +74,7 @@ typedef struct ciaosr_options {
                              * 0 = default (128), < 0 = never */
     int scatter_small_max;  /* RDN trunk: largest map (pixels) for the small-map dense-block kernels; 0 = default (18432),
                              * < 0 = never */
-    int kv_rows;            /* fp32 fused head: (query, sample) rows per workgroup, 32 (default) or 64 */
+    int kv_rows;            /* fp32 fused head: (query, sample) rows per workgroup, 32 or 64; 0 = automatic (64 from 32768 queries) */
     int decode_rows;        /* fp32 fused decode: queries per workgroup, 32 (default) or 64 */
     int bf16_single;        /* _bf16 entries: 0 (default) = every weight enters the MFMA as a bf16 PAIR hi + lo (hi = bf16(w),
                              * lo = bf16(w - hi): 16 mantissa bits, two MFMAs per product); 1 = hi only (one MFMA, 8 bits).

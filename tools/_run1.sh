@@ -1,3 +1,3 @@
-python tools/enc_lab.py fp32 8 2>&1 | tail -n 1
-python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-260
-timeout 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "rdn_trunk or encoder_features or fused_and_staged or full_c3_tile or tile_batch or tile_streams or e2e_restorer" 2>&1 | tail -n 3
+python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-330
+CIAOSR_HIP_LIB=$PWD/ciaosr_amd/csrc/libciaosr_bk16.so python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-330
+CIAOSR_HIP_LIB=$PWD/ciaosr_amd/csrc/libciaosr_bk16.so timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "gemm or csattn" 2>&1 | tail -n 3

@@ -9,7 +9,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // MODE 0: K VALU behind every MFMA; 1: the 4 K VALU of a round in one cluster behind its 4 MFMAs; 2: as 0 with v_pk_fma_f32 (K/2 instructions);
 // 3: 16 MFMAs, then their 16 K VALU in one cluster (the shape hipcc gives the Winograd step)
-template <int K, int L, int MODE>
+template <int K, int L, int MODE, int H16 = 0>
 __global__ __launch_bounds__(1024) void bench(float* out, unsigned long long* cyc, int rounds) {
     __shared__ float4 lds[4096];
     const int t = threadIdx.x;
@@ -24,6 +24,9 @@ __global__ __launch_bounds__(1024) void bench(float* out, unsigned long long* cy
     for (int i = 0; i < 4; ++i) dd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    f16x8 ha, hb;
+    for (int i = 0; i < 8; ++i) { ha[i] = (_Float16)(a + i); hb[i] = (_Float16)(b - i); }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 px[4];
     for (int i = 0; i < 4; ++i) px[i] = f32x2{x[i], x[i + 4]};
@@ -39,7 +42,8 @@ __global__ __launch_bounds__(1024) void bench(float* out, unsigned long long* cy
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            if (H16) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc[j], 0, 0, 0);
+            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
             if (MODE == 0) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[(j * K + k) & 7]) : "v"(a));
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(1024) void bench(float* out, unsigned long long* cy
     if ((t & 63) == 0) atomicMax(&cyc[blockIdx.x], t1 - t0);
 }
 
-template <int K, int L, int MODE = 0>
+template <int K, int L, int MODE = 0, int H16 = 0>
 static void run(int waves_per_simd) {
     float* out; unsigned long long* cyc;
     const int rounds = 2000, grid = 256, block = 256 * waves_per_simd;
@@ -72,7 +76,7 @@ static void run(int waves_per_simd) {
     hipMalloc(&cyc, sizeof(unsigned long long) * grid);
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(cyc, 0, sizeof(unsigned long long) * grid);
-        hipLaunchKernelGGL((bench<K, L, MODE>), dim3(grid), dim3(block), 0, 0, out, cyc, rounds);
+        hipLaunchKernelGGL((bench<K, L, MODE, H16>), dim3(grid), dim3(block), 0, 0, out, cyc, rounds);
     }
     hipDeviceSynchronize();
     unsigned long long h[256];
@@ -82,7 +86,7 @@ static void run(int waves_per_simd) {
     avg /= grid;
     const double per_mfma = avg / (rounds * 4.0 * waves_per_simd);
     static const char* mode[] = {"interleaved", "cluster per 4 MFMAs", "packed (K/2 v_pk_fma)", "cluster per 16 MFMAs"};
-    printf("waves/SIMD %d  VALU per MFMA %2d (%s)  ds_read_b128 per 4 MFMA %d : %.1f cycles per MFMA on the SIMD (64 = peak, slowest wave)\n", waves_per_simd, K, mode[MODE], L, per_mfma);
+    printf("%s waves/SIMD %d  VALU per MFMA %2d (%s)  ds_read_b128 per 4 MFMA %d : %.1f cycles per MFMA on the SIMD (peak: 64 f32 / 32 f16, slowest wave)\n", H16 ? "f16 32x32x16" : "f32 32x32x2 ", waves_per_simd, K, mode[MODE], L, per_mfma);
     hipFree(out); hipFree(cyc);
 }
 
@@ -91,6 +95,7 @@ int main() {
         run<0, 0>(w); run<1, 0>(w); run<2, 0>(w); run<3, 0>(w); run<4, 0>(w); run<6, 0>(w); run<8, 0>(w);
         run<2, 0, 1>(w); run<4, 0, 1>(w); run<2, 0, 3>(w); run<4, 0, 3>(w); run<4, 0, 2>(w); run<8, 0, 2>(w);
         run<0, 1>(w); run<0, 2>(w); run<0, 4>(w); run<2, 2>(w); run<4, 2, 2>(w);
+        run<0, 0, 0, 1>(w); run<1, 0, 0, 1>(w); run<2, 0, 0, 1>(w); run<4, 0, 0, 1>(w); run<8, 0, 0, 1>(w); run<2, 0, 1, 1>(w); run<4, 0, 1, 1>(w); run<4, 0, 3, 1>(w); run<4, 0, 2, 1>(w); run<0, 2, 0, 1>(w); run<0, 4, 0, 1>(w);
     }
     return 0;
 }
