@@ -74,11 +74,17 @@ static void run(int waves_per_simd) {
     const int rounds = 2000, grid = 256, block = 256 * waves_per_simd;
     hipMalloc(&out, sizeof(float) * grid * block);
     hipMalloc(&cyc, sizeof(unsigned long long) * grid);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0.f;
     for (int rep = 0; rep < 2; ++rep) {
         hipMemset(cyc, 0, sizeof(unsigned long long) * grid);
+        hipEventRecord(e0, 0);
         hipLaunchKernelGGL((bench<K, L, MODE, H16>), dim3(grid), dim3(block), 0, 0, out, cyc, rounds);
+        hipEventRecord(e1, 0);
     }
     hipDeviceSynchronize();
+    hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[256];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     double avg = 0;
@@ -86,7 +92,7 @@ static void run(int waves_per_simd) {
     avg /= grid;
     const double per_mfma = avg / (rounds * 4.0 * waves_per_simd);
     static const char* mode[] = {"interleaved", "cluster per 4 MFMAs", "packed (K/2 v_pk_fma)", "cluster per 16 MFMAs"};
-    printf("%s waves/SIMD %d  VALU per MFMA %2d (%s)  ds_read_b128 per 4 MFMA %d : %.1f cycles per MFMA on the SIMD (peak: 64 f32 / 32 f16, slowest wave)\n", H16 ? "f16 32x32x16" : "f32 32x32x2 ", waves_per_simd, K, mode[MODE], L, per_mfma);
+    printf("%s waves/SIMD %d  VALU per MFMA %2d (%s)  ds_read_b128 per 4 MFMA %d : %.1f cycles per MFMA on the SIMD (peak: 64 f32 / 32 f16, slowest wave); kernel %.3f ms by HIP events = %.2f counter ticks per ns\n", H16 ? "f16 32x32x16" : "f32 32x32x2 ", waves_per_simd, K, mode[MODE], L, per_mfma, ms, avg / (ms * 1e6));
     hipFree(out); hipFree(cyc);
 }
 
