@@ -1,1 +1,3 @@
-for a in 0 14 30; do echo "abl $a"; CIAOSR_GEMM_ABL=$a python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | grep -o "csa_attn_v=[0-9.]*"; done
+python tools/enc_lab.py fp32 8 2>&1 | tail -n 1
+for v in 1 4; do CIAOSR_HIP_LIB=$PWD/ciaosr_amd/csrc/libciaosr_st$v.so python tools/enc_lab.py fp32 8 2>&1 | tail -n 1; done
+CIAOSR_WINO_PERSIST=0 python tools/enc_lab.py fp32 8 2>&1 | tail -n 1
