@@ -396,6 +396,32 @@ def test_fused_and_staged_head_paths_agree(dev):
     assert (fused - staged).abs().max() < tol and (fused_mfma - staged).abs().max() < tol and (fused_gemm - staged).abs().max() < tol
 
 
+@pytest.mark.parametrize('hw', [(37, 53), (64, 64), (23, 24)])
+def test_logit_table_winograd_route_matches_gemm_route(dev, hw):
+    """The fp32 logit table built as nine Winograd F(2x2, 3x3) convolutions of the product maps Pi_o = F . shift_o(F)
+    (head_ops.hip qk_maps + dense_wino_f32.hip wino_table_f32; default from 512 LR pixels at C = 64) against the 576-deep GEMM of
+    (q * key) rows (`head_route` bit CIAOSR_HEAD_TABLE_GEMM): the same sums re-associated through the transform.  Ragged 8x16 tiles in
+    both directions, a map that is exactly tiled, and one just above the threshold."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd._lib import HEAD_TABLE_GEMM
+    from ciaosr_amd.coords import make_coord, make_cell
+    h, w = hw
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 5, head_gain=2.0), dev, eval_bsize=30000)
+    feat = randn((1, 64, h, w), 21).to(dev)
+    ht, wt = 3 * h, 3 * w
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    x = (randn((1, 3, h, w), 22) * 0.3).to(dev)
+    with hip_ops.profile():
+        wino = g._predict([feat], coord, cell, 30000, x).cpu()
+    assert 'head_qk_maps' in hip_ops.profile.results()
+    with hip_ops.profile():
+        gemm = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(head_route=HEAD_TABLE_GEMM)).cpu()
+    assert 'head_qk_maps' not in hip_ops.profile.results()
+    d = (wino - gemm).abs().max().item()
+    print(f'{h}x{w}: Winograd table vs GEMM table max |delta| {d:.2e} (output scale {gemm.abs().max().item():.2f})')
+    assert d < 2e-5 * max(1.0, gemm.abs().max().item()), d
+
+
 def test_as_written_staged_route_vs_golden_and_fused(dev):
     """Third evaluation route: the reference's op order through the staged C entry points with no algebraic
     restructuring (ciaosr_gather_rows_f32 -> ciaosr_mlp_forward_f32 x2 -> ciaosr_local_attention_f32 ->
