@@ -1,15 +1,17 @@
 // Exact-fp32 MFMA GEMM for gfx950:  C = act((A . B^T + bias) * alpha)
 //
 // v_mfma_f32_32x32x2_f32 (64 cycles/SIMD, 157 TFLOP/s chip peak, bitwise an fmaf chain).
-// Tile 128x128x32, 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA tiles
+// Tile 128x128x16 (BK below), 256 threads = 4 waves as 2(M) x 2(N), each wave 64x64 = 2x2 MFMA tiles
 // (64 accumulator VGPRs).  A and B tiles are staged through LDS with a register prefetch of the
-// next K-tile and two LDS buffers (one barrier per K-tile).  LDS rows are padded to 36 floats so
+// next K-tile and two LDS buffers (one barrier per K-tile).  LDS rows are padded to BK + 4 floats so
 // the per-lane float4 fragment reads (ds_read_b128) are bank-conflict free; one float4 feeds four
 // MFMAs because the k index inside a fragment is free to be permuted consistently on A and B:
 // lane (i = l&31, h = l>>5) holds k = 8j + 4h + e for MFMA e of chunk j.
 //
 // Replaces torch addmm / conv2d(1x1) / conv_transpose2d-as-GEMM of the reference
 // (mlp_refiner.py:79-89, arch_csnln.py:452-453,475,499-500,511,516).
+#include <type_traits>
+
 #include "common.h"
 
 namespace ciaosr {
@@ -19,8 +21,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef CIAOSR_GEMM32_TNK
 #define CIAOSR_GEMM32_TNK 24
 #endif
+// k-tile depth 16 (round 3): 40 KB of LDS per workgroup = THREE workgroups per CU (768 slots: the 2304 tiles of the attn.V contraction
+// are 3.0 rounds instead of 4.5 of 512), affordable since the k loop carries no per-tile VALU work any more.  C3 tile: csa_attn_v
+// 6.12 -> 5.73 ms, head_table 0.41 -> 0.28 ms (32 stays selectable at build time)
 #ifndef CIAOSR_GEMM32_BK
-#define CIAOSR_GEMM32_BK 32
+#define CIAOSR_GEMM32_BK 16
 #endif
 constexpr int BM = 128, BN = 128, BK = CIAOSR_GEMM32_BK;   // BK = 32 or 16
 constexpr int F4R = BK / 4;              // float4 per tile row
@@ -60,6 +65,12 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned 
     const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, 0, 0);
     return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
 }
+// the same load with a wave-uniform byte offset in the scalar operand (not part of the range check: an out-of-range per-lane offset
+// stays out of range)
+__device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned s_off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)byte_off, (int)s_off, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
 __device__ __forceinline__ float4 mask4(float4 v, int first, int limit) {
     if (first + 1 >= limit) v.y = 0.f;
     if (first + 2 >= limit) v.z = 0.f;
@@ -68,7 +79,8 @@ __device__ __forceinline__ float4 mask4(float4 v, int first, int limit) {
 }
 
 // MULTI: several column tiles per workgroup in one pipeline; plain epilogue only ((acc + bias) * alpha, no activation, no split-K)
-template <bool B_KN, bool MULTI>
+// SM: A holds logits and p.a_stats their row statistics -- the staging writes probabilities (row softmax applied on the fly)
+template <bool B_KN, bool MULTI, bool SM = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                  // [2][A_TILE]
@@ -96,75 +108,117 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.B), 0, p.b_bytes, 0x00020000);
 
-    auto load_tiles = [&](int kt, int n0) {
-        const int k0 = kt * BK;
+    // The k loop carries no per-load address or validity arithmetic on the VALU (every VALU instruction of a SIMD costs its fp32 matrix
+    // pipe ~4 cycles, tools/ubench/mfma_valu.hip; ablation at the attn.V shape: MFMAs + fragment reads alone 0.92 of the peak, the full
+    // loop 0.79, of which ~80 VALU per 64 MFMAs of offsets, selects and masks were the larger part): per-thread byte offsets are formed
+    // once per column tile (a row / column past the edge = an out-of-range offset: the descriptor returns zeros), the k-tile enters as
+    // the SCALAR offset of the load, and the selects of a ragged K run on a uniform branch that only the last k-tile takes.
+    unsigned offA[NSA], offB[NSA > NSB ? NSA : NSB];
 #pragma unroll
-        for (int s = 0; s < NSA; ++s) {
-            const int idx = t + 256 * s;
-            const int r = idx / F4R, c4 = (idx % F4R) * 4;
-            const int gm = m0 + r, gk = k0 + c4;
-            ra[s] = buf_ld4(rs_a, (gm < p.M && gk < p.K) ? ((unsigned)gm * (unsigned)p.lda + (unsigned)gk) * 4u : kOobG);
-        }
+    for (int s = 0; s < NSA; ++s) {
+        const int idx = t + 256 * s;
+        const int gm = m0 + idx / F4R;
+        offA[s] = gm < p.M ? ((unsigned)gm * (unsigned)p.lda + (unsigned)((idx % F4R) * 4)) * 4u : kOobG;
+    }
+    auto set_cols = [&](int n0) __attribute__((always_inline)) {
         if (!B_KN) {
 #pragma unroll
             for (int s = 0; s < NSA; ++s) {
                 const int idx = t + 256 * s;
-                const int r = idx / F4R, c4 = (idx % F4R) * 4;
-                const int gn = n0 + r, gk = k0 + c4;
-                rb[s] = buf_ld4(rs_b, (gn < p.N && gk < p.K) ? ((unsigned)gn * (unsigned)p.ldb + (unsigned)gk) * 4u : kOobG);
+                const int gn = n0 + idx / F4R;
+                offB[s] = gn < p.N ? ((unsigned)gn * (unsigned)p.ldb + (unsigned)((idx % F4R) * 4)) * 4u : kOobG;
             }
         } else {
 #pragma unroll
             for (int s = 0; s < NSB; ++s) {
                 const int idx = t + 256 * s;
-                const int kr = idx >> 5, n4 = (idx & 31) * 4;
-                const int gk = k0 + kr, gn = n0 + n4;
-                rb[s] = buf_ld4(rs_b, (gk < p.K && gn < p.N) ? ((unsigned)gk * (unsigned)p.ldb + (unsigned)gn) * 4u : kOobG);
+                const int gn = n0 + (idx & 31) * 4;
+                offB[s] = gn < p.N ? ((unsigned)(idx >> 5) * (unsigned)p.ldb + (unsigned)gn) * 4u : kOobG;      // rows k >= K lie past the descriptor's end
             }
+        }
+    };
+    const bool k_ragged = (p.K % BK) != 0;                       // uniform
+    int cols_n0 = -1;
+    auto load_tiles = [&](int kt, int n0) __attribute__((always_inline)) {
+        if (n0 != cols_n0) { set_cols(n0); cols_n0 = n0; }       // uniform: once per column tile
+        const int k0 = kt * BK;
+        const unsigned sk = (unsigned)k0 * 4u;
+        if (k_ragged && k0 + BK > p.K) {                         // last k-tile of a ragged K: float4s wholly past K are not read
+#pragma unroll
+            for (int s = 0; s < NSA; ++s) {
+                const bool in = k0 + ((t + 256 * s) % F4R) * 4 < p.K;
+                ra[s] = buf_ld4s(rs_a, in ? offA[s] : kOobG, sk);
+                if (!B_KN) rb[s] = buf_ld4s(rs_b, in ? offB[s] : kOobG, sk);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NSA; ++s) ra[s] = buf_ld4s(rs_a, offA[s], sk);
+            if (!B_KN) {
+#pragma unroll
+                for (int s = 0; s < NSA; ++s) rb[s] = buf_ld4s(rs_b, offB[s], sk);
+            }
+        }
+        if (B_KN) {
+            const unsigned skb = (unsigned)k0 * (unsigned)p.ldb * 4u;
+#pragma unroll
+            for (int s = 0; s < NSB; ++s) rb[s] = buf_ld4s(rs_b, offB[s], skb);
         }
     };
     // row-softmax statistics of this thread's four A rows (rows t / 8 + 32 s), when A holds logits
     float2 ast[4];
-    if (p.a_stats) {
+    if constexpr (SM) {
 #pragma unroll
         for (int s = 0; s < NSA; ++s) {
             const int gm = m0 + ((t + 256 * s) / F4R);
             ast[s] = gm < p.M ? p.a_stats[(size_t)gm * p.a_stats_stride] : make_float2(0.f, 0.f);
         }
     }
-    auto store_tiles = [&](int buf, int kt, int n0) {
-        float* a = As + buf * A_TILE;
-        float* b = Bs + buf * B_TILE;
+    const bool k_ragged4 = k_ragged && (p.K & 3) != 0;          // a float4 can straddle K
+    const bool n_ragged4 = B_KN && (p.N & 3) != 0;               // ... or N (the [k][n] image)
+    // this thread's LDS store slots: one base per operand, the element index an immediate of the ds instruction
+    const int sa_off = (t / F4R) * LDS_A + (t % F4R) * 4;                     // + s * (256 / F4R) rows
+    const int sb_off = B_KN ? (t >> 5) * LDS_BKN + (t & 31) * 4 : sa_off;     // [k][n] image: + s * 8 k-rows
+    auto store_tiles_m = [&](int buf, auto masked_c, int kt, int n0) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+        float* a = As + buf * A_TILE + sa_off;
+        float* b = Bs + buf * B_TILE + sb_off;
         const int k0 = kt * BK;
 #pragma unroll
         for (int s = 0; s < NSA; ++s) {
-            const int idx = t + 256 * s;
-            const int r = idx / F4R, c4 = (idx % F4R) * 4;
+            const int c4 = ((t + 256 * s) % F4R) * 4;
             float4 v = ra[s];
-            if (p.a_stats) {                                          // uniform; 3 VALU per element: one FMA, v_exp_f32, one multiply
+            if constexpr (SM) {                                       // 3 VALU per element: one FMA, v_exp_f32, one multiply
                 constexpr float kL2e = 1.4426950408889634f;
                 v.x = __builtin_amdgcn_exp2f(__builtin_fmaf(v.x, kL2e, -ast[s].x)) * ast[s].y;
                 v.y = __builtin_amdgcn_exp2f(__builtin_fmaf(v.y, kL2e, -ast[s].x)) * ast[s].y;
                 v.z = __builtin_amdgcn_exp2f(__builtin_fmaf(v.z, kL2e, -ast[s].x)) * ast[s].y;
                 v.w = __builtin_amdgcn_exp2f(__builtin_fmaf(v.w, kL2e, -ast[s].x)) * ast[s].y;
             }
-            *reinterpret_cast<float4*>(a + r * LDS_A + c4) = mask4(v, k0 + c4, p.K);
+            if constexpr (MASKED) v = mask4(v, k0 + c4, p.K);
+            *reinterpret_cast<float4*>(a + s * (256 / F4R) * LDS_A) = v;
         }
         if (!B_KN) {
 #pragma unroll
             for (int s = 0; s < NSA; ++s) {
-                const int idx = t + 256 * s;
-                const int r = idx / F4R, c4 = (idx % F4R) * 4;
-                *reinterpret_cast<float4*>(b + r * LDS_A + c4) = mask4(rb[s], k0 + c4, p.K);
+                const int c4 = ((t + 256 * s) % F4R) * 4;
+                float4 v = rb[s];
+                if constexpr (MASKED) v = mask4(v, k0 + c4, p.K);
+                *reinterpret_cast<float4*>(b + s * (256 / F4R) * LDS_A) = v;
             }
         } else {
 #pragma unroll
             for (int s = 0; s < NSB; ++s) {
-                const int idx = t + 256 * s;
-                const int kr = idx >> 5, n4 = (idx & 31) * 4;
-                *reinterpret_cast<float4*>(b + kr * LDS_BKN + n4) = mask4(rb[s], n0 + n4, p.N);
+                const int n4 = ((t + 256 * s) & 31) * 4;
+                float4 v = rb[s];
+                if constexpr (MASKED) v = mask4(v, n0 + n4, p.N);
+                *reinterpret_cast<float4*>(b + s * 8 * LDS_BKN) = v;
             }
         }
+    };
+    auto store_tiles = [&](int buf, int kt, int n0) __attribute__((always_inline)) {
+        // ONE uniform branch around the whole store phase: only the last k-tile of a K (column tile of an N) that is not a multiple of 4 masks
+        if ((k_ragged4 && kt * BK + BK > p.K) || (n_ragged4 && n0 + BN > p.N)) store_tiles_m(buf, std::true_type{}, kt, n0);
+        else store_tiles_m(buf, std::false_type{}, kt, n0);
     };
 
     f32x16 acc[2][2];
@@ -339,10 +393,15 @@ static int gemm_launch(GemmP& p, bool b_kn, hipStream_t stream, const char* tag)
     CIAOSR_BIG_LDS((gemm_f32_kernel<false, false>), smem);
     CIAOSR_BIG_LDS((gemm_f32_kernel<true, true>), smem);
     CIAOSR_BIG_LDS((gemm_f32_kernel<false, true>), smem);
+    CIAOSR_BIG_LDS((gemm_f32_kernel<true, false, true>), smem);
+    CIAOSR_BIG_LDS((gemm_f32_kernel<false, false, true>), smem);
     {
         ProfScope prof(tag ? tag : (b_kn ? "gemm_f32_nn" : "gemm_f32_nt"), stream);
         const dim3 grid(p.n_wg, p.splitk);
-        if (p.tn_per_wg > 1) {
+        if (p.a_stats) {                                         // gemm_f32_softmax_a: one column tile per workgroup
+            if (b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, false, true>), grid, dim3(256), smem, stream, p);
+            else hipLaunchKernelGGL((gemm_f32_kernel<false, false, true>), grid, dim3(256), smem, stream, p);
+        } else if (p.tn_per_wg > 1) {
             if (b_kn) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), smem, stream, p);
             else hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), smem, stream, p);
         } else {

@@ -69,9 +69,9 @@ __global__ __launch_bounds__(1024) void bench(float* out, unsigned long long* cy
 }
 
 template <int K, int L, int MODE = 0, int H16 = 0>
-static void run(int waves_per_simd) {
+static void run(int waves_per_simd, int rounds = 2000) {
     float* out; unsigned long long* cyc;
-    const int rounds = 2000, grid = 256, block = 256 * waves_per_simd;
+    const int grid = 256, block = 256 * waves_per_simd;
     hipMalloc(&out, sizeof(float) * grid * block);
     hipMalloc(&cyc, sizeof(unsigned long long) * grid);
     hipEvent_t e0, e1;
@@ -96,7 +96,11 @@ static void run(int waves_per_simd) {
     hipFree(out); hipFree(cyc);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) {      // sustained-load check: pure MFMA streams of growing length (does the clock hold?)
+        for (int r : {2000, 20000, 100000, 400000}) { run<0, 0>(4, r); run<0, 0, 0, 1>(4, r); }
+        return 0;
+    }
     for (int w = 1; w <= 4; w *= 2) {
         run<0, 0>(w); run<1, 0>(w); run<2, 0>(w); run<3, 0>(w); run<4, 0>(w); run<6, 0>(w); run<8, 0>(w);
         run<2, 0, 1>(w); run<4, 0, 1>(w); run<2, 0, 3>(w); run<4, 0, 3>(w); run<4, 0, 2>(w); run<8, 0, 2>(w);
