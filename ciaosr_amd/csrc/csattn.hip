@@ -14,8 +14,6 @@
 //
 // The score matrix is materialised in HBM (1.36 GB at the 192x192 tile: < 1 % of 288 GB and two
 // passes at HBM speed, against 1.76 TFLOP of MFMA work).
-#include <cstdlib>
-
 #include "ops.h"
 
 namespace ciaosr {
@@ -179,8 +177,7 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
     else
         RUN(gemm_f32(Qp, 9 * p.Ch, Kn, 9 * p.Ch, false, S, p.Lld, nullptr, HWp, p.L, 9 * p.Ch, w->softmax_scale,
                      CIAOSR_ACT_NONE, 0.f, s, "csa_scores"));
-    static const bool sm_inplace = [] { const char* e = getenv("CIAOSR_CSA_SOFTMAX_INPLACE"); return e && atoi(e) != 0; }();
-    if (composed && (size_t)HWp * 2 <= p.n_Qp && !sm_inplace) {
+    if (composed && (size_t)HWp * 2 <= p.n_Qp) {
         // composed fold + down with the row softmax applied in the attn.V operand staging (statistics-only pass over S: the in-place
         // rewrite of the 1.36-GB logit matrix is gone; probabilities = exp2(x log2 e - max log2 e) / sum, equal to softmax_rows' to rounding)
         const int Hh = p.Hp / 2, Wh = p.Wp / 2;

@@ -1,2 +1,2 @@
-timeout 900 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "gemm or csattn or head or full_c3_tile or e2e_restorer or swinir" 2>&1 | tail -n 3
-python bench.py --no-extras --no-cpu-baseline --no-live-pmc 2>&1 | tail -n 1 | cut -c1-330
+python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-400
+CIAOSR_CSA_SOFTMAX_INPLACE=1 python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-400
