@@ -82,15 +82,26 @@ __global__ __launch_bounds__(512, 2) void conv1x1_resident_f32_kernel(Res1x1P p)
     auto epilogue = [&](int tile) {
         const long row = (long)tile * 32 + li;
         if (row >= p.M) return;
+        // every load first (bias, residual: 16 float4 in flight), then the arithmetic and the stores: written load -> store per column
+        // group, the possible aliasing of dst with res / bias makes hipcc keep that order and the eight round trips run one after the other
+        float4 bq[2][4], rq[2][4];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = 32 * nt + 8 * g + 4 * lh;
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+                bq[nt][g] = *reinterpret_cast<const float4*>(p.bias + n);
+                rq[nt][g] = p.res ? *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * nt + 8 * g + 4 * lh;
+                const float4 b = bq[nt][g];
                 float4 v = make_float4(acc[nt][4 * g] + b.x, acc[nt][4 * g + 1] + b.y, acc[nt][4 * g + 2] + b.z, acc[nt][4 * g + 3] + b.w);
                 if (p.res) {
-                    const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldres + n);
+                    const float4 r = rq[nt][g];
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 *reinterpret_cast<float4*>(p.dst + (size_t)row * p.ld_dst + n) = v;

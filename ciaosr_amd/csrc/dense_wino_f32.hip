@@ -278,6 +278,10 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
     __syncthreads();
     WPROBE(29);
     float* const xi = TABLE ? p.x + (size_t)img * p.out_y_stride : p.x + (size_t)img * p.H * p.W * p.ldx;
+    // this thread's four output units share their channel quad: ONE bias load in front of the loop (inside it, behind the bounds
+    // test and next to the stores it may alias, hipcc keeps load -> store order and the L2 round trip is paid per unit)
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (!TABLE) bias4 = *reinterpret_cast<const float4*>(p.bias + 32 * ((t >> 8) & 1) + 8 * ((t >> 6) & 3) + 4 * ((t & 63) >> 5));
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const int unit = t + 512 * u;                  // (y, x, nt, q, lane): 2 x 2 x 2 x 4 x 64
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void dense_wino_f32_kernel(DenseWinoP p) {
         if (y < p.H && x < p.W) {
             const int co = 32 * nt + 8 * q + 4 * (ul >> 5);
             if constexpr (!TABLE) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+                const float4 b = bias4;                 // co is the same for every unit of a thread (512 u only moves the pixel)
                 o.x = fmaxf(o.x + b.x, 0.f); o.y = fmaxf(o.y + b.y, 0.f);
                 o.z = fmaxf(o.z + b.z, 0.f); o.w = fmaxf(o.w + b.w, 0.f);
             }

@@ -1,2 +1,2 @@
-python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-400
-CIAOSR_CSA_SOFTMAX_INPLACE=1 python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-400
+python tools/enc_lab.py fp32 8 2>&1 | tail -n 1
+timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "rdn_trunk or encoder_features or tile_batch" 2>&1 | tail -n 3
