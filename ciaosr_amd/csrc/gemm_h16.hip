@@ -474,15 +474,27 @@ __global__ __launch_bounds__(256, 2) void conv1x1_skinny_h16_kernel(Skinny16P p)
         }
     }
     if (row >= p.M) return;
+    // every epilogue load first (bias, residual: 16 float4 in flight): written load -> store per column group, the stores' possible
+    // aliasing with res / bias keeps hipcc from hoisting the next group's loads and the wave pays eight L2 / HBM round trips in a row --
+    // three times its 72 MFMAs
+    float4 bq[2][4], rq[2][4];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = 32 * nt + 8 * q + 4 * lh;
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+            bq[nt][q] = *reinterpret_cast<const float4*>(p.bias + n);
+            rq[nt][q] = p.res ? *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldres + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = 32 * nt + 8 * q + 4 * lh;
+            const float4 b = bq[nt][q];
             float v0 = acc[nt][4 * q] + b.x, v1 = acc[nt][4 * q + 1] + b.y, v2 = acc[nt][4 * q + 2] + b.z, v3 = acc[nt][4 * q + 3] + b.w;
             if (p.res) {
-                const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)row * p.ldres + n);
+                const float4 r = rq[nt][q];
                 v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
             }
             *reinterpret_cast<float4*>(p.out + (size_t)row * p.ldo + n) = make_float4(v0, v1, v2, v3);

@@ -1,2 +1,3 @@
-python tools/enc_lab.py fp32 8 2>&1 | tail -n 1
-timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "rdn_trunk or encoder_features or tile_batch" 2>&1 | tail -n 3
+python tools/enc_lab.py f16 8 2>&1 | tail -n 1
+python tools/enc_lab.py bf16 8 2>&1 | tail -n 1
+timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "rdn_trunk or tile_batch or full_c3_tile" 2>&1 | tail -n 3
