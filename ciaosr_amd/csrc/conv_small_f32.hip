@@ -133,6 +133,25 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
     const __amdgpu_buffer_rsrc_t rs_d2 = __builtin_amdgcn_make_buffer_rsrc(p.dst2 ? p.dst2 : p.dst, 0, p.dst2 ? p.dst2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.src), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    // bias and residual of every unit first (in flight together): inside the unit loop, behind the stores they may alias, each is its
+    // own round trip
+    float4 bq[MT], rq[MT];
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        const int unit = t + 256 * u;
+        const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
+        const int idx = 32 * r + (ul & 31);
+        const int y = ty0 + (idx >> 3), x = tx0 + (idx & 7);
+        const int co = 32 * nt + 8 * q + 4 * (ul >> 5);
+        const bool ok = y < p.H && x < p.W && co < p.Cout;
+        const unsigned pix = (unsigned)(y * p.W + x);
+        bq[u] = (p.bias && ok) ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.res) {
+            const i32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? (int)((pix * (unsigned)p.ld_res + (unsigned)co) * 4u) : (int)kOobC, 0, 0);
+            rq[u] = make_float4(__int_as_float(rr.x), __int_as_float(rr.y), __int_as_float(rr.z), __int_as_float(rr.w));
+        }
+    }
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
         const int unit = t + 256 * u;
@@ -148,16 +167,13 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvSmallP p) {
         const int co = 32 * nt + 8 * q + 4 * (ul >> 5);
         const bool ok = y < p.H && x < p.W && co < p.Cout;            // Cout % 4 == 0
         const unsigned pix = (unsigned)(y * p.W + x);
-        if (p.bias && ok) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + co);
+        {
+            const float4 b = bq[u];
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
         v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
         if (p.act == CIAOSR_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (p.res) {
-            const i32x4 rr = __builtin_amdgcn_raw_buffer_load_b128(rs_r, ok ? (int)((pix * (unsigned)p.ld_res + (unsigned)co) * 4u) : (int)kOobC, 0, 0);
-            v.x += __int_as_float(rr.x); v.y += __int_as_float(rr.y); v.z += __int_as_float(rr.z); v.w += __int_as_float(rr.w);
-        }
+        if (p.res) { v.x += rq[u].x; v.y += rq[u].y; v.z += rq[u].z; v.w += rq[u].w; }
         i32x4 iv;
         iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
         __builtin_amdgcn_raw_buffer_store_b128(iv, rs_d, ok ? (int)((pix * (unsigned)p.ld_dst + (unsigned)co) * 4u) : (int)kOobC, 0, 0);

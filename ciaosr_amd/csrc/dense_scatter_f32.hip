@@ -167,15 +167,15 @@ __global__ __launch_bounds__(256) void dense_scatter_small_kernel(ScatterP p) {
             v[u].x += o.x; v[u].y += o.y; v[u].z += o.z; v[u].w += o.w;
         }
     }
+    // the units of a thread share their channel quad: one bias load in front of the stores it may alias
+    const float4 bias4 = layer == p.step ? *reinterpret_cast<const float4*>(p.bias + 64 * layer + 32 * half + 8 * ((t >> 6) & 3) + 4 * ((t & 63) >> 5))
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
-        const int unit = t + 256 * u;
-        const int ul = unit & 63, q = (unit >> 6) & 3;
-        const int col = 32 * half + 8 * q + 4 * (ul >> 5);
         float4 o = make_float4(v[u].x + prev[u].x, v[u].y + prev[u].y, v[u].z + prev[u].z, v[u].w + prev[u].w);
         i32x4 iv;
         if (layer == p.step) {                             // this layer is complete: bias, ReLU -> input group s + 1
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + 64 * layer + col);
+            const float4 b = bias4;
             o.x = fmaxf(o.x + b.x, 0.f); o.y = fmaxf(o.y + b.y, 0.f); o.z = fmaxf(o.z + b.z, 0.f); o.w = fmaxf(o.w + b.w, 0.f);
             iv.x = __float_as_int(o.x); iv.y = __float_as_int(o.y); iv.z = __float_as_int(o.z); iv.w = __float_as_int(o.w);
             __builtin_amdgcn_raw_buffer_store_b128(iv, rs, (int)xoff[u], 0, 0);

@@ -120,6 +120,18 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
     const __amdgpu_buffer_rsrc_t rs_c2 = __builtin_amdgcn_make_buffer_rsrc(p.C2 ? p.C2 : p.C, 0, p.C2 ? p.c2_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.res ? p.res : p.A), 0, p.res ? p.res_bytes : 0u, 0x00020000);
+    // bias and residual of every unit first (in flight together, under the LDS reduction): inside the unit loop, behind the stores
+    // they may alias, each would be its own round trip -- a tenth of a ~9-us launch
+    float4 bq[MT], rq[MT];
+#pragma unroll
+    for (int u = 0; u < MT; ++u) {
+        const int unit = t + 256 * u;
+        const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
+        const int m = m0 + 32 * r + (ul & 31), n = n0 + 8 * q + 4 * (ul >> 5);
+        const bool ok = m < p.M && n < p.N;
+        bq[u] = (p.bias && ok) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        rq[u] = p.res ? gs_load4(rs_r, ok ? ((unsigned)m * (unsigned)p.ldres + (unsigned)n) * 4u : kOobGS) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int u = 0; u < MT; ++u) {
         const int unit = t + 256 * u;
@@ -132,8 +144,8 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
         }
         const int m = m0 + 32 * r + (ul & 31), n = n0 + 8 * q + 4 * (ul >> 5);
         const bool ok = m < p.M && n < p.N;                       // N % 4 == 0
-        if (p.bias && ok) {
-            const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+        {
+            const float4 b = bq[u];
             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
         v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) void gemm_small_f32_kernel(GemmSmallP p) {
             v.w = 0.5f * v.w * (1.f + erff(v.w * 0.70710678118654752f));
         }
         if (p.res) {
-            const float4 rr = gs_load4(rs_r, ok ? ((unsigned)m * (unsigned)p.ldres + (unsigned)n) * 4u : kOobGS);
+            const float4 rr = rq[u];
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         gs_store4(rs_c, ok ? ((unsigned)m * (unsigned)p.ldc + (unsigned)n) * 4u : kOobGS, v);
