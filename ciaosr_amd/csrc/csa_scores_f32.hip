@@ -30,7 +30,7 @@ struct BoxP {
     const float* M; int ldm; unsigned m_bytes; int Hp, Wp;      // query map [Hp*Wp][ldm], 32 channels
     const float* R; int ldr; unsigned r_bytes; int Hl, Wl;      // key map [Hl*Wl][ldr]
     const float* nrm;                                            // [Hl*Wl] alpha / max(patch norm, floor)
-    float* S; int lds_;                                          // [Hp*Wp][lds_]
+    float* S; int lds_; unsigned s_bytes;                        // [Hp*Wp][lds_]
     int pbx, lbx, n_lb, n_items;                                 // blocks per row of each map, key blocks in total, (query, key) block pairs
 };
 
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
 #pragma unroll
             for (int b = 0; b < 3; ++b) lcol9[3 * a + b] = (lyy + a) * BHW + lxx + b;     // halo index of l + (a - 1, b - 1)
         const int q0 = 32 * (wv - 4);
+        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(p.S, 0, p.s_bytes, 0x00020000);
 #pragma unroll 1
         for (int it = i0; it <= i1; ++it) {                          // iteration `it` consumes item `it - 1`
             if (it > i0) {
@@ -162,19 +163,24 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
                 // the query pixel of output q is wave-uniform and q is a compile-time index: every LDS address is a per-lane base
                 // (this lane's nine halo columns, on this wave's first halo row) + an immediate
                 const float* D = Dl + k * (BDB / 4) + (q0 >> 4) * BHW * BDP;
-                float* srow = p.S + ((size_t)(py0 + (q0 >> 4)) * p.Wp + px0) * p.lds_ + (size_t)ly * p.Wl + lx;
+                // stores through a buffer descriptor: lane validity (key pixel inside the map) and the wave-uniform row validity fold into
+                // the per-lane offset (out of range = dropped), the output row into the SCALAR offset -- no branch per output, so the
+                // 288 LDS reads of the item's 32 outputs can be batched ahead of their sums (behind a branch each, every output waited
+                // for its own nine reads)
+                const unsigned lane_off = l_ok ? (unsigned)((size_t)ly * p.Wl + lx) * 4u : kOobB;
+                const int qy0 = py0 + (q0 >> 4);
                 const float* dk[9];
 #pragma unroll
                 for (int e = 0; e < 9; ++e) dk[e] = D + lcol9[e];
 #pragma unroll
                 for (int q = 0; q < 32; ++q) {
                     const int pyy = q >> 4, pxx = q & 15;                    // relative to this wave's two query rows
-                    float s = 0.f;
+                    float s = dk[0][(pyy * BHW + pxx) * BDP];
 #pragma unroll
-                    for (int a = 0; a < 3; ++a)
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) s += dk[3 * a + b][((pyy + a) * BHW + pxx + b) * BDP];
-                    if (l_ok && py0 + (q0 >> 4) + pyy < p.Hp && px0 + pxx < p.Wp) srow[((size_t)pyy * p.Wp + pxx) * p.lds_] = s * sc;
+                    for (int e = 1; e < 9; ++e) s += dk[e][((pyy + e / 3) * BHW + pxx + e % 3) * BDP];     // same order as before: (a, b) row-major
+                    const bool row_ok = qy0 + pyy < p.Hp && px0 + pxx < p.Wp;           // wave-uniform
+                    const unsigned soff = (unsigned)(((size_t)(qy0 + pyy) * p.Wp + px0 + pxx) * p.lds_ * 4);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(s * sc), rs_s, (int)(row_ok ? lane_off : kOobB), (int)(row_ok ? soff : 0u), 0);
                 }
             }
             __syncthreads();
@@ -189,7 +195,8 @@ int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, 
                        float* nrm, float* S, int ld_s, hipStream_t s) {
     CIAOSR_CHECK_ARG(M && R && nrm && S && csa_scores_box_ok(Ch, ldm, ldr) && aligned16(M) && aligned16(R));
     const size_t mb = (size_t)Hp * Wp * ldm * 4, rb = (size_t)Hl * Wl * ldr * 4;
-    CIAOSR_CHECK_ARG(mb < 0xFFFFFF00ull && rb < 0xFFFFFF00ull);
+    const size_t sb = ((size_t)Hp * Wp - 1) * ld_s * 4 + (size_t)Hl * Wl * 4;
+    CIAOSR_CHECK_ARG(mb < 0xFFFFFF00ull && rb < 0xFFFFFF00ull && sb < 0xFFFFFF00ull);
     {
         ProfScope prof("csa_key_norms", s);
         hipLaunchKernelGGL(csa_key_norms_kernel, dim3(ceil_div((long)Hl * Wl, 4)), dim3(256), 0, s, R, ldr, Hl, Wl, Ch, floor_, alpha, nrm);
@@ -199,7 +206,7 @@ int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, 
     BoxP p;
     p.M = M; p.ldm = ldm; p.m_bytes = (unsigned)mb; p.Hp = Hp; p.Wp = Wp;
     p.R = R; p.ldr = ldr; p.r_bytes = (unsigned)rb; p.Hl = Hl; p.Wl = Wl;
-    p.nrm = nrm; p.S = S; p.lds_ = ld_s;
+    p.nrm = nrm; p.S = S; p.lds_ = ld_s; p.s_bytes = (unsigned)sb;
     p.pbx = ceil_div(Wp, BSW); p.lbx = ceil_div(Wl, BLW);
     p.n_lb = ceil_div(Hl, BLH) * p.lbx;
     const long n_items = (long)ceil_div(Hp, BSH) * p.pbx * p.n_lb;

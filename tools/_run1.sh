@@ -1,4 +1,2 @@
-python tools/enc_lab.py f16 8 2>&1 | tail -n 1
-python tools/enc_lab.py bf16 8 2>&1 | tail -n 1
-python tools/enc_lab.py f16 1 2>&1 | tail -n 1
-timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "rdn_trunk or tile_batch or full_c3_tile" 2>&1 | tail -n 3
+python tools/kernel_lab.py --quick fp32=fp32 2>&1 | tail -n 1 | cut -c1-260
+timeout 600 python -m pytest tests/test_hip_parity.py -x -q -m gpu -k "csattn or full_c3_tile or e2e_restorer" 2>&1 | tail -n 3
