@@ -30,7 +30,7 @@ struct BoxP {
     const float* M; int ldm; unsigned m_bytes; int Hp, Wp;      // query map [Hp*Wp][ldm], 32 channels
     const float* R; int ldr; unsigned r_bytes; int Hl, Wl;      // key map [Hl*Wl][ldr]
     const float* nrm;                                            // [Hl*Wl] alpha / max(patch norm, floor)
-    float* S; int lds_; unsigned s_bytes;                        // [Hp*Wp][lds_]
+    float* S; int lds_; size_t s_floats;                         // [Hp*Wp][lds_]; s_floats: extent
     int pbx, lbx, n_lb, n_items;                                 // blocks per row of each map, key blocks in total, (query, key) block pairs
 };
 
@@ -150,7 +150,6 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
 #pragma unroll
             for (int b = 0; b < 3; ++b) lcol9[3 * a + b] = (lyy + a) * BHW + lxx + b;     // halo index of l + (a - 1, b - 1)
         const int q0 = 32 * (wv - 4);
-        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(p.S, 0, p.s_bytes, 0x00020000);
 #pragma unroll 1
         for (int it = i0; it <= i1; ++it) {                          // iteration `it` consumes item `it - 1`
             if (it > i0) {
@@ -169,6 +168,12 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
                 // for its own nine reads)
                 const unsigned lane_off = l_ok ? (unsigned)((size_t)ly * p.Wl + lx) * 4u : kOobB;
                 const int qy0 = py0 + (q0 >> 4);
+                // (the descriptor is based at this wave's first output row: S as a whole may exceed the 4 GiB a descriptor spans)
+                const size_t s_base = ((size_t)qy0 * p.Wp + px0) * p.lds_;                      // floats, wave-uniform
+                const size_t s_left = p.s_floats > s_base ? (p.s_floats - s_base) * 4 : 0;      // bytes up to the end of S
+                const size_t s_span = ((size_t)p.Wp + BSW) * p.lds_ * 4;                        // two output rows of this block
+                const __amdgpu_buffer_rsrc_t rs_s =
+                    __builtin_amdgcn_make_buffer_rsrc(p.S + s_base, 0, (unsigned)(s_left < s_span ? s_left : s_span), 0x00020000);
                 const float* dk[9];
 #pragma unroll
                 for (int e = 0; e < 9; ++e) dk[e] = D + lcol9[e];
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(512) void csa_scores_box_f32_kernel(BoxP p) {
 #pragma unroll
                     for (int e = 1; e < 9; ++e) s += dk[e][((pyy + e / 3) * BHW + pxx + e % 3) * BDP];     // same order as before: (a, b) row-major
                     const bool row_ok = qy0 + pyy < p.Hp && px0 + pxx < p.Wp;           // wave-uniform
-                    const unsigned soff = (unsigned)(((size_t)(qy0 + pyy) * p.Wp + px0 + pxx) * p.lds_ * 4);
+                    const unsigned soff = (unsigned)(((size_t)pyy * p.Wp + pxx) * p.lds_ * 4);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(s * sc), rs_s, (int)(row_ok ? lane_off : kOobB), (int)(row_ok ? soff : 0u), 0);
                 }
             }
@@ -195,8 +200,8 @@ int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, 
                        float* nrm, float* S, int ld_s, hipStream_t s) {
     CIAOSR_CHECK_ARG(M && R && nrm && S && csa_scores_box_ok(Ch, ldm, ldr) && aligned16(M) && aligned16(R));
     const size_t mb = (size_t)Hp * Wp * ldm * 4, rb = (size_t)Hl * Wl * ldr * 4;
-    const size_t sb = ((size_t)Hp * Wp - 1) * ld_s * 4 + (size_t)Hl * Wl * 4;
-    CIAOSR_CHECK_ARG(mb < 0xFFFFFF00ull && rb < 0xFFFFFF00ull && sb < 0xFFFFFF00ull);
+    const size_t s_floats = ((size_t)Hp * Wp - 1) * ld_s + (size_t)Hl * Wl;
+    CIAOSR_CHECK_ARG(mb < 0xFFFFFF00ull && rb < 0xFFFFFF00ull && ((size_t)Wp + BSW) * ld_s * 4 < 0xFFFFFF00ull);
     {
         ProfScope prof("csa_key_norms", s);
         hipLaunchKernelGGL(csa_key_norms_kernel, dim3(ceil_div((long)Hl * Wl, 4)), dim3(256), 0, s, R, ldr, Hl, Wl, Ch, floor_, alpha, nrm);
@@ -206,7 +211,7 @@ int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, 
     BoxP p;
     p.M = M; p.ldm = ldm; p.m_bytes = (unsigned)mb; p.Hp = Hp; p.Wp = Wp;
     p.R = R; p.ldr = ldr; p.r_bytes = (unsigned)rb; p.Hl = Hl; p.Wl = Wl;
-    p.nrm = nrm; p.S = S; p.lds_ = ld_s; p.s_bytes = (unsigned)sb;
+    p.nrm = nrm; p.S = S; p.lds_ = ld_s; p.s_floats = s_floats;
     p.pbx = ceil_div(Wp, BSW); p.lbx = ceil_div(Wl, BLW);
     p.n_lb = ceil_div(Hl, BLH) * p.lbx;
     const long n_items = (long)ceil_div(Hp, BSH) * p.pbx * p.n_lb;

@@ -422,6 +422,29 @@ def test_logit_table_winograd_route_matches_gemm_route(dev, hw):
     assert d < 2e-5 * max(1.0, gemm.abs().max().item()), d
 
 
+def test_logit_table_winograd_route_at_its_largest_map(dev):
+    """The Winograd logit-table route at the largest map it takes (256 x 256 LR pixels = the 65536-row chunk its product maps live in;
+    one column more falls back to the GEMM route), x2 queries, against the GEMM route.  Head without the non-local branch (its fp32
+    logit matrix would be 4.3 GB at this size, past the 4-GiB descriptors of the attn.V contraction: that path raises)."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd._lib import HEAD_TABLE_GEMM
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 6, head_gain=1.5, non_local=False), dev, eval_bsize=30000, non_local_attn=False)
+    for h, w, expect_wino in ((256, 256, True), (256, 257, False)):
+        feat = randn((1, 64, h, w), 31).to(dev)
+        ht, wt = 2 * h, 2 * w
+        coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+        with hip_ops.profile():
+            a = g._predict([feat], coord, cell, 30000, None).cpu()
+        assert ('head_qk_maps' in hip_ops.profile.results()) == expect_wino, (h, w, sorted(hip_ops.profile.results()))
+        b = g._predict([feat], coord, cell, 30000, None, hip_ops.Options(head_route=HEAD_TABLE_GEMM)).cpu()
+        d = (a - b).abs().max().item()
+        print(f'{h}x{w}: default vs GEMM-table route max |delta| {d:.2e}')
+        assert d < 2e-5 * max(1.0, b.abs().max().item()), d
+        del feat, coord, cell, a, b
+        torch.cuda.empty_cache()
+
+
 def test_as_written_staged_route_vs_golden_and_fused(dev):
     """Third evaluation route: the reference's op order through the staged C entry points with no algebraic
     restructuring (ciaosr_gather_rows_f32 -> ciaosr_mlp_forward_f32 x2 -> ciaosr_local_attention_f32 ->
