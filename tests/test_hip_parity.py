@@ -236,6 +236,28 @@ def test_csattn_composed_tail_forced_on_small_goldens(dev, tag):
     assert (y[0] - want).abs().max().item() < TOL
 
 
+def test_csattn_logit_matrix_past_4gib_runs_as_row_blocks(dev):
+    """256 x 256 LR pixels: the fp32 logit matrix [65536][16384] is 4.3 GB, more than one buffer descriptor spans.  The contractions over
+    it run as row blocks (gemm_f32 / gemm_f32_softmax_a split M; the scores consumers base their descriptor at their own output rows).
+    No reference vector at this size (the CPU path needs minutes): the composed tail (softmax in the attn.V staging, V' with 16C columns,
+    edge variants) against the uncomposed one (in-place softmax, 36C-column V patches, fold, down convolution) -- two routes that share
+    only the scores."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_state_dict
+    P = seeded_state_dict(csattn_shapes(64, prefix=''), 11, 1.0)
+    att = _my_csattn(64, P, dev, prefix='')
+    x = randn((1, 64, 256, 256), 12).to(dev)
+    with hip_ops.profile():
+        y = att(x).cpu()
+    assert 'csa_attn_v_edge' in hip_ops.profile.results()
+    z = att(x, options=hip_ops.Options(csa_composed_min=-1)).cpu()
+    d = (y - z).abs().max().item()
+    print(f'256x256 cs_attn: composed vs uncomposed tail max |delta| {d:.2e} (scale {z.abs().max().item():.2f})')
+    assert d < 2e-5 * max(1.0, z.abs().max().item()), d
+    del x, y, z
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'f16'])
 @pytest.mark.parametrize('tag', ['64x64', '67x70'])
 def test_csattn_bf16_mode_vs_reference(dev, tag, precision):
