@@ -357,9 +357,10 @@ int gemm_f32(const float* A, int lda, const float* B, int ldb, bool b_kn, float*
     CIAOSR_CHECK_ARG(K > 0 && A && B && C);
     CIAOSR_CHECK_ARG((lda & 3) == 0 && (ldb & 3) == 0);
     CIAOSR_CHECK_ARG(aligned16(A) && aligned16(B));
-    if (((size_t)(M - 1) * lda + K) * sizeof(float) >= 0xFFFFFF00ull && M > BM) {
-        // A spans more than one buffer descriptor (4 GiB): rows are independent, so run row blocks (multiples of the row tile)
-        const int half = (M / 2 + BM - 1) / BM * BM;
+    if (((size_t)(M - 1) * lda + K) * sizeof(float) >= 0xFFFFFF00ull && M > 1) {
+        // A spans more than one buffer descriptor (4 GiB): rows are independent, so run row blocks (multiples of the row tile while
+        // there are that many rows; a strided row set -- one row per image line -- may have to go down to single rows)
+        const int half = M > BM ? (M / 2 + BM - 1) / BM * BM : (M + 1) / 2;
         const int rc = gemm_f32(A, lda, B, ldb, b_kn, C, ldc, bias, half, N, K, alpha, act, slope, stream, tag);
         if (rc != CIAOSR_OK) return rc;
         return gemm_f32(A + (size_t)half * lda, lda, B, ldb, b_kn, C + (size_t)half * ldc, ldc, bias, M - half, N, K, alpha, act, slope, stream, tag);
@@ -459,8 +460,8 @@ int gemm_f32_softmax_a(const float* A, int lda, const float* a_stats2, int a_sta
     if (M <= 0 || N <= 0) return CIAOSR_OK;
     CIAOSR_CHECK_ARG(K > 0 && A && B && C && a_stats2 && a_stats_stride >= 1);
     CIAOSR_CHECK_ARG((lda & 3) == 0 && (ldb & 3) == 0 && aligned16(A) && aligned16(B) && (reinterpret_cast<uintptr_t>(a_stats2) & 7u) == 0);
-    if (((size_t)(M - 1) * lda + K) * sizeof(float) >= 0xFFFFFF00ull && M > BM) {      // A past one descriptor: row blocks (see gemm_f32)
-        const int half = (M / 2 + BM - 1) / BM * BM;
+    if (((size_t)(M - 1) * lda + K) * sizeof(float) >= 0xFFFFFF00ull && M > 1) {       // A past one descriptor: row blocks (see gemm_f32)
+        const int half = M > BM ? (M / 2 + BM - 1) / BM * BM : (M + 1) / 2;
         const int rc = gemm_f32_softmax_a(A, lda, a_stats2, a_stats_stride, B, ldb, b_kn, C, ldc, half, N, K, partial, partial_floats, stream, tag);
         if (rc != CIAOSR_OK) return rc;
         return gemm_f32_softmax_a(A + (size_t)half * lda, lda, a_stats2 + (size_t)half * a_stats_stride * 2, a_stats_stride, B, ldb, b_kn,

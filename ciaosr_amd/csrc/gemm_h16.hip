@@ -386,6 +386,13 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     if (M <= 0 || N <= 0) return CIAOSR_OK;
     CIAOSR_CHECK_ARG(A && B && C && K > 0 && (K & 7) == 0);
     CIAOSR_CHECK_ARG((lda & 7) == 0 && (ldb & 7) == 0 && (ldc & 3) == 0 && aligned16(A) && aligned16(B) && aligned16(C));
+    if (((size_t)(M - 1) * lda + K) * 2 >= 0xFFFFFF00ull && M > GM) {       // A past one buffer descriptor (4 GiB): independent row blocks
+        const int half = (M / 2 + GM - 1) / GM * GM;
+        const size_t c_row = (size_t)ldc * (c_bf16 ? 2 : 4);
+        const int rc = gemm_h16_nt(A, lda, B, ldb, C, ldc, c_bf16, half, N, K, alpha, s, tag);
+        if (rc != CIAOSR_OK) return rc;
+        return gemm_h16_nt(A + (size_t)half * lda, lda, B, ldb, static_cast<char*>(C) + (size_t)half * c_row, ldc, c_bf16, M - half, N, K, alpha, s, tag);
+    }
     Gemm16P p;
     p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.C = C; p.ldc = ldc; p.c_bf16 = c_bf16 ? 1 : 0;
     p.M = M; p.N = N; p.K = K; p.alpha = alpha;

@@ -1276,6 +1276,27 @@ def test_linearity_of_the_decode_residual_at_full_tile_size(dev):
     assert (ys - yf).abs().max() < 5e-5 * max(1.0, yf.abs().max().item())
 
 
+def test_whole_image_path_with_operands_past_4gib(dev):
+    """Untiled RDN x4 on a 300 x 300 LR image (the configs' scale > 4 rule disables tiling, configs/001_...rdn...py:47-50): the cs_attn
+    logit matrix is 8.1 GB in fp32 and 4.1 GB of half probabilities -- operands past one 4-GiB buffer descriptor, walked as row blocks.
+    No reference vector at this size: the f16 mode against the fp32 path (PSNR > 50 dB, the distance the reference-pinned 192 x 192
+    tile shows), every value finite."""
+    import math
+    from ciaosr_amd.coords import make_coord, make_cell
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    model = _restorer('rdn', 4, dev, dict(scale=4))
+    seeded_init_(model, seed=3, gain=1.0, head_gain=SQRT6)
+    model = model.to(dev)
+    lq = synthetic_pair(300, 300, 4)[0].to(dev)
+    coord, cell = make_coord((1200, 1200)).unsqueeze(0).to(dev), make_cell((1200, 1200)).unsqueeze(0).to(dev)
+    a = model.restore(lq, coord, cell, options='fp32').cpu()
+    b = model.restore(lq, coord, cell, options='f16').cpu()
+    assert a.shape == (1, 3, 1200, 1200) and torch.isfinite(a).all() and torch.isfinite(b).all()
+    psnr = -10 * math.log10(max((a - b).double().pow(2).mean().item(), 1e-20))
+    print(f'300x300 whole image: PSNR(f16, fp32) {psnr:.1f} dB, means {a.mean().item():.6f} / {b.mean().item():.6f}')
+    assert psnr > 50.0, psnr
+
+
 def test_tiny_image_whole_path(dev):
     """Smallest sensible LR image (4x6, odd sizes inside cs_attn after halving) at a big scale (x12)."""
     from ciaosr_amd.coords import make_coord, make_cell
