@@ -48,6 +48,8 @@ def self_launch(argv):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault('NCCL_MIN_P2P_NCHANNELS', '1')              # tile_shard.rccl_env_defaults (torch not imported yet here)
+    env.setdefault('NCCL_MAX_P2P_NCHANNELS', '1')
     env.setdefault('OMP_NUM_THREADS', '4')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
@@ -77,9 +79,11 @@ def rdn_ciaosr(test_cfg):
 
 
 def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
-    """Algorithmic work of ALL launches of kernel `tag` in one step of this workload (one 48x48 tile):
-    (amount, 'flop'|'byte').  FLOPs = 2 x MACs of the contraction as the reference writes it, minus the
-    exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query."""
+    """Algorithmic work of ALL launches of kernel `tag` on ONE tile of Q queries / HW LR pixels (the caller multiplies by the
+    tiles of a step): (amount, 'flop'|'flop16'|'byte').  FLOPs = 2 x MACs of the contraction as the reference writes it, minus
+    the exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query.  Kernels that reach the
+    same result with fewer multiplies (Winograd, box sum) are priced on the reference's form here; `executed_ratio` gives the
+    flops their MFMAs actually execute, so that a fraction above 1 never stands alone."""
     if tag.endswith('_f16'):               # IEEE-half kernels: the bf16 kernels' work and peak (same MFMA rate)
         tag = tag[:-4] + '_bf16'
     D, Dv, R = 9 * C, 10 * C, Q * J
@@ -126,6 +130,50 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),
     }
     return table.get(tag)
+
+
+def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
+    """MFMA flops a kernel EXECUTES / its algorithmic flops (`kernel_work`).  1 unless the kernel restructures the contraction:
+    Winograd F(2x2, 3x3) issues 16 multiplies per 2x2 output tile and channel pair instead of 36 (dense layers, logit table:
+    dense_wino_f32.hip); the fp32 correlation scores are a 3x3 diagonal box sum of a K = C/2 per-pixel correlation whose D blocks
+    of (8+2)x(16+2) query-halo x (4+2)x(16+2) key-halo pixels are computed as 6 x 4 MFMA tiles of 32x32 per 8x16 x 4x16 item
+    (csa_scores_f32.hip); hi + lo weight pairs issue two MFMAs per product (bf16 pairs, f16-pairs), activation pairs three."""
+    base = tag[:-5] if tag.endswith('_bf16') else (tag[:-4] if tag.endswith('_f16') else tag)
+    half = base != tag
+    if not half:
+        if base in ('enc_dense_wino', 'head_logit_table'):
+            return 16.0 / 36.0
+        if base == 'csa_scores' and HW >= 4096:
+            side = HW ** 0.5
+            items = -(-side // 8) * -(-side // 16) * -(-(side / 2) // 4) * -(-(side / 2) // 16)
+            return items * 2.0 * 192 * 128 * (C / 2) / (2.0 * HW * (HW / 4) * 4.5 * C)
+        return 1.0
+    if base in ('head_kv_fused', 'head_decode_fused', 'enc_dense'):
+        if precision == 'f16x3':
+            return 3.0
+        if precision == 'f16-pairs' or (precision == 'bf16' and not bf16_single):
+            return 2.0
+    return 1.0
+
+
+def roofline_object(tag, total_ms, launches, Q, HW, n_tiles, precision='fp32', bf16_single=False):
+    """The `roofline` entry of one kernel tag from its HIP-event time: algorithmic work / time against the gfx950 peak, with the
+    executed-work twin (`executed_frac` <= 1 is the matrix pipe's share; `frac` may exceed 1 for Winograd / box-sum kernels)."""
+    work = kernel_work(tag, Q, HW)
+    if not work or total_ms <= 0:
+        return None
+    amount, kind = work[0] * n_tiles, work[1]
+    if kind == 'byte':
+        ach = amount / (total_ms * 1e-3) / 1e9
+        return dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(ach / PEAK_HBM_GBS, 4),
+                    traffic=None, algorithmic_bytes_per_launch=round(amount / max(launches, 1)))
+    peak = PEAK_F32_MFMA_TFLOPS if kind == 'flop' else PEAK_BF16_MFMA_TFLOPS
+    ach = amount / (total_ms * 1e-3) / 1e12
+    ratio = executed_ratio(tag, HW, precision=precision, bf16_single=bf16_single)
+    return dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
+                algorithmic_flop_per_launch=round(amount / max(launches, 1)),
+                executed_flop_per_launch=round(amount * ratio / max(launches, 1)),
+                executed_frac=round(ach * ratio / peak, 4))
 
 
 def _cores():
@@ -277,6 +325,10 @@ def main():
     ap.add_argument('--encoder-ahead', action='store_true', help='test_cfg.encoder_ahead: trunk of the next tile batch on a side stream under the heads of the current one (bitwise the same image; per-kernel timings then overlap)')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
+    ap.add_argument('--rank0-share', default='1.0',
+                    help='N > 1, tile sharding: fraction of the full rounds rank 0 (which also blends every tile and finalizes the image) '
+                         'takes a tile in (tile_shard.tile_owners; it always sits out the ragged last round); a number in [0, 1], or "auto": '
+                         'rank 0 times its blend + finalize + de-normalise work against a tile and every rank takes its answer')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
                     help='c3 (default; the config BASELINE.json\'s metric is quoted on): LR 1356x2040, 117 tiles; c3s: LR 339x510 (6 tiles); '
                          'c3tile: one 192x192 LR tile; c2: LR 48x48 (BASELINE configs[1]); c2q: C2 with its query range sharded over the ranks '
@@ -301,16 +353,25 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device('cuda', local_dev)
     rccl_ranks = 1
+    p2p_channels = None
+    watchdog = None
     if world > 1:
+        import datetime
+        from ciaosr_amd.tile_shard import StepDeadline, ensure_communicator, rccl_env_defaults
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        p2p_channels = rccl_env_defaults()            # before the communicator exists: RCCL reads its environment at init
+        # bounded waits: a step (incl. the profiled / checked ones) past the deadline ends THIS rank with exit code 3, and the
+        # launcher then ends the others; collectives time out on the same scale instead of the 10 / 30-minute defaults
+        deadline_s = float(os.environ.get('CIAOSR_STEP_DEADLINE_S', '900'))
+        pg_timeout = datetime.timedelta(seconds=max(deadline_s, 60.0))
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-        # ranks as the communicator itself counts them: an all-reduce of ones over RCCL
-        ones = torch.ones(1, device=dev if backend == 'nccl' else 'cpu', dtype=torch.int32)
-        dist.all_reduce(ones)
-        rccl_ranks = int(ones.item())
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
+        watchdog = StepDeadline(deadline_s, what='bench step', rank=rank)
+        # ranks as the communicator itself counts them: an all-reduce of ones over RCCL (also: the communicator exists before the
+        # first grouped point-to-point call)
+        rccl_ranks = ensure_communicator(None, dev)
         assert rccl_ranks == world == dist.get_world_size()
 
     from ciaosr_amd import hip_ops, _lib
@@ -334,15 +395,43 @@ def main():
         q_cell = make_cell((lr_h * scale, lr_w * scale)).unsqueeze(0).to(dev)
 
     tail = {}                                         # stream events of the last step (N > 1): exposed-tail figure
+    share = dict(value=1.0, source='argument')
+
+    def rank0_share_auto():
+        """Rank 0's own extra work per image (n blends of a tile + tile_finalize + denorm_clamp, on scratch buffers) against one tile's
+        compute time -> the fraction of full rounds it should join so that its stream ends with the peers'; broadcast to every rank."""
+        val = [1.0, 0.0, 0.0]
+        if rank == 0:
+            hh, ww = lr_h * scale, lr_w * scale
+            E = torch.zeros(3, hh, ww, device=dev)
+            Wt = torch.ones_like(E)
+            tl = synthetic_pair(192, 192, scale)[0].to(dev)
+            model.restore(tl, options=opt)
+            t_tile = time_steps(lambda: model.restore(tl, options=opt), 2, dev)
+            tile_out = torch.zeros(768 * 768, 3, device=dev)
+
+            def extra():
+                for _ in range(n_tiles_img):
+                    hip_ops.tile_blend(E, Wt, tile_out, 0, 0, 768, 768)
+                hip_ops.denorm_clamp(hip_ops.tile_finalize(E, Wt), hh, ww, model.rgb_mean, model.rgb_std)
+            extra()
+            t_extra = time_steps(extra, 1, dev)
+            per_rank = t_tile * n_tiles_img / world
+            val = [min(max(1.0 - t_extra / per_rank, 0.0), 1.0), t_tile, t_extra]
+        box = [val]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
 
     def step():
+        if watchdog is not None:
+            watchdog.beat()
         if world == 1:
             return model.restore(lq, options=opt)
         x = model.normalize(lq)
         if args.workload == 'c2q':
             pred = predict_query_sharded(model, x, q_coord, q_cell, rank, world, options=opt)
         else:
-            pred = clip_test_distributed(model, x, rank, world, options=opt, stats=tail)
+            pred = clip_test_distributed(model, x, rank, world, options=opt, stats=tail, rank0_share=share['value'])
         if rank == 0:
             out = hip_ops.denorm_clamp(pred[0].contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
             tail['ready'] = torch.cuda.Event(enable_timing=True)
@@ -357,10 +446,18 @@ def main():
         torch.cuda.synchronize(dev)
 
     if world > 1:
+        if args.workload != 'c2q':
+            if args.rank0_share == 'auto':
+                v = rank0_share_auto()
+                share.update(value=float(v[0]), source=f'auto: tile {v[1]:.2f} ms, rank-0 blends + finalize + de-normalise {v[2]:.2f} ms per image')
+            else:
+                share.update(value=float(args.rank0_share))
         # correctness of the sharded path before timing it: rank 0's blended image must be bitwise equal to the
-        # single-process clip_test of the same image on this GPU
+        # single-process clip_test of the same image on this GPU (this step also sets up every peer connection of the
+        # communicator: nothing is connected lazily inside the timed region)
         out = step()
         if rank == 0:
+            watchdog.beat()
             ref = model.restore(lq, options=opt)[0]
             assert torch.equal(out, ref), f'tile-sharded output differs from 1-GPU output by {(out - ref).abs().max().item()}'
             del ref
@@ -426,51 +523,32 @@ def main():
         tile_lr = 48 if args.workload in ('c2', 'c2q') else 192
         n_tiles = n_tiles_img
         if world > 1 and args.workload != 'c2q':
-            n_tiles = (n_tiles + world - 1) // world          # tiles t = 0, R, 2R, ... run on rank 0 (whose kernels are timed)
+            from ciaosr_amd.tile_shard import partition
+            n_tiles = max(len(partition(n_tiles_img, world, share['value'])[0]), 1)      # rank 0's tiles (its kernels are timed)
         Q, HW = (tile_lr * scale) ** 2, tile_lr * tile_lr
         roof = None
         if dominant and dominant in prof_dom:
-            work = kernel_work(dominant, Q, HW)
-            if work:
-                work = (work[0] * n_tiles, work[1])
             avg_ms = prof_dom[dominant]['avg_ms']
             launches_per_step = prof_dom[dominant]['launches'] / prof_steps
             step_ms = prof_dom[dominant]['total_ms'] / prof_steps      # all launches of the tag in one step
-            if work:
-                amount, kind = work
-                if kind in ('flop', 'flop16'):
-                    peak = PEAK_F32_MFMA_TFLOPS if kind == 'flop' else PEAK_BF16_MFMA_TFLOPS
-                    ach = amount / (step_ms * 1e-3) / 1e12
-                    roof = dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s',
-                                frac=round(ach / peak, 4), traffic=None)
-                    roof['algorithmic_flop_per_launch'] = round(amount / launches_per_step)
-                    if kind == 'flop16' and ((args.precision == 'bf16' and not args.bf16_single) or args.precision == 'f16-pairs') and \
-                            dominant.rsplit('_', 1)[0] in ('head_kv_fused', 'head_decode_fused', 'enc_dense'):
-                        # hi + lo weight pairs: the kernel issues two MFMAs per algorithmic product
-                        roof['executed_mfma_flop_per_launch'] = 2 * roof['algorithmic_flop_per_launch']
-                        roof['mfma_pipe_frac'] = round(2 * ach / peak, 4)
-                else:
-                    ach = amount / (step_ms * 1e-3) / 1e9
-                    roof = dict(bound='hbm', achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
-                    roof['algorithmic_bytes_per_launch'] = round(amount / launches_per_step)
+            roof = roofline_object(dominant, step_ms, launches_per_step, Q, HW, n_tiles, args.precision, args.bf16_single)
+            if roof:
                 roof.update(kernel=dominant, timing='HIP events on the launch stream inside the timed region' if live else
                             f'HIP events in a separate pass of {prof_steps} steps (too many short launches per step to bracket live)',
                             avg_launch_ms=round(avg_ms, 5),
                             launches=prof_dom[dominant]['launches'],
                             share_of_step=round(prof_all[dominant]['total_ms'] /
                                                 max(sum(v['total_ms'] for v in prof_all.values()), 1e-9), 3))
-                # the other kernels of the step against their own rooflines (one fully profiled step)
+                # the other kernels of the step against their own rooflines (one fully profiled step); `frac` is priced on the
+                # reference's form of the contraction, `executed_frac` on the flops the kernel's MFMAs execute
                 others = {}
                 for tag, pr in prof_all.items():
-                    wk = kernel_work(tag, Q, HW)
-                    if tag == dominant or not wk or pr['total_ms'] < 0.02:
+                    ro = roofline_object(tag, pr['total_ms'], pr['launches'], Q, HW, n_tiles, args.precision, args.bf16_single)
+                    if tag == dominant or not ro or pr['total_ms'] < 0.02:
                         continue
-                    amt, knd = wk[0] * n_tiles, wk[1]
-                    rate = amt / (pr['total_ms'] * 1e-3)
-                    pk = {'flop': PEAK_F32_MFMA_TFLOPS * 1e12, 'flop16': PEAK_BF16_MFMA_TFLOPS * 1e12, 'byte': PEAK_HBM_GBS * 1e9}[knd]
-                    others[tag] = dict(bound='hbm' if knd == 'byte' else 'mfma', ms_per_step=round(pr['total_ms'], 4),
-                                       frac=round(rate / pk, 4))
+                    others[tag] = dict(bound=ro['bound'], ms_per_step=round(pr['total_ms'], 4), frac=ro['frac'])
+                    if 'executed_frac' in ro:
+                        others[tag]['executed_frac'] = ro['executed_frac']
                 roof['other_kernels'] = others
                 # HBM bytes per launch: OFFLINE evidence from the committed rocprofv3 --pmc passes of this round (separate
                 # passes, FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, tools/pmc_summary.py); null when the summary is absent
@@ -480,7 +558,8 @@ def main():
                           'head_kv_fused_f16': 'head_kv_fused_h16_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
                           'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
-                pmc_path = os.path.join(REPO, 'profiles', f'r2_{unit}_pmc_hbm_traffic.json')
+                pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (4, 3))
+                                 if os.path.exists(q)), '')
                 live_traffic = None
                 if world == 1 and not args.no_live_pmc and dominant in tag2fn:
                     # LIVE: two rocprofv3 --pmc child passes of this script on one tile, now, on this box
@@ -513,8 +592,9 @@ def main():
             'config': {'workload': wl_desc + (', fp32' if args.precision == 'fp32' else f', {args.precision} mode')
                        + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs, '
                                                  'RCCL gather of the RGB slices' if args.workload == 'c2q' else
-                                                 f' (C4); tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world}), RCCL gather of '
-                                                 'the output tiles to rank 0 overlapped with compute, rank-0 blend in the reference order')),
+                                                 f' (C4); tiles of the one image sharded over {world} GPUs (tile t -> rank t % {world}; rank 0, which also '
+                                                 'blends, sits out the ragged last round), grouped RCCL point-to-point delivery of the output tiles to '
+                                                 'rank 0 under compute, rank-0 blend in the reference order')),
                        'lr': [lr_h, lr_w], 'scale': scale, 'tiles': n_tiles_img, 'queries_per_step': out_pixels,
                        'parallelism': (f'query-shard x{world}' if args.workload == 'c2q' else f'tile-shard x{world}')},
             'roofline': roof,
@@ -524,8 +604,11 @@ def main():
         if world > 1:
             from ciaosr_amd.tile_shard import partition
             line['rank_ms_per_step'] = rank_ms
+            line['p2p_channels'] = p2p_channels
+            line['step_deadline_s'] = watchdog.seconds
             if args.workload != 'c2q':
-                line['tiles_per_rank'] = [len(p) for p in partition(n_tiles_img, world)]
+                line['tiles_per_rank'] = [len(p) for p in partition(n_tiles_img, world, share['value'])]
+                line['rank0_share'] = dict(share)
                 if 'last_own_tile' in tail and 'ready' in tail:
                     # GPU-timeline time on rank 0 from "its last own tile's kernels are done" to "the image is ready": the last
                     # round's receives, the remaining blends, tile_finalize and denorm_clamp -- the part of the exchange that does
@@ -551,24 +634,42 @@ def main():
                     hb[tag] = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                    frac=round(gbs / PEAK_HBM_GBS, 4), ms_per_tile=round(st[tag]['total_ms'], 4))
             roof['staged_path_hbm_kernels'] = hb
-            # (2) the other precision / the other single-tile config, for the record (not the headline)
+            # (2) the other precision / the other single-tile config, for the record (not the headline); every 16-bit figure carries
+            # the roofline object of ITS dominant kernel (one profiled pass of the same input)
+            def mode_roofline(inp, o, precision, n_t):
+                with hip_ops.profile():
+                    model.restore(inp, options=o)
+                    torch.cuda.synchronize(dev)
+                pr = hip_ops.profile.results()
+                if not pr:
+                    return None
+                dom = max(pr, key=lambda k_: pr[k_]['total_ms'])
+                ro = roofline_object(dom, pr[dom]['total_ms'], pr[dom]['launches'], Q, HW, n_t, precision)
+                if ro:
+                    ro.update(kernel=dom, avg_launch_ms=round(pr[dom]['avg_ms'], 5), launches=pr[dom]['launches'],
+                              share_of_step=round(pr[dom]['total_ms'] / max(sum(v['total_ms'] for v in pr.values()), 1e-9), 3),
+                              timing='HIP events on the launch stream, one profiled pass after the timed one')
+                return ro
+
             if args.workload in ('c3', 'c3s', 'c3tile'):
-                o16 = hip_ops.Options('bf16')
-                model.restore(tl, options=o16)
-                extras['c3_tile_bf16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=o16), 3, dev), 3)
-                oh = hip_ops.Options('f16')
-                model.restore(tl, options=oh)
-                extras['c3_tile_f16_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=oh), 3, dev), 3)
+                modes = [('bf16', hip_ops.Options('bf16'), 'bf16'), ('f16', hip_ops.Options('f16'), 'f16'),
+                         ('f16_pairs', hip_ops.Options('f16-pairs'), 'f16-pairs')]
+                if 'f16x3' in hip_ops.PRECISIONS:
+                    modes.append(('f16x3', hip_ops.Options('f16x3'), 'f16x3'))
+                o16, oh = modes[0][1], modes[1][1]
+                for nm, o, prec in modes:
+                    model.restore(tl, options=o)
+                    extras[f'c3_tile_{nm}_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=o), 3, dev), 3)
+                    if args.workload != 'c3':
+                        extras[f'c3_tile_{nm}_mode_roofline'] = mode_roofline(tl, o, prec, 1)
                 extras['c3_tile_fp32_ms'] = round(time_steps(lambda: model.restore(tl), 3, dev), 3)
-                op = hip_ops.Options('f16-pairs')
-                model.restore(tl, options=op)
-                extras['c3_tile_f16_pairs_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=op), 3, dev), 3)
                 if args.workload == 'c3':        # the whole C3 image in the opt-in 16-bit modes (PSNR-gated extensions; not the headline)
-                    for nm, o in (('f16', oh), ('f16_pairs', op), ('bf16', o16)):
+                    for nm, o, prec in modes:
                         model.restore(lq, options=o)
                         t_ = time_steps(lambda: model.restore(lq, options=o), 1, dev)
                         extras[f'c3_{nm}_mode_ms'] = round(t_, 1)
                         extras[f'c3_{nm}_mode_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
+                        extras[f'c3_{nm}_mode_roofline'] = mode_roofline(lq, o, prec, n_tiles_img)
                     # opt-in test_cfg.encoder_ahead: the trunk of tile batch k + 1 on a side stream under the heads of batch k (bitwise the
                     # same image).  Not the headline: per-kernel event timings overlap while two streams share the chip.
                     model.test_cfg['encoder_ahead'] = True
@@ -600,7 +701,9 @@ def main():
                 line['cpu_baseline'] = cpu_baseline_c3(n_tiles_img, out_pixels, scale)
         print(json.dumps(line), flush=True)
     if world > 1:
+        watchdog.beat()
         dist.barrier()
+        watchdog.stop()
         dist.destroy_process_group()
 
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             for (int s = 0; s < NSB; ++s) {
                 const int idx = t + 256 * s;
                 const int gn = n0 + (idx & 31) * 4;
-                offB[s] = gn < p.N ? ((unsigned)(idx >> 5) * (unsigned)p.ldb + (unsigned)gn) * 4u : kOobG;      // rows k >= K lie past the descriptor's end
+                offB[s] = gn < p.N ? ((unsigned)(idx >> 5) * (unsigned)p.ldb + (unsigned)gn) * 4u : kOobG;      // rows k >= K: masked in load_tiles
             }
         }
     };
@@ -159,9 +159,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
             }
         }
         if (B_KN) {
+            // the k-tile sits in the SCALAR offset, which the descriptor's range check does not see: rows k >= K of a ragged last k-tile
+            // would read whatever follows B (a NaN there times the zero-masked A columns is NaN), so they take the out-of-range per-lane
+            // offset on the same uniform branch as the ragged A columns
             const unsigned skb = (unsigned)k0 * (unsigned)p.ldb * 4u;
+            if (k_ragged && k0 + BK > p.K) {
 #pragma unroll
-            for (int s = 0; s < NSB; ++s) rb[s] = buf_ld4s(rs_b, offB[s], skb);
+                for (int s = 0; s < NSB; ++s) rb[s] = buf_ld4s(rs_b, k0 + ((t + 256 * s) >> 5) < p.K ? offB[s] : kOobG, skb);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NSB; ++s) rb[s] = buf_ld4s(rs_b, offB[s], skb);
+            }
         }
     };
     // row-softmax statistics of this thread's four A rows (rows t / 8 + 32 s), when A holds logits

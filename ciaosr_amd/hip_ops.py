@@ -83,6 +83,14 @@ def take_workspaces(stream):
     return {k: _workspaces.pop(k) for k in keys}
 
 
+def poison_workspaces():
+    """Test hook: fill every cached scratch buffer with 0xFF bytes (fp32 / bf16 / half NaN patterns).  A kernel that reads scratch
+    it (or an earlier kernel of the call) did not write -- a ragged tile edge, a row past K -- then shows up as NaN in the result."""
+    for buf in _workspaces.values():
+        if buf is not None:
+            buf.fill_(0xFF)
+
+
 def release_workspaces():
     """Drop every cached scratch buffer (they are re-grown on demand)."""
     _workspaces.clear()
@@ -177,6 +185,9 @@ def tile_finalize(E, Wt):
     out = torch.empty(Himg * Wimg, 3, dtype=torch.float32, device=E.device)
     _lib.call('ciaosr_tile_finalize_f32', ptr(E), ptr(Wt), ptr(out), Himg, Wimg, stream_ptr())
     return out
+
+
+PRECISIONS = ('fp32', 'bf16', 'f16', 'f16-pairs')       # what Options(precision) / test_cfg.precision accept
 
 
 class Options:

@@ -1,65 +1,170 @@
 """Tile-sharded inference of one large image across the GPUs of a node.
 
 Units = the LR tiles of `CiaoSR.clip_test` (ciaosr.py:233-254): every tile runs encoder + cs_attn +
-head on its own crop with no cross-tile data, so the tile list is partitioned over ranks
-(row-major tile index t -> rank t % R) with no collective on the data path.  The one exchange is
-the delivery of output tiles to rank 0 (RCCL point-to-point over xGMI; torch.distributed backend
-'nccl' on ROCm, 'gloo' in the CPU tests): a peer `isend`s each tile the moment its kernels are
-queued -- the copy runs on RCCL's own stream over that peer's direct xGMI link to rank 0 while the
-peer's next tile computes -- and rank 0 blends the tiles of round k-1 (tiles (k-1)R+1 .. kR-1, which
-have had a whole tile time to arrive) after launching its own tile kR, always in the reference order
-(h outer, w inner), so the result is bitwise equal to the 1-GPU run.  Nothing is all-gathered: a peer
-holds only its own not-yet-delivered tiles, rank 0 a ring of two rounds of receive buffers
-(2 tiles per peer), and exchange + blend hide under compute except for the last round.
+head on its own crop with no cross-tile data, so the tile list is partitioned over ranks (`tile_owners`:
+row-major tile index t -> rank t % R, except that rank 0 -- which also owns every blend and the finalize --
+sits out the ragged last round) with no collective on the data path.  The one exchange is the delivery of
+output tiles to rank 0 (RCCL point-to-point over xGMI; torch.distributed backend 'nccl' on ROCm, 'gloo' in
+the CPU tests and the one-GPU rehearsals):
+
+* a peer hands each tile to RCCL the moment its kernels are queued -- the send runs on RCCL's own stream
+  over that peer's direct xGMI link to rank 0 while the peer's next tile computes;
+* rank 0 posts the receives of a round as ONE grouped operation (one RCCL kernel for the R - 1 peers) AFTER
+  its own tile of that round has been queued: RCCL orders the receive kernel behind the work already on the
+  compute stream, so it starts when rank 0's tile ends -- which is when the peers' tiles of the same round
+  end -- instead of spinning on rank 0's CUs for a whole tile time; it then runs under rank 0's NEXT tile;
+* rank 0 blends a round's tiles one round later (they have had a whole tile time to arrive), always in the
+  reference order (h outer, w inner), so the result is bitwise equal to the 1-GPU run.
+
+Nothing is all-gathered: a peer holds only its own not-yet-delivered tiles, rank 0 two rounds of receive
+buffers, and exchange + blend hide under compute except for the last round.  Both sides use the grouped
+form (`dist.batch_isend_irecv`), i.e. the process group's ONE communicator (created eagerly by
+`init_process_group(device_id=...)`): no per-pair communicator is built lazily inside the timed region.
 """
+import math
+import os
+import sys
+import threading
+import time
+
 import torch
 import torch.distributed as dist
 
 from .restorer import tile_grid
 
 
-def partition(n_tiles, world):
-    """tile index -> owning rank, and per-rank tile lists (round-robin keeps neighbours apart so
-    each rank's share of the expensive border tiles is even)."""
-    return [[t for t in range(n_tiles) if t % world == r] for r in range(world)]
+def rccl_env_defaults(env=None):
+    """Environment defaults for the tile exchange, applied with setdefault BEFORE the communicator exists (RCCL reads them at
+    init): one point-to-point channel -- a 7-MB tile per peer and round needs ~0.3 ms of one channel, and every further channel is
+    one more workgroup of the receive kernel resident on rank 0's CUs beside its own tile; dmabuf IPC (this driver's only mode).
+    Returns the p2p channel count in force (reported by bench.py)."""
+    env = os.environ if env is None else env
+    env.setdefault('NCCL_MIN_P2P_NCHANNELS', '1')
+    env.setdefault('NCCL_MAX_P2P_NCHANNELS', '1')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return int(env['NCCL_MAX_P2P_NCHANNELS'])
+
+
+class StepDeadline:
+    """Bounded wait for the N-rank paths: `beat()` at the start of every step; a rank whose step does not finish within `seconds`
+    writes one line to stderr and leaves with exit code 3 (`os._exit`: no exec, no unwinding through a hung collective), so the
+    launcher (torch.distributed.run) tears the other ranks down instead of the job hanging on a lost peer."""
+
+    def __init__(self, seconds, what='step', rank=0):
+        self.seconds, self.what, self.rank = float(seconds), what, rank
+        self.t = time.monotonic()
+        self._stop = threading.Event()
+        self._thread = None
+        if self.seconds > 0:
+            self._thread = threading.Thread(target=self._run, name='ciaosr-step-deadline', daemon=True)
+            self._thread.start()
+
+    def beat(self):
+        self.t = time.monotonic()
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(min(1.0, self.seconds / 4)):
+            late = time.monotonic() - self.t
+            if late > self.seconds:
+                sys.stderr.write(f'[ciaosr] rank {self.rank}: {self.what} not finished after {late:.0f} s '
+                                 f'(deadline {self.seconds:.0f} s): leaving with exit code 3\n')
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def tile_owners(n_tiles, world, rank0_share=1.0):
+    """owner[t] of every tile.  Rounds of `world` consecutive tiles, rank r taking the r-th tile of its round (t % R when nothing is
+    skipped: neighbours stay apart, every rank's share of the border tiles is even).  Rank 0 also blends all n tiles and
+    finalizes the image, so it gets the lighter share wherever one exists: it sits out the ragged last round (117 tiles on 8
+    ranks: 14 / 15 x 5 / 14 x 2 instead of 15 x 5 / 14 x 3 with rank 0 among the fifteens), and with `rank0_share` s < 1 it takes
+    part in a fraction s of the full rounds only (evenly spaced; s = 0: rank 0 only blends).  The blend order never changes."""
+    if world <= 1:
+        return [0] * n_tiles
+    s = min(max(float(rank0_share), 0.0), 1.0)
+    owners, k = [], 0
+    while len(owners) < n_tiles:
+        left = n_tiles - len(owners)
+        takes0 = math.ceil((k + 1) * s - 1e-9) > math.ceil(k * s - 1e-9)
+        if left < world and k > 0:
+            takes0 = False
+        ranks = ([0] if takes0 else []) + list(range(1, world))
+        owners += ranks[:left]
+        k += 1
+    return owners
+
+
+def partition(n_tiles, world, rank0_share=1.0):
+    """Per-rank tile lists of `tile_owners`."""
+    owners = tile_owners(n_tiles, world, rank0_share)
+    return [[t for t in range(n_tiles) if owners[t] == r] for r in range(world)]
+
+
+_warm_groups = set()
+
+
+def ensure_communicator(group=None, device=None):
+    """The group's communicator must exist before the first grouped point-to-point call that only SOME ranks take part in
+    (torch.distributed.batch_isend_irecv: 'if this is the first collective call in the group, all ranks must participate'): one
+    all-reduce of ones, once per group, by every rank.  Returns the rank count as the communicator counts it."""
+    if not dist.is_initialized():
+        return 1
+    key = id(group if group is not None else dist.distributed_c10d._get_default_group())
+    if key in _warm_groups:
+        return dist.get_world_size(group)
+    on_gpu = device is not None and torch.device(device).type == 'cuda' and dist.get_backend(group) != 'gloo'
+    ones = torch.ones(1, dtype=torch.int32, device=device if on_gpu else 'cpu')
+    dist.all_reduce(ones, group=group)
+    _warm_groups.add(key)
+    return int(ones.item())
 
 
 class _Mover:
-    """isend / irecv of one tile, hiding the single-GPU rehearsal case (gloo backend with CUDA tensors: staged through
+    """Grouped isend / irecv of tiles, hiding the single-GPU rehearsal case (gloo backend with CUDA tensors: staged through
     the host).  Keeps the tensors alive until their transfer has completed."""
 
     def __init__(self, group, device):
         self.group = group
         self.via_host = device is not None and torch.device(device).type == 'cuda' and dist.get_backend(group) == 'gloo'
-        self.pending = []          # (work, tensors kept alive)
+        self.pending = []          # (works, tensors kept alive)
 
     def send(self, t, dst):
         buf = t.cpu() if self.via_host else t.contiguous()
-        self.pending.append((dist.isend(buf, dst=dst, group=self.group), buf))
+        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst, self.group)])
+        self.pending.append((works, buf))
         # drop what has been delivered: a peer never holds more than its in-flight tiles
-        while self.pending and self.pending[0][0].is_completed():
+        while self.pending and all(w.is_completed() for w in self.pending[0][0]):
             self.pending.pop(0)
 
-    def recv(self, like_shape, src, device):
-        buf = torch.empty(like_shape, dtype=torch.float32, device='cpu' if self.via_host else device)
-        return dist.irecv(buf, src=src, group=self.group), buf
+    def recv_many(self, like_shape, srcs, device):
+        """One grouped receive of len(srcs) equally shaped tiles (RCCL: ONE kernel on the communicator's stream, ordered behind
+        what the compute stream holds at this moment).  Returns a batch handle for `take`."""
+        bufs = [torch.empty(like_shape, dtype=torch.float32, device='cpu' if self.via_host else device) for _ in srcs]
+        works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, s, self.group) for b, s in zip(bufs, srcs)])
+        return dict(works=works, bufs=bufs, waited=False)
 
-    def take(self, handle, device):
-        work, buf = handle
-        work.wait()                # NCCL: the current stream waits for the copy (no host block); gloo: host waits
+    def take(self, batch, i, device):
+        if not batch['waited']:
+            for w in batch['works']:
+                w.wait()           # NCCL: the current stream waits for the grouped copy (no host block); gloo: host waits
+            batch['waited'] = True
+        buf, batch['bufs'][i] = batch['bufs'][i], None
         return buf.to(device) if self.via_host else buf
 
     def drain(self):
-        for work, _ in self.pending:
-            work.wait()
+        for works, _ in self.pending:
+            for w in works:
+                w.wait()
         self.pending = []
 
 
 def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_fn, rank, world, group=None,
-                      device=None, gather_to_all=False, mark=None):
+                      device=None, gather_to_all=False, mark=None, rank0_share=1.0):
     """Generic driver (device-agnostic so it can be exercised with gloo on CPU).
 
-    mark(name): optional probe, called at 'last_own_tile' (this rank's last tile has been queued) and, on rank 0,
+    mark(name): optional probe, called at 'start', at 'last_own_tile' (this rank's last tile has been queued) and, on rank 0,
     at 'finalized' (every tile blended and normalised) -- bench.py records stream events there to report the exposed tail.
 
     tile_fn(hi, wi, tile)      -> [B, th*tw, 3] tensor (prediction of the LR crop), th = tw = tile*sf
@@ -72,13 +177,19 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
     th = tw = round(tile * sf)
     n = len(origins)
     shape = (b, th * tw, 3)
+    owners = tile_owners(n, world, rank0_share)
+    if world > 1:
+        ensure_communicator(group, device)
     mover = _Mover(group, device) if world > 1 else None
+    if mark is not None:
+        mark('start')
 
     if rank != 0:
-        # peer: compute tile t = rank, rank + R, ... and hand each to RCCL as soon as it is queued
-        for t in range(rank, n, world):
-            hi, wi = origins[t]
-            mover.send(tile_fn(hi, wi, tile), 0)
+        # peer: compute the own tiles in tile order and hand each to RCCL as soon as it is queued
+        for t in range(n):
+            if owners[t] == rank:
+                hi, wi = origins[t]
+                mover.send(tile_fn(hi, wi, tile), 0)
         if mark is not None:
             mark('last_own_tile')
         mover.drain()
@@ -86,25 +197,44 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
     else:
         E = torch.zeros(b, c, round(h * sf), round(w * sf), dtype=torch.float32, device=device)
         Wt = torch.zeros_like(E)
+        handles = {}               # peer tile -> (batch, index in the batch)
+        state = dict(posted=0, blended=0)
+
+        def post(upto):
+            """Grouped receive of every peer tile below `upto` that has none yet."""
+            peer = [t for t in range(state['posted'], upto) if owners[t] != 0]
+            state['posted'] = max(state['posted'], upto)
+            if peer:
+                batch = mover.recv_many(shape, [owners[t] for t in peer], device)
+                for i, t in enumerate(peer):
+                    handles[t] = (batch, i)
 
         def blend(t, out):
             hi, wi = origins[t]
             blend_fn(E, Wt, out, round(hi * sf), round(wi * sf), th, tw)
 
-        prev = []                  # receive handles of the previous round's peer tiles, in tile order
-        for t0 in range(0, n, world):
-            # receives of THIS round are posted before the own tile is launched, consumed one round later
-            cur = [(t, mover.recv(shape, t % world, device)) for t in range(t0 + 1, min(t0 + world, n))]
+        def blend_peers_below(upto):
+            for t in range(state['blended'], upto):
+                batch, i = handles.pop(t)
+                blend(t, mover.take(batch, i, device))
+            state['blended'] = max(state['blended'], upto)
+
+        own = [t for t in range(n) if owners[t] == 0]
+        if mark is not None and not own:
+            mark('last_own_tile')
+        for k, t0 in enumerate(own):
             hi, wi = origins[t0]
-            own = tile_fn(hi, wi, tile)
-            if mark is not None and t0 + world >= n:
+            out = tile_fn(hi, wi, tile)
+            if mark is not None and k == len(own) - 1:
                 mark('last_own_tile')
-            for t, handle in prev:                         # tiles (t0 - R + 1 .. t0 - 1) precede t0 in the reference order
-                blend(t, mover.take(handle, device))
-            blend(t0, own)
-            prev = cur
-        for t, handle in prev:
-            blend(t, mover.take(handle, device))
+            # the peers compute the tiles up to rank 0's next own tile while t0 computes here: their receives are posted NOW,
+            # behind t0 on the compute stream, and consumed one round later
+            post(own[k + 1] if k + 1 < len(own) else n)
+            blend_peers_below(t0)                          # tiles below t0 precede it in the reference order
+            blend(t0, out)
+            state['blended'] = t0 + 1
+        post(n)
+        blend_peers_below(n)
         result = finalize_fn(E, Wt)
         if mark is not None:
             mark('finalized')
@@ -122,15 +252,20 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
     return result
 
 
-def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False, options=None, stats=None):
+def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False, options=None, stats=None,
+                          rank0_share=None):
     """Tile-sharded counterpart of CiaoSR.clip_test on the GPUs of one node.
-    `stats` (optional dict) receives a stream event per probe point of `sharded_clip_test` (bench.py's exposed-tail figure)."""
+    `stats` (optional dict) receives a stream event per probe point of `sharded_clip_test` (bench.py's exposed-tail figure).
+    `rank0_share` (default `test_cfg.rank0_share` or 1): see `tile_owners`; every rank must pass the same value."""
     from . import hip_ops
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
     cfg = restorer.test_cfg
     sf = cfg.get('scale')
     opt = restorer.options(options)
+    if rank0_share is None:
+        rank0_share = cfg.get('rank0_share', None)
+    rank0_share = 1.0 if rank0_share is None else float(rank0_share)
 
     def tile_fn(hi, wi, tile):
         out, _ = restorer.run_tile(x_norm, hi, wi, tile, sf, opt)
@@ -145,7 +280,8 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
     if (n_batch > 1 and x_norm.is_cuda and x_norm.shape[0] == 1 and enc is not None and hasattr(enc, 'forward_hwc_batch')
             and enc.supported() and getattr(gen, '_head', None) is not None):
         tile_sz, origins = tile_grid(x_norm.shape[-2], x_norm.shape[-1], cfg.get('tile'), cfg.get('tile_overlap'))
-        mine = origins[rank::world]
+        owners = tile_owners(len(origins), world, rank0_share)
+        mine = [o for o, r in zip(origins, owners) if r == rank]
         pos = {o: i for i, o in enumerate(mine)}
         cache = {}
 
@@ -177,7 +313,7 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
             stats[name] = ev
 
     return sharded_clip_test(tuple(x_norm.shape), cfg.get('tile'), cfg.get('tile_overlap'), sf, tile_fn, blend_fn,
-                             finalize_fn, rank, world, group, x_norm.device, gather_to_all, mark)
+                             finalize_fn, rank, world, group, x_norm.device, gather_to_all, mark, rank0_share)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -229,6 +365,7 @@ def query_sharded_predict(feature_fn, predict_fn, coord, cell, rank, world, chun
     if world == 1:
         return slab[:, :q1 - q0]
     # RGB slices -> rank 0, point to point (each peer over its own xGMI link); only rank 0 allocates the full output
+    ensure_communicator(group, coord.device)
     mover = _Mover(group, coord.device)
     if rank != 0:
         if q1 > q0:
@@ -236,11 +373,11 @@ def query_sharded_predict(feature_fn, predict_fn, coord, cell, rank, world, chun
         mover.drain()
         out = None
     else:
-        handles = [(r, mover.recv((b, s[1] - s[0], 3), r, coord.device)) for r, s in enumerate(slices) if r > 0 and s[1] > s[0]]
+        handles = [(r, mover.recv_many((b, s[1] - s[0], 3), [r], coord.device)) for r, s in enumerate(slices) if r > 0 and s[1] > s[0]]
         out = torch.empty(b, n_query, 3, dtype=torch.float32, device=coord.device)
         out[:, q0:q1] = slab[:, :q1 - q0]
         for r, handle in handles:
-            out[:, slices[r][0]:slices[r][1]] = mover.take(handle, coord.device)
+            out[:, slices[r][0]:slices[r][1]] = mover.take(handle, 0, coord.device)
     if gather_to_all:
         if rank != 0:
             out = torch.empty(b, n_query, 3, dtype=torch.float32, device=coord.device)

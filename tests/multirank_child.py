@@ -38,6 +38,40 @@ def main():
     model = model.to(dev)
     checked = []
 
+    if os.environ.get('CIAOSR_CHILD_CASE') == 'c4':
+        # C4 at its real shape: the 117 tiles of the LR 1356x2040 image over the ranks (8 ranks: 14 full rounds through the
+        # two-round receive ring + a ragged round of 5 that rank 0 sits out), f16 (short) and one fp32 run
+        from ciaosr_amd.tile_shard import StepDeadline, partition
+        watchdog = StepDeadline(float(os.environ.get('CIAOSR_STEP_DEADLINE_S', '900')), what='C4 rehearsal step', rank=rank)
+        lq = synthetic_pair(1356, 2040, scale)[0].to(dev)
+        for precision in os.environ.get('CIAOSR_CHILD_PRECISIONS', 'f16,fp32').split(','):
+            watchdog.beat()
+            opt = hip_ops.Options(precision)
+            x = model.normalize(lq)
+            stats = {}
+            pred = clip_test_distributed(model, x, rank, world, options=opt, stats=stats)
+            if rank == 0:
+                out = hip_ops.denorm_clamp(pred[0].contiguous(), 1356 * scale, 2040 * scale, model.rgb_mean, model.rgb_std)
+                del pred
+                watchdog.beat()
+                ref = model.restore(lq, options=opt)[0]
+                assert torch.equal(out, ref), (precision, (out - ref).abs().max().item())
+                assert float(out.std()) > 1e-3 and 'finalized' in stats
+                checked.append(f'c4/{precision}')
+                del out, ref
+            else:
+                assert pred is None
+            watchdog.beat()
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            print('MULTIRANK_OK', world, backend, ' '.join(checked), 'tiles_per_rank',
+                  ','.join(str(len(p)) for p in partition(117, world)), flush=True)
+        dist.barrier()
+        watchdog.stop()
+        dist.destroy_process_group()
+        return
+
     # (1) C4 in small: the 6 tiles of a 339x510 LR image over the ranks, default tile batching (8) and batches of 2
     lq = synthetic_pair(339, 510, scale)[0].to(dev)
     for precision in ('fp32', 'f16'):

@@ -55,6 +55,23 @@ def test_gemm_matches_torch(dev, M, N, K, kn):
     assert (got_relu.cpu().double() - want.clamp(min=0)).abs().max() < 2e-5 * math.sqrt(K)
 
 
+@pytest.mark.parametrize('M,N,K', [(300, 130, 598), (2304, 64, 625), (128, 256, 17), (64, 36, 1190)])
+def test_gemm_kn_ragged_k_ignores_what_lies_behind_b(dev, M, N, K):
+    """B in [k][n] form with K % 16 != 0 (cs_attn's attn.V with L = 598, 625, 1190): the k-tile of the [k][n] image travels in the
+    buffer load's SCALAR offset, which the descriptor's range check does not include, so the rows k >= K of the last k-tile must be
+    masked per lane -- B is a sub-view of a NaN-filled buffer here, and a NaN read there would survive the zeroed A columns."""
+    from ciaosr_amd import hip_ops
+    a = randn((M, K), 21).to(dev)
+    ld = (N + 3) // 4 * 4
+    pool = torch.full((K + 64, ld), float('nan'), device=dev)
+    pool[:K, :N] = randn((K, N), 22).to(dev)
+    b = pool[:K, :N]
+    got = hip_ops.gemm(a, b, b_is_kn=True)
+    want = a.double().cpu() @ b.double().cpu()
+    assert torch.isfinite(got).all()
+    assert (got.cpu().double() - want).abs().max() < 2e-5 * math.sqrt(K)
+
+
 def test_gemm_asymmetric_transpose_detecting(dev):
     """A = I with an asymmetric B catches a row/col swap in the MFMA C-layout."""
     from ciaosr_amd import hip_ops
@@ -222,6 +239,22 @@ def test_csattn_big_map_composed_tail_vs_reference(dev, tag):
     prof3 = hip_ops.profile.results()
     assert 'csa_patch_q' in prof3 and 'csa_key_norms' not in prof3, sorted(prof3)
     assert (y3[0] - want).abs().max().item() < TOL and (y3 - y).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'f16'])
+def test_csattn_never_reads_scratch_it_did_not_write(dev, precision):
+    """67x70 (L = 34 x 35 = 1190: ragged against every k-tile depth, reflect-padded rows): every scratch buffer of the call is
+    filled with NaN bit patterns before the second run.  Same result => no kernel of cs_attn (incl. the softmax-staging attn.V
+    GEMM, whose [k][n] operand sits in the middle of the workspace) reads a byte that this call did not write first."""
+    from ciaosr_amd import hip_ops
+    att, x, want = _csattn_golden('67x70', dev)
+    opt = hip_ops.Options(precision)
+    y0 = att(x, options=opt).clone()
+    hip_ops.poison_workspaces()
+    y1 = att(x, options=opt)
+    assert torch.isfinite(y1).all() and torch.equal(y0, y1)
+    if precision == 'fp32':
+        assert (y1.cpu()[0] - want).abs().max().item() < TOL
 
 
 @pytest.mark.parametrize('tag', ['48', '45x51'])
@@ -741,6 +774,23 @@ def test_e2e_restorer_vs_golden(dev, tag, kind, scale):
     _, gt = synthetic_pair(48, 48, scale)
     d_psnr = abs(psnr_tensors(out, gt, crop_border=scale) - psnr_tensors(ref, gt, crop_border=scale))
     assert d_psnr <= 0.01, d_psnr
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'f16', 'f16-pairs'])
+def test_whole_path_never_reads_scratch_it_did_not_write(dev, precision):
+    """RDN x4 on a ragged 45x51 LR image (nothing divides the tile sizes of any kernel): second run with every scratch buffer of
+    the first filled with NaN bit patterns must be bitwise the first and finite -- trunk, cs_attn, tables, fused head, decode."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32), blocks=3)
+    seeded_init_(model, seed=5, gain=1.5, head_gain=SQRT6)
+    model = model.to(dev)
+    lq = synthetic_pair(45, 51, 4, seed=77)[0].to(dev)
+    opt = hip_ops.Options(precision)
+    y0 = model.restore(lq, options=opt).clone()
+    hip_ops.poison_workspaces()
+    y1 = model.restore(lq, options=opt)
+    assert torch.isfinite(y1).all() and torch.equal(y0, y1) and float(y1.std()) > 1e-3
 
 
 def _tile192_checks(out, fx, tol):

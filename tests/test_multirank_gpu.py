@@ -26,7 +26,7 @@ def gpu():
 
 def _env(**kw):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
-    env.update(CIAOSR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4', **kw)
+    env.update(dict(CIAOSR_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4'), **kw)
     return env
 
 
@@ -47,6 +47,40 @@ def test_child_ranks_tile_and_query_sharding_are_bitwise_the_single_process_resu
         assert case in ok[0], ok[0]
 
 
+def test_c4_at_its_real_shape_eight_ranks_117_tiles(gpu):
+    """BASELINE config C4's shape on the one GPU (exchange over gloo): 8 fresh ranks x the 117 tiles of the LR 1356x2040 image,
+    f16 and fp32 -- rank 0's image bitwise == restore(); 117 = 14 full rounds of 8 + a ragged round of 5 that rank 0 sits out."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'multirank_child.py')]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, cwd=ROOT,
+                         env=_env(CIAOSR_CHILD_CASE='c4', OMP_NUM_THREADS='2'))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    ok = [l for l in out.stdout.splitlines() if l.startswith('MULTIRANK_OK')]
+    assert len(ok) == 1 and ok[0].split()[1] == '8', out.stdout[-1500:]
+    assert 'c4/f16' in ok[0] and 'c4/fp32' in ok[0] and 'tiles_per_rank 14,15,15,15,15,15,14,14' in ok[0], ok[0]
+
+
+def test_bench_eight_ranks_c3_from_a_plain_shell(gpu):
+    """`python bench.py --gpus 8 --workload c3 --precision f16 --steps 1` from a plain shell: the C4 command line, rehearsed on one
+    GPU over gloo; the line carries the N > 1 diagnostics."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--workload', 'c3', '--precision', 'f16', '--steps', '1',
+           '--warmup', '1']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, cwd=ROOT, env=_env(OMP_NUM_THREADS='2'))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['rccl_ranks'] == 8 and d['scaling'] == 'strong'
+    assert d['tiles_per_rank'] == [14, 15, 15, 15, 15, 15, 14, 14] and len(d['rank_ms_per_step']) == 8
+    assert d['p2p_channels'] == 1 and d['step_deadline_s'] > 0 and d['rank0_share']['value'] == 1.0
+    assert 0 <= d['exposed_tail_ms'] < d['ms_per_step']
+    assert d['config']['tiles'] == 117 and d['config']['parallelism'] == 'tile-shard x8'
+
+
 def test_bench_starts_its_own_ranks_from_a_plain_shell(gpu):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver starts N = 1): bench.py spawns its ranks,
     asserts the sharded image bitwise against restore() before timing, and rank 0 prints the one JSON line."""
@@ -57,7 +91,7 @@ def test_bench_starts_its_own_ranks_from_a_plain_shell(gpu):
     assert len(lines) == 1, out.stdout[-1500:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['scaling'] == 'strong' and d['steps'] == 2
-    assert d['tiles_per_rank'] == [3, 3] and len(d['rank_ms_per_step']) == 2
+    assert d['tiles_per_rank'] == [3, 3] and len(d['rank_ms_per_step']) == 2 and d['p2p_channels'] == 1
     assert 0 <= d['exposed_tail_ms'] < d['ms_per_step']
     assert abs(d['value'] - 1356 * 2040 / 1e6 / (d['ms_per_step'] * 1e-3)) < 1e-2 * d['value']
     assert d['config']['parallelism'] == 'tile-shard x2' and d['roofline']['kernel']

@@ -35,7 +35,7 @@ def _tile_fn_factory(fx):
     return tile_fn, tuple(x.shape)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, rank0_share=1.0):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -43,7 +43,10 @@ def _worker(rank, world, port, ret):
     from ciaosr_amd.tile_shard import sharded_clip_test
     fx = load_golden('tiling_small')
     tile_fn, shape = _tile_fn_factory(fx)
-    out = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, rank, world)
+    marks = []
+    out = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, rank, world, mark=marks.append,
+                            rank0_share=rank0_share)
+    assert marks[0] == 'start' and 'last_own_tile' in marks and (rank != 0 or marks[-1] == 'finalized')
     if rank == 0:
         ret['out'] = out
     else:
@@ -68,12 +71,69 @@ def test_two_rank_gloo_equals_single_process_bitwise():
     assert (img - torch.from_numpy(fx['out'])).abs().max() < 5e-5
 
 
+@pytest.mark.slow
+@pytest.mark.parametrize('world,share', [(3, 1.0), (3, 0.5), (4, 0.0)])
+def test_ragged_rounds_and_lighter_rank0_shares_are_bitwise_the_single_process_result(world, share):
+    """12 tiles: 3 ranks = 4 full rounds; share 0.5 = rank 0 sits out every second round; 4 ranks with share 0 = rank 0 only
+    receives, blends and finalizes (rounds of 3, ragged nowhere).  Always the reference blend order => bitwise."""
+    from ciaosr_amd.tile_shard import sharded_clip_test, partition
+    fx = load_golden('tiling_small')
+    tile_fn, shape = _tile_fn_factory(fx)
+    single = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29597 + world, ret, share), nprocs=world, join=True)
+    assert torch.equal(ret['out'], single)
+    assert len(partition(12, world, share)[0]) == {(3, 1.0): 4, (3, 0.5): 2, (4, 0.0): 0}[(world, share)]
+
+
 def test_partition_covers_every_tile_once():
-    from ciaosr_amd.tile_shard import partition
-    for n, w in ((117, 8), (117, 2), (6, 4), (1, 8), (22, 8)):
+    from ciaosr_amd.tile_shard import partition, tile_owners
+    for n, w in ((117, 8), (117, 2), (117, 4), (6, 4), (1, 8), (22, 8), (5, 8)):
         parts = partition(n, w)
         assert sorted(t for p in parts for t in p) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+        owners = tile_owners(n, w)
+        full = n - n % w if n >= w else 0
+        assert owners[:full] == [t % w for t in range(full)]             # full rounds: t -> rank t % R
+    # C4: 117 tiles on 8 ranks = 14 full rounds + a ragged round of 5 that rank 0 (every blend + the finalize are its) sits out
+    assert [len(p) for p in partition(117, 8)] == [14, 15, 15, 15, 15, 15, 14, 14]
+    assert tile_owners(117, 8)[112:] == [1, 2, 3, 4, 5]
+    assert [len(p) for p in partition(117, 2)] == [58, 59] and [len(p) for p in partition(117, 4)] == [29, 30, 29, 29]
+    assert partition(1, 8)[0] == [0]                                      # a single round is never skipped
+    # lighter shares: still a partition, rank 0 first in the rounds it joins, evenly spaced
+    for share, n0 in ((0.5, 8), (0.25, 4), (0.0, 0)):
+        parts = partition(117, 8, share)
+        assert sorted(t for p in parts for t in p) == list(range(117)) and len(parts[0]) == n0
+    assert partition(64, 8, 0.5)[0] == [0, 15, 30, 45]
+
+
+def _hung_peer_worker(rank, world, port):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ciaosr_amd.tile_shard import StepDeadline, ensure_communicator, _Mover
+    ensure_communicator(None, None)
+    watchdog = StepDeadline(2.0, what='step', rank=rank)
+    watchdog.beat()
+    if rank == 0:
+        mover = _Mover(None, None)
+        batch = mover.recv_many((1, 4, 3), [1], 'cpu')
+        mover.take(batch, 0, 'cpu')              # rank 1 never sends: without the deadline this waits for the 30-min gloo timeout
+    else:
+        import time
+        time.sleep(20)
+        os._exit(0)
+
+
+def test_step_deadline_ends_a_rank_whose_peer_never_delivers():
+    """A lost peer must end the job, not hang it: the waiting rank leaves with exit code 3 once its step is past the deadline."""
+    import time
+    t0 = time.time()
+    with pytest.raises(Exception) as err:
+        mp.spawn(_hung_peer_worker, args=(2, 29611), nprocs=2, join=True)
+    assert 'exit code 3' in str(err.value), str(err.value)
+    assert time.time() - t0 < 18
 
 
 def test_query_slices_cover_the_range_and_respect_chunks():

@@ -38,6 +38,8 @@ def self_launch(argv):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('NCCL_MIN_P2P_NCHANNELS', '1')       # tile_shard.rccl_env_defaults (torch is not imported yet here)
+    env.setdefault('NCCL_MAX_P2P_NCHANNELS', '1')
     env.setdefault('OMP_NUM_THREADS', '4')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
@@ -87,7 +89,7 @@ def main(argv=None):
     from ciaosr_amd.checkpoint import load_checkpoint
     from ciaosr_amd.config import Config
     from ciaosr_amd.dataset import SRFolderDataset
-    from ciaosr_amd.tile_shard import clip_test_distributed
+    from ciaosr_amd.tile_shard import StepDeadline, clip_test_distributed, rccl_env_defaults
 
     cfg = Config.fromfile(args.config)
     if args.checkpoint in (None, 'None'):
@@ -99,7 +101,13 @@ def main(argv=None):
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', args.local_rank)) % max(torch.cuda.device_count(), 1))
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # CIAOSR_DIST_BACKEND=gloo: rehearse the N-rank path on fewer GPUs than ranks (host-staged copies)
-        dist.init_process_group(os.environ.get('CIAOSR_DIST_BACKEND') or cfg.get('dist_params', {}).get('backend', 'nccl'))
+        import datetime
+        backend = os.environ.get('CIAOSR_DIST_BACKEND') or cfg.get('dist_params', {}).get('backend', 'nccl')
+        rccl_env_defaults()
+        deadline_s = float(os.environ.get('CIAOSR_STEP_DEADLINE_S', '900'))          # per image; a lost peer ends the job, not hangs it
+        kw = dict(device_id=torch.device('cuda', torch.cuda.current_device())) if backend == 'nccl' else {}
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=max(deadline_s, 60.0)), **kw)
+        watchdog = StepDeadline(deadline_s, what='image', rank=rank)
     if args.seed is not None:
         torch.manual_seed(args.seed)
     dev = torch.device('cuda', torch.cuda.current_device())
@@ -114,6 +122,8 @@ def main(argv=None):
 
     results = []
     for i in range(len(dataset)):
+        if distributed:
+            watchdog.beat()
         d = dataset[i]
         lq, gt = d['lq'].unsqueeze(0).to(dev), d['gt'].unsqueeze(0).to(dev)
         coord, cell = d['coord'].unsqueeze(0).to(dev), d['cell'].unsqueeze(0).to(dev)
@@ -154,7 +164,9 @@ def main(argv=None):
             with open(args.out, 'wb') as f:
                 pickle.dump(results, f)
     if distributed:
+        watchdog.beat()
         dist.barrier()
+        watchdog.stop()
         dist.destroy_process_group()
     return results
 
