@@ -84,6 +84,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     the exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query.  Kernels that reach the
     same result with fewer multiplies (Winograd, box sum) are priced on the reference's form here; `executed_ratio` gives the
     flops their MFMAs actually execute, so that a fraction above 1 never stands alone."""
+    if tag.endswith('_f16x3'):             # both operands as half pairs: the same algorithmic work, three MFMAs per product
+        tag = tag[:-6] + '_bf16'
     if tag.endswith('_f16'):               # IEEE-half kernels: the bf16 kernels' work and peak (same MFMA rate)
         tag = tag[:-4] + '_bf16'
     D, Dv, R = 9 * C, 10 * C, Q * J
@@ -138,6 +140,8 @@ def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     dense_wino_f32.hip); the fp32 correlation scores are a 3x3 diagonal box sum of a K = C/2 per-pixel correlation whose D blocks
     of (8+2)x(16+2) query-halo x (4+2)x(16+2) key-halo pixels are computed as 6 x 4 MFMA tiles of 32x32 per 8x16 x 4x16 item
     (csa_scores_f32.hip); hi + lo weight pairs issue two MFMAs per product (bf16 pairs, f16-pairs), activation pairs three."""
+    if tag.endswith('_f16x3'):
+        return 3.0
     base = tag[:-5] if tag.endswith('_bf16') else (tag[:-4] if tag.endswith('_f16') else tag)
     half = base != tag
     if not half:
@@ -149,8 +153,6 @@ def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
             return items * 2.0 * 192 * 128 * (C / 2) / (2.0 * HW * (HW / 4) * 4.5 * C)
         return 1.0
     if base in ('head_kv_fused', 'head_decode_fused', 'enc_dense'):
-        if precision == 'f16x3':
-            return 3.0
         if precision == 'f16-pairs' or (precision == 'bf16' and not bf16_single):
             return 2.0
     return 1.0
@@ -317,10 +319,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
-                         'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product): the fp32-tolerance fast mode')
+                         'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product); f16x3: the fp32-tolerance '
+                         'fast mode -- head weights AND activations as half pairs (three MFMAs per product), fp32 trunk and tables')
     ap.add_argument('--tile-batch', type=int, default=0, help='developer: test_cfg.tile_batch (0 = the default 8)')
     ap.add_argument('--encoder-ahead', action='store_true', help='test_cfg.encoder_ahead: trunk of the next tile batch on a side stream under the heads of the current one (bitwise the same image; per-kernel timings then overlap)')
     ap.add_argument('--bf16-single', action='store_true',
@@ -585,6 +588,7 @@ def main():
             'dtype': 'f32' if args.precision == 'fp32' else (
                 'f16 (IEEE half) MFMA inputs, saturating conversions, fp32 accumulate, in the head, the dense layers and the cs_attn contractions'
                 + ('; weights as half hi+lo pairs' if args.precision == 'f16-pairs' else '')
+                + ('; head weights and activations as half hi+lo pairs (three MFMAs per product), fp32 trunk' if args.precision == 'f16x3' else '')
                 if args.precision.startswith('f16') else
                 'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
                 + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),

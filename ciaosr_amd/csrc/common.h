@@ -55,6 +55,16 @@ static inline bool allow_big_lds(LdsAttrOnce& once, K kernel, size_t bytes) {
 
 int launch_status(const char* what);
 
+// ciaosr_options_t hygiene, checked by every entry point that takes one: the reserved words must be 0 (a caller built against a
+// later, longer layout -- or passing garbage -- is refused instead of being half-understood) and the enumerated fields in range.
+static inline bool options_ok(const ciaosr_options_t* o) {
+    if (!o) return true;
+    return o->reserved[0] == 0 && o->reserved[1] == 0 && (o->head_route & ~7) == 0 && (o->kv_rows == 0 || o->kv_rows == 32 || o->kv_rows == 64) &&
+           (o->decode_rows == 0 || o->decode_rows == 32 || o->decode_rows == 64) && (o->bf16_single == 0 || o->bf16_single == 1) &&
+           (o->dense_direct == 0 || o->dense_direct == 1) && (o->csa_scores_gemm == 0 || o->csa_scores_gemm == 1) &&
+           o->f16_pairs >= 0 && o->f16_pairs <= 2;
+}
+
 }  // namespace ciaosr
 
 // one-time (per device) > 64 KiB LDS opt-in for `kernel`; returns CIAOSR_ERR_LAUNCH from the enclosing function on failure

@@ -69,6 +69,7 @@ extern "C" size_t ciaosr_cs_attn_workspace_bytes_scale(int H, int W, int C, int 
 static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaosr_csattn_weights_t* w, float* out, int ld_out,
                    const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, Prec prec) {
     CIAOSR_CHECK_ARG(feat_hwc && w && out && workspace && H >= 2 && W >= 2);
+    CIAOSR_CHECK_ARG(options_ok(opt));
     const int C = w->channels;
     const int sc = w->scale ? w->scale : 2;
     CIAOSR_CHECK_ARG(C >= 4 && (C & 3) == 0 && ld_feat >= C && (ld_feat & 3) == 0 && (ld_out & 3) == 0);
@@ -139,7 +140,9 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
         RUN(h.cast_rows(Kn, Kq, Kb, Kq, p.L, Kq, s));
         // probabilities straight from the contraction (two passes over the short-K GEMM, no fp32 logit matrix, no softmax kernel);
         // the logits buffer serves as the statistics scratch
-        if (h.softmax_gemm_scratch(HWp, p.L) <= p.n_S) {
+        // (the fused form takes its pass-1 maximum on the raw accumulators, which needs a positive scale; a non-positive
+        // softmax_scale -- no config has one -- takes the logits + softmax_rows route instead of being refused)
+        if (h.softmax_gemm_scratch(HWp, p.L) <= p.n_S && w->softmax_scale > 0.f) {
             RUN(h.softmax_gemm_nt(Qb, Kq, Kb, Kq, P16, p.Lld8, HWp, p.L, Kq, w->softmax_scale, S, p.n_S, s,
                                   f16 ? "csa_scores_f16" : "csa_scores_bf16"));
         } else {

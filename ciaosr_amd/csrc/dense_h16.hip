@@ -511,13 +511,19 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
     CIAOSR_BIG_LDS(dense_h16_kernel<false>, kDenseLds);
     CIAOSR_BIG_LDS(dense_h16_dma_kernel, kDense2Lds);
     ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
-    static const int variant = getenv("CIAOSR_DENSE_V") ? atoi(getenv("CIAOSR_DENSE_V")) : 2;     // developer A/B: 1 = the round-2 kernel
+    // no process-global switches in the product library: the developer A/B knobs exist in the CIAOSR_PROBE build only
+#ifdef CIAOSR_PROBE
+    static const int variant = getenv("CIAOSR_DENSE_V") ? atoi(getenv("CIAOSR_DENSE_V")) : 2;     // 1 = the round-2 kernel
+    static const int slices_env = getenv("CIAOSR_DENSE_SLICES") ? atoi(getenv("CIAOSR_DENSE_SLICES")) : 2;
+    const int slices = slices_env < 1 ? 1 : slices_env;
+#else
+    constexpr int variant = 2, slices = 2;
+#endif
     if (p.wf_lo)
         hipLaunchKernelGGL(dense_h16_kernel<true>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     else if (variant == 1 || n_img < 2)      // one image = 256 workgroups on 256 CUs: nothing to pair up, the deeper pipeline of the first kernel wins (2.74 vs 2.96 ms)
         hipLaunchKernelGGL(dense_h16_kernel<false>, dim3(dense_h16_tiles(H, W)), dim3(256), kDenseLds, s, p);
     else {   // two workgroups per CU; a batch is cut into image slices so that both slots of every CU are filled
-        static const int slices = getenv("CIAOSR_DENSE_SLICES") ? atoi(getenv("CIAOSR_DENSE_SLICES")) : 2;
         hipLaunchKernelGGL(dense_h16_dma_kernel, dim3(dense_h16_tiles(H, W), n_img < slices ? n_img : slices), dim3(256), kDense2Lds, s, p);
     }
     return launch_status("dense" CIAOSR_H16_SUFFIX);

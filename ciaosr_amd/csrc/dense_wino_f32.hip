@@ -341,7 +341,11 @@ int dense_layer_wino_f32(float* X, int ldx, int H, int W, int l, const float* fr
 // (the logit table of the fused head: Pi_o = F . shift_o(F), head.hip).  Pi: [9][H*W][64]; frag_wino: 16 arrays of the transformed
 // [64 n_blk][64] weights in fragment order.
 int wino_table_f32(const float* Pi, int H, int W, const float* frag_wino, int n_blk, float* out, int ldg, hipStream_t s) {
+#ifdef CIAOSR_PROBE       // developer A/B only: the product library reads no environment
     static const int per_wg = [] { const char* e = getenv("CIAOSR_TABLE_BLK"); const int v = e ? atoi(e) : 4; return v == 1 || v == 2 ? v : 4; }();
+#else
+    constexpr int per_wg = 4;
+#endif
     CIAOSR_CHECK_ARG(Pi && frag_wino && out && n_blk >= 1 && (ldg & 3) == 0 && aligned16(Pi) && aligned16(frag_wino) && aligned16(out));
     const size_t in_bytes = (size_t)9 * H * W * 64 * 4;
     CIAOSR_CHECK_ARG(in_bytes < 0xFFFFFF00ull);

@@ -82,12 +82,17 @@ extern "C" size_t ciaosr_rdn_workspace_bytes(int H, int W, const ciaosr_rdn_weig
 // blocks run per image.  Each image is computed by exactly the workgroups, in exactly the order, of a single-image call: bitwise equal.
 static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rdn_weights_t* w, float* feat_hwc,
                        const ciaosr_options_t* opt, void* workspace, size_t workspace_bytes, void* stream_, Prec prec) {
+    // f16_pairs = 2 ("f16x3", the fp32-tolerance fast mode): the trunk runs its fp32 route -- half ACTIVATIONS in 128 dense layers
+    // alone cost rms 4.6e-5 / max 4e-4 on the full C3 tile, and activation pairs (three MFMAs per product + a second patch) would
+    // cost the dense layers about what the fp32 Winograd form does
+    if (prec == kF16 && opt && opt->f16_pairs == 2) prec = kF32;
     const bool bf16 = prec != kF32;      // a 16-bit MFMA mode (bf16 or f16 entry)
     // route thresholds (per-call options; defaults: halo-resident dense layers from 128 tiles of 12x12 pixels on, small-map
     // kernels up to 18432 pixels = 128 such tiles)
     const int min_tiles = opt && opt->dense_min_tiles ? opt->dense_min_tiles : 128;
     const int small_max = opt && opt->scatter_small_max ? opt->scatter_small_max : 18432;
     CIAOSR_CHECK_ARG(x_nchw && w && feat_hwc && workspace && B >= 1 && H > 0 && W > 0);
+    CIAOSR_CHECK_ARG(options_ok(opt));
     const int C = w->mid_channels, G = w->growth, NB = w->num_blocks, NL = w->num_layers;
     CIAOSR_CHECK_ARG(C % 32 == 0 && G % 32 == 0 && NB >= 1 && NL >= 1 && w->dense && w->lff);
     CIAOSR_CHECK_ARG(C == G);   // mmedit's RDN feeds rdbs[b>0] with channel_growth channels and adds sfe1 (mid) at the end

@@ -131,7 +131,10 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     const int route = opt ? opt->head_route : 0;
     // hi + lo weight pairs: the bf16 entry unless single is asked for, the f16 entry when pairs are asked for
     const bool lo = (prec == kBF16 && !(opt && opt->bf16_single)) || (prec == kF16 && opt && opt->f16_pairs);
+    // f16_pairs = 2 ("f16x3"): the activations of the three MLP chains as half pairs too (head_fused_x3.hip), every table in fp32
+    const bool x3 = prec == kF16 && opt && opt->f16_pairs == 2;
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
+    CIAOSR_CHECK_ARG(options_ok(opt));
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
     CIAOSR_CHECK_ARG(w->local_size >= 1 && w->local_size <= 3 && w->softmax_scale != 0.f);
     CIAOSR_CHECK_ARG(mlp_ok(w->q) && mlp_ok(w->k) && mlp_ok(w->v));
@@ -187,6 +190,11 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     const bool fused = !(route & CIAOSR_HEAD_STAGED) && w->local_size == 2 && chain_fused_ok(w->k, false, bf16) &&
                        chain_fused_ok(w->v, false, bf16) && chain_fused_ok(w->q, true, bf16) && (p.Dv & 7) == 0;
     if (bf16 && !fused) return CIAOSR_ERR_UNSUPPORTED;   // the 16-bit modes exist for the fused kernels only
+    if (x3) {                                            // the pair kernels read every lo fragment unconditionally
+        for (int i = 1; i < w->k.n_layers; ++i) CIAOSR_CHECK_ARG(w->k.frag16_lo[i]);
+        for (int i = 1; i < w->v.n_layers; ++i) CIAOSR_CHECK_ARG(w->v.frag16_lo[i]);
+        for (int i = 0; i + 1 < w->q.n_layers; ++i) CIAOSR_CHECK_ARG(w->q.frag16_lo[i]);
+    }
     // exact layer-1 hoist: T = U . W1[:, :fan]^T + b1, one row per LR pixel
     // f16 mode: on the 16-bit GEMM from a half copy of U (the staged route's activation buffers are free on the fused route)
     const size_t u16_bytes = (size_t)p.HW * p.Dv * 2 + 256, w16_bytes = (size_t)(p.wk0 + p.wv0) * p.Dv * 2 + 512;
@@ -221,11 +229,11 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         const long total = (long)p.HW * 9;
         // 16-bit modes: the table GEMM on the 16-bit MFMA (fp32 table out).  (Half-pairs mode: the exact-fp32 GEMM here was measured
         // and changes nothing -- max |delta| 1.04e-3 -> 1.14e-3 on the full-tile vector, +0.9 ms: W5's rounding is not what limits it.)
-        const bool table16 = bf16 && (p.D & 7) == 0;
+        const bool table16 = bf16 && !x3 && (p.D & 7) == 0;
         if (table16) RUN(transpose_cast_h16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, prec == kF16, s));
         // fp32, C = 64: nine Winograd convolutions of the product maps Pi_o = F . shift_o(F) (same sums as the GEMM rows below,
         // re-associated through the transform; 20x fewer multiplies).  The maps live where the GEMM would keep its row chunk.
-        const bool table_wino = prec == kF32 && w->k_out_wino && !(route & CIAOSR_HEAD_TABLE_GEMM) && p.C == 64 && !w->no_unfold &&
+        const bool table_wino = (prec == kF32 || x3) && w->k_out_wino && !(route & CIAOSR_HEAD_TABLE_GEMM) && p.C == 64 && !w->no_unfold &&
                                 p.HW >= 512 && p.HW <= kQkChunk;
         if (table_wino) {
             RUN(qk_maps(feat_hwc, p.C, p.C, H, W, QK, s));
@@ -260,7 +268,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             kp.Z = Z; kp.ldz = p.Dv;
             kp.rows_per_wg = opt ? opt->kv_rows : 0;
             kp.G = use_table ? G : nullptr; kp.ldg = kLdG; kp.g_bytes = (unsigned)((size_t)p.HW * 9 * kLdG * sizeof(float));
-            RUN(bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
+            RUN(x3 ? x3::head_kv_fused_x3(kp, s) : bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;
             qp.Z = Z; qp.ldz = p.Dv; qp.Dv = p.Dv;
@@ -277,7 +285,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             qp.b_last = mq.bias[mq.n_layers - 1];
             qp.rows_per_wg = opt ? opt->decode_rows : 0;
             qp.x_lr = x_lr_nchw; qp.coord = coord; qp.q0 = q0; qp.nq = nq; qp.H = H; qp.W = W; qp.rgb = rgb;
-            RUN(bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
+            RUN(x3 ? x3::head_decode_fused_x3(qp, s) : bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
             continue;
         }
         HeadRowsP hp;

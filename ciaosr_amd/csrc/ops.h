@@ -188,6 +188,12 @@ namespace b16 { CIAOSR_H16_DECLS }
 namespace f16 { CIAOSR_H16_DECLS }
 #undef CIAOSR_H16_DECLS
 
+// head_fused_x3.hip: the fused head with both MFMA operands as half hi + lo pairs (three MFMAs per product; Z in fp32)
+namespace x3 {
+int head_kv_fused_x3(const FusedKVP& p, hipStream_t s);
+int head_decode_fused_x3(const FusedQP& p, hipStream_t s);
+}
+
 // precision of an entry point: the suffix of its name
 enum Prec { kF32 = 0, kBF16 = 1, kF16 = 2 };
 struct H16Ops {

@@ -187,7 +187,7 @@ def tile_finalize(E, Wt):
     return out
 
 
-PRECISIONS = ('fp32', 'bf16', 'f16', 'f16-pairs')       # what Options(precision) / test_cfg.precision accept
+PRECISIONS = ('fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3')       # what Options(precision) / test_cfg.precision accept
 
 
 class Options:
@@ -195,8 +195,9 @@ class Options:
 
     precision  'fp32' (exact-fp32 MFMA, the contract precision), 'bf16' (bf16 MFMA inputs, fp32 accumulation; weights as
                hi + lo pairs unless bf16_single), 'f16' (IEEE half MFMA inputs, one MFMA per product, saturating at 65504)
-               or 'f16-pairs' (= 'f16' with f16_pairs=1: half activations, every weight as a half hi + lo pair):
-               selects the _f32 / _bf16 / _f16 entry point of the C ABI.
+               'f16-pairs' (= 'f16' with f16_pairs=1: half activations, every weight as a half hi + lo pair) or 'f16x3'
+               (= 'f16' with f16_pairs=2, the fp32-tolerance fast mode: the head's weights AND activations as half pairs, three
+               MFMAs per product, fp32 trunk and tables, half cs_attn contractions): selects the _f32 / _bf16 / _f16 entry point.
     the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
     Immutable; `replace()` returns a modified copy."""
     _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'dense_direct', 'csa_scores_gemm', 'f16_pairs')
@@ -206,6 +207,9 @@ class Options:
         if precision in ('f16-pairs', 'f16_pairs', 'f16p'):      # the fp32-tolerance fast mode: half activations, half weight PAIRS
             precision = 'f16'
             kw.setdefault('f16_pairs', 1)
+        if precision in ('f16x3', 'f16-x3'):                     # ... with the activations of the MLP chains as pairs too
+            precision = 'f16'
+            kw.setdefault('f16_pairs', 2)
         object.__setattr__(self, 'precision', {'fp32': 'fp32', 'f32': 'fp32', 'bf16': 'bf16', 'f16': 'f16', 'fp16': 'f16', 'half': 'f16'}[precision])
         for f in self._C_FIELDS:
             object.__setattr__(self, f, int(kw.pop(f, 0)))

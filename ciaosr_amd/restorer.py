@@ -213,6 +213,7 @@ class CiaoSR(BasicRestorer):
         per-tile order: the image is bitwise the default path's."""
         gen = self.generator
         opt = self.options(options)
+        gen._require_hip_trunk(img_lq)                       # an uncovered trunk raises CiaoSRHipError here, not a C-level argument error
         enc = gen._encoder_hip
         dev = img_lq.device
         cur = torch.cuda.current_stream(dev)
@@ -337,7 +338,14 @@ class CiaoSR(BasicRestorer):
         # longer (take_workspaces removes them from hip_ops' cache: a later eager call on a stream that re-uses the handle gets
         # fresh scratch, and dropping `run` frees the memory).  Weights must not change after capture (a repack would be
         # invisible to the captured launches).
-        keep = (hip_ops.take_workspaces(side), dict(hip_ops._coord_cache),
+        # With test_cfg.tile_streams > 1 or test_cfg.encoder_ahead the captured launches also point into the scratch of the restorer's
+        # cached side streams: those buffers are taken too (a later, larger eager call on such a stream would otherwise re-grow -- i.e.
+        # free -- a buffer the graph still reads and writes).
+        scratch = hip_ops.take_workspaces(side)
+        for streams in self.__dict__.get('_tile_stream_cache', {}).values():
+            for st in streams:
+                scratch.update(hip_ops.take_workspaces(st))
+        keep = (scratch, dict(hip_ops._coord_cache),
                 [getattr(m, '_packed', None) for m in self.modules()],
                 [(getattr(o, '_st', None), getattr(o, '_keep', None), getattr(o, '_mask_keep', None),
                   getattr(o, '_st_f16', None), getattr(o, '_keep_f16', None))

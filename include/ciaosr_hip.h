@@ -85,11 +85,15 @@ typedef struct ciaosr_options {
                              * 1 = the direct halo-resident kernel (exact fmaf chains, 2.8x the MFMA cycles) */
     int csa_scores_gemm;    /* _f32 cs_attn with 32 match channels: 0 (default) = correlation scores as a 3x3 diagonal box sum of the
                              * per-pixel correlation (K = 32, no patch rows); 1 = the 288-wide patch-row GEMM.  Same fp32 products, other order */
-    int reserved[2];        /* must be 0 */
+    int reserved[2];        /* must be 0 (checked by every entry point that takes the struct: a non-zero word is CIAOSR_ERR_BAD_ARG) */
     int f16_pairs;          /* _f16 entries: 0 (default) = one IEEE-half weight per product; 1 = every dense-layer / head weight enters
                              * the MFMA as a half PAIR hi + lo (hi = half(w), lo = half(w - hi): ~20 mantissa bits, two MFMAs per product)
                              * and the layers the plain f16 mode runs with single 16-bit weights elsewhere (RDB local feature fusion,
-                             * layer-0 tables) take the fp32 route of the bf16 mode: the "fp32-tolerance" fast mode (activations stay half) */
+                             * layer-0 tables) take the fp32 route of the bf16 mode (activations stay half: max |delta| 1.04e-3 on the
+                             * full C3 tile, 4 % outside the fp32 tolerance);
+                             * 2 = "f16x3", the fp32-tolerance fast mode: the ACTIVATIONS of the three MLP chains are half pairs too
+                             * (w_hi a_hi + w_lo a_hi + w_hi a_lo: three MFMAs per product, head_fused_x3.hip), Z travels in fp32, the
+                             * layer-0 and logit tables and the whole RDN trunk take their _f32 routes, cs_attn's contractions stay half */
 } ciaosr_options_t;
 
 /* ---- layout plumbing -------------------------------------------------------------------- */
