@@ -20,6 +20,14 @@
 //   * per 8-channel step a wave reads the 2 x 4 window pixels its row needs (8 ds_read_b128), forms its four transformed values
 //     with 32 additions, and issues 16 MFMAs against 4 pre-packed 1-KB weight fragments from L2 (the transformed weights
 //     U[p] = (G g G^T)[p] as 16 separate [64][cin] matrices in ciaosr_pack_fragments_f32 order).
+//
+// Round 4, measured and NOT kept: 4 waves per workgroup (one per SIMD), each owning BOTH channel halves of its transformed row (8
+// accumulator tiles), so that the input transform is computed once per row instead of by both channel-half waves (1.3 instead of 2.6
+// VALU per MFMA).  Correct (same tests), no spills (256 VGPR + 133 AGPR), and SLOWER on the same box: enc_dense_wino 753 -> 783 ms per
+// C3 step, logit table 61.5 -> 63.8.  It is what tools/ubench/mfma_valu.hip predicts: with ONE wave per SIMD a VALU instruction beside
+// an fp32 MFMA costs ~20 cycles of the pipe (64 -> 84 at one per MFMA), with two waves ~6 (64 -> 70): 1.3 VALU per MFMA alone on a
+// SIMD is ~86 cycles per MFMA, 2.6 shared by two waves ~81.  Halving the VALU work only pays with two waves per SIMD, and two waves
+// of 8 accumulator tiles + a weight ring do not fit 256 registers each.
 #include <cstdlib>
 
 #include "ops.h"

@@ -24,6 +24,13 @@ namespace x3 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/head_probe.py 192 f16x3): cycle stamps of workgroup phases
+__device__ unsigned long long g_xprobe[4096 * 16];
+#define XPROBE(slot) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_xprobe[blockIdx.x * 16 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XPROBE(slot) do { } while (0)
+#endif
+
 constexpr int XBM = 128;           // rows per workgroup = 32 queries x 4 key samples (decode: 128 queries)
 constexpr int XMI = XBM / 32;      // 32-row MFMA tiles
 constexpr int XH = 256;            // hidden width
@@ -49,13 +56,28 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
     const float floor_ = RELU ? 0.f : -kHalfMax;
     const f32x2_t v = {__builtin_amdgcn_fmed3f(a, floor_, kHalfMax), __builtin_amdgcn_fmed3f(b, floor_, kHalfMax)};
     const f16x2_t h = __builtin_convertvector(v, f16x2_t);
-    const f32x2_t r = {v.x - (float)h.x, v.y - (float)h.y};          // exact in fp32
+    // residual x - hi (exact in fp32) as ONE v_fma_mix_f32 per element (fma of the half operand, taken straight from its half of the
+    // packed register, with -1.0 and the fp32 x) instead of a convert and a subtract: 6 VALU per pair instead of 8 in an epilogue that
+    // no MFMA covers (hipcc folds the fma(x, -1, y) form back into cvt + sub, hence the asm)
+    const unsigned hp = __builtin_bit_cast(unsigned, h);
+    f32x2_t r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r.x) : "v"(hp), "v"(v.x));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r.y) : "v"(hp), "v"(v.y));
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2_t));
 }
 // hi + lo of packed element 0 / 1 back to fp32
-__device__ __forceinline__ float pair0(unsigned hi, unsigned lo) { return h16_lo<true>(hi) + h16_lo<true>(lo); }
-__device__ __forceinline__ float pair1(unsigned hi, unsigned lo) { return h16_hi<true>(hi) + h16_hi<true>(lo); }
+// (one v_fma_mix_f32 each: hi * 1.0 + lo with both half operands read from their packed registers)
+__device__ __forceinline__ float pair0(unsigned hi, unsigned lo) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi), "v"(lo));
+    return r;
+}
+__device__ __forceinline__ float pair1(unsigned hi, unsigned lo) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi), "v"(lo));
+    return r;
+}
 
 __device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) { return mfma_h16<true>(a, b, c); }
 
@@ -189,6 +211,7 @@ __global__ __launch_bounds__(XNT) void head_kv_fused_x3_kernel(FusedKVP p) {
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (XBM / 4);
 
+    XPROBE(0);
     // ---- index math: row m = 32 j + q (exactly head_fused_h16.hip's) ----------------------------------------------
     int bad = 0;
     if (t < XBM) {
@@ -225,9 +248,15 @@ __global__ __launch_bounds__(XNT) void head_kv_fused_x3_kernel(FusedKVP p) {
     const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, p.u_bytes, 0x00020000);
 
     // ================= phi_k =====================================================================
+    XPROBE(1);
     build_rows_x3(Xh, Xl, p.k, s_kpix, s_t4, t);
-    for (int l = 0; l < p.k.n_hidden; ++l) hidden_layer_x3(Xh, Xl, p.k.frag_hidden[l], p.k.frag_hidden_lo[l], p.k.bias_hidden[l], w, lane);
+    XPROBE(2);
+    for (int l = 0; l < p.k.n_hidden; ++l) {
+        hidden_layer_x3(Xh, Xl, p.k.frag_hidden[l], p.k.frag_hidden_lo[l], p.k.bias_hidden[l], w, lane);
+        if (l < 3) XPROBE(10 + l);
+    }
     __syncthreads();
+    XPROBE(3);
     if (table) {
         // logit = h4 . G[query pixel, key offset] + c (fp32 table, hi + lo activations): 4 threads per row, 16 gathers in flight
         const int row = t >> 2, part = t & 3;
@@ -314,9 +343,15 @@ __global__ __launch_bounds__(XNT) void head_kv_fused_x3_kernel(FusedKVP p) {
     }
 
     // ================= phi_v =====================================================================
+    XPROBE(4);
     build_rows_x3(Xh, Xl, p.v, s_kpix, s_t4, t);          // every wave is past its logit reads of X (barrier above)
-    for (int l = 0; l < p.v.n_hidden; ++l) hidden_layer_x3(Xh, Xl, p.v.frag_hidden[l], p.v.frag_hidden_lo[l], p.v.bias_hidden[l], w, lane);
+    XPROBE(5);
+    for (int l = 0; l < p.v.n_hidden; ++l) {
+        hidden_layer_x3(Xh, Xl, p.v.frag_hidden[l], p.v.frag_hidden_lo[l], p.v.bias_hidden[l], w, lane);
+        if (l < 3) XPROBE(13 + l);
+    }
     __syncthreads();
+    XPROBE(6);
     {
         const int n_units = (p.v.n_out + 31) >> 5;
         const __amdgpu_buffer_rsrc_t rs_bv =
@@ -368,6 +403,13 @@ __global__ __launch_bounds__(XNT) void head_kv_fused_x3_kernel(FusedKVP p) {
             }
         }
     }
+    XPROBE(7);
+#ifdef CIAOSR_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_xprobe[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_getreg(63492);    // HW_REG_HW_ID
+        g_xprobe[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_getreg(63508);    // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -554,3 +596,9 @@ int head_decode_fused_x3(const FusedQP& p, hipStream_t s) {
 
 }  // namespace x3
 }  // namespace ciaosr
+
+#ifdef CIAOSR_PROBE
+extern "C" int ciaosr_debug_probe_x3_read(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::x3::g_xprobe), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif

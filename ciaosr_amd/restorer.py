@@ -128,6 +128,8 @@ class CiaoSR(BasicRestorer):
         The tile loop runs tiles on several streams: nothing a tile reads may be first built on another tile's stream."""
         opt = self.options(options)
         gen = self.generator
+        if hasattr(gen, 'effective_options'):
+            opt = gen.effective_options(opt)
         head = getattr(gen, '_head', None)
         if head is not None:
             head.struct(opt.half)

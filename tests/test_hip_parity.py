@@ -1127,14 +1127,16 @@ def test_swinir_e2e_vs_golden(dev, precision):
     from tests.test_host_logic import _swinir_ciaosr
     fx = load_golden('swinir_c5')
     model = _swinir_ciaosr(dict(scale=3.3))
-    assert seeded_init_(model, seed=int(fx['weight_seed']), gain=1.0, head_gain=SQRT6) == str(fx['sha'])
+    assert seeded_init_(model, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=SQRT6) == str(fx['sha'])
     model = model.to(dev)
     ht, wt = [int(v) for v in fx['target']]
     coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
     model.test_cfg['precision'] = precision
     with hip_ops.profile():
         out = model(lq=_t(fx['lq']).to(dev), gt=None, test_mode=True, coord=coord, cell=cell)['output']
-    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_bf16', 'f16': 'head_kv_fused_f16'}[precision] in hip_ops.profile.results()
+    # precision='bf16' on the SwinIR head runs the f16 kernels (LocalImplicitSRSWINIR.effective_options)
+    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_f16', 'f16': 'head_kv_fused_f16'}[precision] in hip_ops.profile.results()
+    assert 'head_kv_fused_bf16' not in hip_ops.profile.results()
     ref = _t(fx['out'])
     err = (out - ref).abs().max().item()
     _, gt = synthetic_pair(24, 24, 3.3)
@@ -1151,7 +1153,9 @@ def test_swinir_c5_at_its_own_size_vs_reference(dev, precision):
     CiaoSR.forward_test output and the reference trunk's features (tests/golden/swinir_c5_48.npz).  48 = 6 windows of 8, so the
     shifted blocks use their own `attn_mask` buffers (swinir_net.py:233-236) -- the 24x24 fixture takes `calculate_mask`.
       fp32: trunk features <= 2e-4 * scale, output |delta| <= 1e-3, PSNR delta vs GT <= 0.01 dB
-      bf16 / f16: PSNR delta vs GT <= 0.01 dB at the fixture's 14.5 dB AND against GT' = reference + 30 dB noise."""
+      f16 / f16x3: PSNR delta vs GT <= 0.01 dB at the fixture's own level AND against GT' = reference + 30 dB noise; f16x3 also
+      the fp32 bound itself.  precision='bf16' is mapped to the f16 kernels by the generator, with a warning (the bf16 mode's 8-bit
+      activations measured 0.060 dB at 30 dB here, six times the gate): the gate asserted for it is the same 0.01 dB."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.coords import make_coord, make_cell
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
@@ -1159,7 +1163,7 @@ def test_swinir_c5_at_its_own_size_vs_reference(dev, precision):
     from tests.test_host_logic import _swinir_ciaosr
     fx = load_golden('swinir_c5_48')
     model = _swinir_ciaosr(dict(scale=3.3))
-    assert seeded_init_(model, seed=int(fx['weight_seed']), gain=1.0, head_gain=SQRT6) == str(fx['sha'])
+    assert seeded_init_(model, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=SQRT6) == str(fx['sha'])
     model = model.to(dev)
     ht, wt = [int(v) for v in fx['target']]
     assert (ht, wt) == (158, 158)
@@ -1172,11 +1176,17 @@ def test_swinir_c5_at_its_own_size_vs_reference(dev, precision):
         print(f'C5 48x48 trunk: max|d| vs reference features {ferr:.3e} (scale {want.abs().max().item():.3f})')
         assert ferr < 2e-4 * max(want.abs().max().item(), 1.0), ferr
     model.test_cfg['precision'] = precision
-    with hip_ops.profile():
+    import warnings
+    from ciaosr_amd.implicit_net import LocalImplicitSRSWINIR
+    LocalImplicitSRSWINIR._warned_bf16 = False
+    with hip_ops.profile(), warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
         out = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)['output']
     prof = hip_ops.profile.results()
     assert 'swin_window_attention' in prof
-    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_bf16', 'f16': 'head_kv_fused_f16', 'f16x3': 'head_kv_fused_f16x3'}[precision] in prof
+    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_f16', 'f16': 'head_kv_fused_f16', 'f16x3': 'head_kv_fused_f16x3'}[precision] in prof
+    assert 'head_kv_fused_bf16' not in prof
+    assert (precision == 'bf16') == any('does not meet the 0.01 dB PSNR gate' in str(c.message) for c in caught)
     ref = _t(fx['out'])
     err = (out - ref).abs().max().item()
     rms = (out - ref).double().pow(2).mean().sqrt().item()
@@ -1193,13 +1203,7 @@ def test_swinir_c5_at_its_own_size_vs_reference(dev, precision):
     if precision == 'f16x3':
         assert rms <= 5e-5, rms
     assert d_psnr <= 0.01, d_psnr
-    if precision == 'bf16':
-        # bf16 mode (8-bit ACTIVATIONS; weights as pairs) does NOT meet the gate at 30 dB on this ill-conditioned fixture (head gain
-        # sqrt(6): logit std ~40, so 2^-9 relative activation noise moves the 4-way attention): rms 3.6e-3, measured 0.060 dB.
-        # f16 (11-bit activations, same MFMA rate) does: 0.0007 dB.  f16 is the 16-bit mode to use; the bf16 bound is what it delivers.
-        assert d_psnr30 <= 0.09, d_psnr30
-    else:
-        assert d_psnr30 <= 0.01, d_psnr30
+    assert d_psnr30 <= 0.01, d_psnr30
 
 
 def test_tools_test_cli_end_to_end(dev, tmp_path, capsys):

@@ -207,7 +207,7 @@ def test_swinir_names_and_trunk_match_reference():
     names = json.load(open(os.path.join(GOLDEN, 'state_dict_names_swinir.json')))
     mine = {k: list(v.shape) for k, v in m.state_dict().items()}
     assert list(mine) == list(names) and mine == names
-    assert seeded_init_(m, seed=int(fx['weight_seed']), gain=1.0, head_gain=6 ** 0.5) == str(fx['sha'])
+    assert seeded_init_(m, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=6 ** 0.5) == str(fx['sha'])
     x = randn((1, 3, 20, 27), fx['x_seed']) * 0.3
     from tests.torch_trunks import swinir_features
     from ciaosr_amd._lib import CiaoSRHipError

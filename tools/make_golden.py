@@ -294,7 +294,8 @@ def gen_e2e(ref):
         test_cfg = ref.ConfigDict(scale=scale, tile=192, tile_overlap=32)
         model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
                            rgb_mean=mean, rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
-        sha = seeded_init_(model, seed=0, gain=1.25 if kind == 'edsr' else 1.6, head_gain=SQRT6)
+        gain = 1.25 if kind == 'edsr' else 1.45     # RDN: 1.6 clamps 31 % of the pixels at 0 / 1 (errors hide there), 1.45: 0.3 %
+        sha = seeded_init_(model, seed=0, gain=gain, head_gain=SQRT6)
         lq, gt = synthetic_pair(48, 48, scale)
         coord, cell, (ht, wt) = coords_for(48, 48, scale)
         with torch.no_grad():
@@ -307,7 +308,7 @@ def gen_e2e(ref):
         with open(os.path.join(OUT, f'state_dict_names_{kind}.json'), 'w') as f:
             json.dump(names, f, indent=0)
         save(tag, lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(0),
-             gain=np.array(1.25 if kind == 'edsr' else 1.6), scale=np.array(scale))
+             gain=np.array(gain), scale=np.array(scale))
 
 
 def gen_tiling(ref):
@@ -319,7 +320,7 @@ def gen_tiling(ref):
     test_cfg = ref.ConfigDict(scale=2, tile=48, tile_overlap=16)
     model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040),
                        rgb_std=(1., 1., 1.), test_cfg=test_cfg).eval()
-    sha = seeded_init_(model, seed=9, gain=2.0, head_gain=SQRT6)
+    sha = seeded_init_(model, seed=9, gain=1.75, head_gain=SQRT6)      # 2.0 clamps 30 % of the pixels, 1.75: 0.6 %
     lq, gt = synthetic_pair(100, 132, 2)
     coord, cell, _ = coords_for(100, 132, 2)
     with torch.no_grad():
@@ -349,7 +350,8 @@ def gen_swinir(ref):
                            rgb_std=(1., 1., 1.), test_cfg=ref.ConfigDict(scale=3.3)).eval()
     finally:
         nn.Module.cuda = orig_cuda
-    sha = seeded_init_(model, seed=2, gain=1.0, head_gain=SQRT6)
+    gain = 0.6                                   # trunk gain 1.0 clamps 31 % of the output pixels at 0 / 1; 0.6: 2 %
+    sha = seeded_init_(model, seed=2, gain=gain, head_gain=SQRT6)
     names = {k2: list(v2.shape) for k2, v2 in model.state_dict().items()}
     with open(os.path.join(OUT, 'state_dict_names_swinir.json'), 'w') as f:
         json.dump(names, f, indent=0)
@@ -364,7 +366,7 @@ def gen_swinir(ref):
     print(f'  swinir: feat std {feat.std():.3f}, out range [{out.min():.3f},{out.max():.3f}] std {out.std():.3f} '
           f'frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f}')
     save('swinir_c5', feat=feat[0], x_seed=np.array(91), lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(2),
-         target=np.array([ht, wt]))
+         gain=np.array(gain), target=np.array([ht, wt]))
 
 
 def gen_swinir48(ref):
@@ -388,7 +390,8 @@ def gen_swinir48(ref):
                            rgb_std=(1., 1., 1.), test_cfg=ref.ConfigDict(scale=3.3)).eval()
     finally:
         nn.Module.cuda = orig_cuda
-    sha = seeded_init_(model, seed=2, gain=1.0, head_gain=SQRT6)
+    gain = 0.55                                  # trunk gain 1.0 clamps 23 % of the output pixels at 0 / 1; 0.55: 4 %
+    sha = seeded_init_(model, seed=2, gain=gain, head_gain=SQRT6)
     lq, gt = synthetic_pair(48, 48, 3.3)
     coord, cell, (ht, wt) = coords_for(48, 48, 3.3)
     import time
@@ -400,7 +403,7 @@ def gen_swinir48(ref):
     psnr_ref = psnr_tensors(out, gt, crop_border=3)
     print(f'  swinir_c5_48: {time.time() - t0:.0f} s, feat std {feat.std():.3f}, out {tuple(out.shape)} range [{out.min():.3f},{out.max():.3f}] '
           f'std {out.std():.3f} frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f} PSNR(ref,GT) {psnr_ref:.4f}')
-    save('swinir_c5_48', feat_s2=feat[0][:, ::2, ::2], lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(2),
+    save('swinir_c5_48', feat_s2=feat[0][:, ::2, ::2], lq=lq, out=out, sha=np.array(sha), weight_seed=np.array(2), gain=np.array(gain),
          target=np.array([ht, wt]), psnr_ref_gt=np.array(psnr_ref, dtype=np.float64))
 
 
