@@ -48,7 +48,7 @@ class OptionsT(C.Structure):
                 ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('reserved', C.c_int * 2), ('f16_pairs', C.c_int)]
 
 
-HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM = 1, 2, 4
+HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG = 1, 2, 4, 8
 
 
 class ConvT(C.Structure):

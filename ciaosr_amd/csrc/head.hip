@@ -133,6 +133,11 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     const bool lo = (prec == kBF16 && !(opt && opt->bf16_single)) || (prec == kF16 && opt && opt->f16_pairs);
     // f16_pairs = 2 ("f16x3"): the activations of the three MLP chains as half pairs too (head_fused_x3.hip), every table in fp32
     const bool x3 = prec == kF16 && opt && opt->f16_pairs == 2;
+    // f16x3 runs the wide-workgroup kernels (head_fused_wide.hip: its two activation arrays leave room for one workgroup per CU);
+    // f16 / f16-pairs keep the 128-row kernels with two workgroups per CU (head_fused_h16.hip) and take the wide form -- 256 rows, half
+    // the weight stream per MFMA, measured equal in time: one workgroup per CU exposes its gather phases -- only with head_route bit 3
+    const bool wide16 = prec == kF16 && (x3 || (route & CIAOSR_HEAD_WIDE_WG));
+    const int wide_mode = x3 ? 2 : (lo ? 1 : 0);
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(options_ok(opt));
     CIAOSR_CHECK_ARG(w->channels >= 4 && (w->channels & 3) == 0 && (w->nonlocal_channels & 3) == 0);
@@ -268,7 +273,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             kp.Z = Z; kp.ldz = p.Dv;
             kp.rows_per_wg = opt ? opt->kv_rows : 0;
             kp.G = use_table ? G : nullptr; kp.ldg = kLdG; kp.g_bytes = (unsigned)((size_t)p.HW * 9 * kLdG * sizeof(float));
-            RUN(x3 ? x3::head_kv_fused_x3(kp, s) : bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
+            RUN(wide16 ? wide::head_kv_fused_wide(kp, wide_mode, s) : bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;
             qp.Z = Z; qp.ldz = p.Dv; qp.Dv = p.Dv;
@@ -285,7 +290,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             qp.b_last = mq.bias[mq.n_layers - 1];
             qp.rows_per_wg = opt ? opt->decode_rows : 0;
             qp.x_lr = x_lr_nchw; qp.coord = coord; qp.q0 = q0; qp.nq = nq; qp.H = H; qp.W = W; qp.rgb = rgb;
-            RUN(x3 ? x3::head_decode_fused_x3(qp, s) : bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
+            RUN(wide16 ? wide::head_decode_fused_wide(qp, wide_mode, s) : bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
             continue;
         }
         HeadRowsP hp;

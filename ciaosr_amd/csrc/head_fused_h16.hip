@@ -661,7 +661,11 @@ int head_kv_fused_h16(const FusedKVP& p, hipStream_t s) {
 }
 
 int head_decode_fused_h16(const FusedQP& p, hipStream_t s) {
+#ifdef CIAOSR_DECODE_LDS       // developer experiment (tools/slp_bisect.py): more LDS than the kernel uses = ONE workgroup per CU
+    const size_t lds = CIAOSR_DECODE_LDS;
+#else
     const size_t lds = (size_t)HBM_ * HLD * 2;
+#endif
     CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<0>, lds);
     CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<2>, lds);
     CIAOSR_BIG_LDS(head_decode_fused_h16_kernel<4>, lds);

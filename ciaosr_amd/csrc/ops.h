@@ -188,10 +188,11 @@ namespace b16 { CIAOSR_H16_DECLS }
 namespace f16 { CIAOSR_H16_DECLS }
 #undef CIAOSR_H16_DECLS
 
-// head_fused_x3.hip: the fused head with both MFMA operands as half hi + lo pairs (three MFMAs per product; Z in fp32)
-namespace x3 {
-int head_kv_fused_x3(const FusedKVP& p, hipStream_t s);
-int head_decode_fused_x3(const FusedQP& p, hipStream_t s);
+// head_fused_wide.hip: the fused head of the IEEE-half modes with one wide workgroup per CU.  mode 0 = f16 (256 rows), 1 = f16-pairs
+// (256 rows, weights as hi + lo pairs), 2 = f16x3 (128 rows, weights AND activations as pairs: three MFMAs per product, Z in fp32)
+namespace wide {
+int head_kv_fused_wide(const FusedKVP& p, int mode, hipStream_t s);
+int head_decode_fused_wide(const FusedQP& p, int mode, hipStream_t s);
 }
 
 // precision of an entry point: the suffix of its name

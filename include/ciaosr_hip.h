@@ -66,6 +66,10 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
                                        * ciaosr_head_weights_t.k_out_wino is given */
 #define CIAOSR_HEAD_NO_LOGIT_TABLE 2  /* head_route bit 1: fused path, imnet_k output layer on the MFMA per (query, sample)
                                        * row instead of the exact 9-rows-per-LR-pixel fold */
+#define CIAOSR_HEAD_WIDE_WG 8         /* head_route bit 3: _f16 entries (f16 / f16-pairs): the fused kernels with ONE 256-row workgroup per CU
+                                       * (head_fused_wide.hip: half the weight stream per MFMA) instead of two 128-row workgroups per CU;
+                                       * same result up to the fp32 summation order of the logit dot product, measured equal in time
+                                       * (f16x3 always runs its 128-row two-array form of that kernel) */
 typedef struct ciaosr_options {
     int head_route;         /* CIAOSR_HEAD_* bits; 0 = automatic */
     int csa_composed_min;   /* cs_attn: LR pixels (after padding) from which the composed fold+down tail applies;

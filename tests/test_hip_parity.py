@@ -428,6 +428,38 @@ def test_head_bf16_mode_full_width_vs_reference(dev, name, C, hw, precision):
     assert psnr > (44.0 if precision == 'bf16' else 58.0) and err.max().item() < (0.3 if precision == 'bf16' else 0.05) * scale
 
 
+@pytest.mark.parametrize('C,hw,target', [(64, (21, 30), (59, 83)), (180, (16, 19), (53, 61))])
+def test_half_head_wide_and_narrow_workgroups_agree(dev, C, hw, target):
+    """The IEEE-half head kernels come in two cuts: head_fused_h16.hip (128 rows per workgroup, two workgroups per CU; the default)
+    and head_fused_wide.hip (256 rows, one per CU; head_route bit HEAD_WIDE_WG).  Same products, same rounding points, so the two
+    agree to the fp32 summation order of the logit dot product -- on a ragged query count (last workgroup partly empty), with the
+    logit table and with the MFMA output layer of imnet_k (HEAD_NO_LOGIT_TABLE), for f16 and f16-pairs; f16x3 (wide only) sits
+    within 1e-4 of the fp32 kernels on the same inputs."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd._lib import HEAD_WIDE_WG, HEAD_NO_LOGIT_TABLE
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(C, (256,) * 4, seeded_head(C, 3, head_gain=2.0), dev, eval_bsize=30000)
+    feat = randn((1, C) + hw, 11).to(dev)
+    ht, wt = target                          # Q not a multiple of 64
+    coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
+    x = (randn((1, 3) + hw, 12) * 0.3).to(dev)
+    fp32 = g._predict([feat], coord, cell, 30000, x, hip_ops.Options('fp32')).cpu()
+    scale = fp32.abs().max().item()
+    for prec in ('f16', 'f16-pairs'):
+        for route in (0, HEAD_NO_LOGIT_TABLE):
+            narrow = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec, head_route=route)).cpu()
+            wide = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec, head_route=route | HEAD_WIDE_WG)).cpu()
+            d = (wide - narrow).abs().max().item()
+            e = (wide - fp32).abs().max().item()
+            print(f'C={C} {prec} route {route}: wide vs narrow {d:.2e}, wide vs fp32 {e:.2e} (scale {scale:.2f})')
+            assert torch.isfinite(wide).all() and d < 2e-3 * scale and e < 0.05 * scale, (prec, route, d, e)
+    for route in (0, HEAD_NO_LOGIT_TABLE):
+        x3 = g._predict([feat], coord, cell, 30000, x, hip_ops.Options('f16x3', head_route=route)).cpu()
+        e = (x3 - fp32).abs().max().item()
+        print(f'C={C} f16x3 route {route}: vs fp32 {e:.2e}')
+        assert e < 1e-4 * max(scale, 1.0), (route, e)
+
+
 def test_fused_and_staged_head_paths_agree(dev):
     """The fused kernels (head_kv_fused / head_decode_fused) against the staged per-layer path on the
     same inputs (both through ciaosr_head_forward_f32), including a ragged last workgroup."""

@@ -19,14 +19,14 @@ lq, _ = synthetic_pair(HW_, HW_, 4)
 lq = lq.to(dev)
 MODE = _s.argv[2] if len(_s.argv) > 2 else 'fp32'          # fp32 | bf16 | bf16-single | f16x3
 from ciaosr_amd import hip_ops
-OPT = hip_ops.Options('fp32') if MODE == 'fp32' else (hip_ops.Options('f16x3') if MODE == 'f16x3' else hip_ops.Options('bf16', bf16_single=int(MODE == 'bf16-single')))
+OPT = hip_ops.Options('fp32') if MODE == 'fp32' else (hip_ops.Options('f16x3') if MODE == 'f16x3' else hip_ops.Options('f16') if MODE == 'f16w' else hip_ops.Options('bf16', bf16_single=int(MODE == 'bf16-single')))
 for _ in range(3):
     model.restore(lq, options=OPT)
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 4096
 buf = (C.c_ulonglong * (4096 * 16))()
-reader = lib.ciaosr_debug_probe_read if MODE == 'fp32' else (lib.ciaosr_debug_probe_x3_read if MODE == 'f16x3' else lib.ciaosr_debug_probe16_read)
+reader = lib.ciaosr_debug_probe_read if MODE == 'fp32' else (lib.ciaosr_debug_probe_x3_read if MODE in ('f16x3', 'f16w') else lib.ciaosr_debug_probe16_read)
 reader.restype = C.c_int
 assert reader(buf, 4096 * 16) == 0
 a = np.frombuffer(buf, dtype=np.uint64).reshape(4096, 16)[:n].astype(np.int64)
@@ -36,12 +36,13 @@ tot = a[:, 7] - a[:, 0]
 print(f'{n} workgroups; lifetime avg {tot.mean():.0f} ticks (min {tot.min()}, max {tot.max()})')
 for i, nm in enumerate(names):
     print(f'  {nm:20s} {d[:, i].mean():9.0f} ticks avg  ({100 * d[:, i].mean() / tot.mean():5.1f} %)')
-if MODE == 'f16x3':
+if MODE in ('f16x3', 'f16w'):
     kl = [a[:, 10] - a[:, 2], a[:, 11] - a[:, 10], a[:, 12] - a[:, 11]]
     vl = [a[:, 13] - a[:, 5], a[:, 14] - a[:, 13], a[:, 15] - a[:, 14]]
     print('  k hidden layers 1..3: ' + ', '.join(f'{x.mean():.0f}' for x in kl) + '   v hidden layers 1..3: ' + ', '.join(f'{x.mean():.0f}' for x in vl))
-    mfma = 32 * 12 * 16 * (6 + 3)       # 12 MFMAs per k-step, 16 k-steps per pass; waves 0-3: 6 hidden layers + 3 v-out units
-    print(f'  MFMA issue cycles of one wave: {mfma} -> two waves per SIMD {2 * mfma - 32 * 192} ({100 * (2 * mfma - 32 * 192) / tot.mean():.1f} % of the lifetime; ONE workgroup per CU)')
+    per_step = 12 if MODE == 'f16x3' else 8     # MFMAs per k-step of a hidden layer (x3: 4 row tiles x 3 products; f16 wide: 8 row tiles)
+    simd = 32 * 16 * (2 * 6 * per_step + 5 * per_step)     # two waves per SIMD: 6 hidden layers each + 3 + 2 v-out units
+    print(f'  MFMA issue cycles of one SIMD (two waves): {simd} ({100 * simd / tot.mean():.1f} % of the lifetime; ONE workgroup per CU)')
 elif MODE == 'fp32':
     kl = [a[:, 10] - a[:, 2], a[:, 11] - a[:, 10], a[:, 12] - a[:, 11]]
     vl = [a[:, 13] - a[:, 5], a[:, 14] - a[:, 13], a[:, 15] - a[:, 14]]
