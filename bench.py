@@ -153,7 +153,7 @@ def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
             return items * 2.0 * 192 * 128 * (C / 2) / (2.0 * HW * (HW / 4) * 4.5 * C)
         return 1.0
     if base in ('head_kv_fused', 'head_decode_fused', 'enc_dense'):
-        if precision == 'f16-pairs' or (precision == 'bf16' and not bf16_single):
+        if precision in ('f16-pairs', 'f16x3-fast') or (precision == 'bf16' and not bf16_single):
             return 2.0
     return 1.0
 
@@ -319,7 +319,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
                          'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product); f16x3: the fp32-tolerance '
@@ -589,6 +589,7 @@ def main():
                 'f16 (IEEE half) MFMA inputs, saturating conversions, fp32 accumulate, in the head, the dense layers and the cs_attn contractions'
                 + ('; weights as half hi+lo pairs' if args.precision == 'f16-pairs' else '')
                 + ('; head weights and activations as half hi+lo pairs (three MFMAs per product), fp32 trunk' if args.precision == 'f16x3' else '')
+                + ('; head weights and activations as half hi+lo pairs (three MFMAs per product), trunk with half weight pairs' if args.precision == 'f16x3-fast' else '')
                 if args.precision.startswith('f16') else
                 'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
                 + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),
@@ -660,6 +661,7 @@ def main():
                          ('f16_pairs', hip_ops.Options('f16-pairs'), 'f16-pairs')]
                 if 'f16x3' in hip_ops.PRECISIONS:
                     modes.append(('f16x3', hip_ops.Options('f16x3'), 'f16x3'))
+                    modes.append(('f16x3_fast', hip_ops.Options('f16x3-fast'), 'f16x3-fast'))
                 o16, oh = modes[0][1], modes[1][1]
                 for nm, o, prec in modes:
                     model.restore(tl, options=o)

@@ -195,12 +195,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmP p) {
         for (int s = 0; s < NSA; ++s) {
             const int c4 = ((t + 256 * s) % F4R) * 4;
             float4 v = ra[s];
-            if constexpr (SM) {                                       // 3 VALU per element: one FMA, v_exp_f32, one multiply
+            if constexpr (SM) {
+                // per element one FMA, v_exp_f32, one multiply; the FMA and the multiply as PACKED fp32 on element pairs (a packed
+                // instruction costs the SIMD's fp32 matrix pipe once, tools/ubench/mfma_valu.hip): 8 instead of 12 VALU per float4.
+                // Same fp32 operations on the same values: bitwise the scalar form.
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
                 constexpr float kL2e = 1.4426950408889634f;
-                v.x = __builtin_amdgcn_exp2f(__builtin_fmaf(v.x, kL2e, -ast[s].x)) * ast[s].y;
-                v.y = __builtin_amdgcn_exp2f(__builtin_fmaf(v.y, kL2e, -ast[s].x)) * ast[s].y;
-                v.z = __builtin_amdgcn_exp2f(__builtin_fmaf(v.z, kL2e, -ast[s].x)) * ast[s].y;
-                v.w = __builtin_amdgcn_exp2f(__builtin_fmaf(v.w, kL2e, -ast[s].x)) * ast[s].y;
+                const f32x2 l2 = {kL2e, kL2e}, nm = {-ast[s].x, -ast[s].x}, rs = {ast[s].y, ast[s].y};
+                f32x2 a = __builtin_elementwise_fma(f32x2{v.x, v.y}, l2, nm), b = __builtin_elementwise_fma(f32x2{v.z, v.w}, l2, nm);
+                a = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} * rs;
+                b = f32x2{__builtin_amdgcn_exp2f(b.x), __builtin_amdgcn_exp2f(b.y)} * rs;
+                v = make_float4(a.x, a.y, b.x, b.y);
             }
             if constexpr (MASKED) v = mask4(v, k0 + c4, p.K);
             *reinterpret_cast<float4*>(a + s * (256 / F4R) * LDS_A) = v;

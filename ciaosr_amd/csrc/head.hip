@@ -131,8 +131,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     const int route = opt ? opt->head_route : 0;
     // hi + lo weight pairs: the bf16 entry unless single is asked for, the f16 entry when pairs are asked for
     const bool lo = (prec == kBF16 && !(opt && opt->bf16_single)) || (prec == kF16 && opt && opt->f16_pairs);
-    // f16_pairs = 2 ("f16x3"): the activations of the three MLP chains as half pairs too (head_fused_x3.hip), every table in fp32
-    const bool x3 = prec == kF16 && opt && opt->f16_pairs == 2;
+    // f16_pairs = 2 / 3 ("f16x3" / "f16x3-fast"): the activations of the three MLP chains as half pairs too (head_fused_wide.hip), every table in fp32
+    const bool x3 = prec == kF16 && opt && opt->f16_pairs >= 2;
     // f16x3 runs the wide-workgroup kernels (head_fused_wide.hip: its two activation arrays leave room for one workgroup per CU);
     // f16 / f16-pairs keep the 128-row kernels with two workgroups per CU (head_fused_h16.hip) and take the wide form -- 256 rows, half
     // the weight stream per MFMA, measured equal in time: one workgroup per CU exposes its gather phases -- only with head_route bit 3

@@ -187,7 +187,7 @@ def tile_finalize(E, Wt):
     return out
 
 
-PRECISIONS = ('fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3')       # what Options(precision) / test_cfg.precision accept
+PRECISIONS = ('fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast')       # what Options(precision) / test_cfg.precision accept
 
 
 class Options:
@@ -210,6 +210,9 @@ class Options:
         if precision in ('f16x3', 'f16-x3'):                     # ... with the activations of the MLP chains as pairs too
             precision = 'f16'
             kw.setdefault('f16_pairs', 2)
+        if precision == 'f16x3-fast':                            # ... and the trunk back on half weight pairs (fp32 trunk = 'f16x3')
+            precision = 'f16'
+            kw.setdefault('f16_pairs', 3)
         object.__setattr__(self, 'precision', {'fp32': 'fp32', 'f32': 'fp32', 'bf16': 'bf16', 'f16': 'f16', 'fp16': 'f16', 'half': 'f16'}[precision])
         for f in self._C_FIELDS:
             object.__setattr__(self, f, int(kw.pop(f, 0)))

@@ -96,8 +96,11 @@ typedef struct ciaosr_options {
                              * layer-0 tables) take the fp32 route of the bf16 mode (activations stay half: max |delta| 1.04e-3 on the
                              * full C3 tile, 4 % outside the fp32 tolerance);
                              * 2 = "f16x3", the fp32-tolerance fast mode: the ACTIVATIONS of the three MLP chains are half pairs too
-                             * (w_hi a_hi + w_lo a_hi + w_hi a_lo: three MFMAs per product, head_fused_x3.hip), Z travels in fp32, the
-                             * layer-0 and logit tables and the whole RDN trunk take their _f32 routes, cs_attn's contractions stay half */
+                             * (w_hi a_hi + w_lo a_hi + w_hi a_lo: three MFMAs per product, head_fused_wide.hip), Z travels in fp32, the
+                             * layer-0 and logit tables and the whole RDN trunk take their _f32 routes, cs_attn's contractions stay half
+                             * (full C3 tile: max |delta| 2.7e-5, rms 2.1e-6 against the reference);
+                             * 3 = "f16x3-fast": the head of 2 on the trunk of 1 (half weight pairs, half activations in the dense
+                             * layers): max |delta| 4.0e-4, rms 4.6e-5 -- still inside the fp32 tolerance, at 2/3 of the time */
 } ciaosr_options_t;
 
 /* ---- layout plumbing -------------------------------------------------------------------- */

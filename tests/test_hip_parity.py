@@ -871,7 +871,7 @@ def _tile192_checks(out, fx, tol):
     return errs
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'fp32-direct', 'bf16', 'bf16-single', 'f16', 'f16-pairs', 'f16x3'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp32-direct', 'bf16', 'bf16-single', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'])
 def test_e2e_full_c3_tile_vs_reference(dev, precision):
     """One full C3 tile: 192x192 LR -> 768x768 through CiaoSR.forward_test (clip_test with one tile; RDN trunk on the
     halo-resident dense kernels, cs_attn on the composed tail, 589 824 queries = 20 reference eval_bsize chunks) against
@@ -895,8 +895,10 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
       mode on this ill-conditioned (head gain sqrt 6) vector.  What is left is the 11-bit rounding of the ACTIVATIONS in front of the
       4-way softmax (logit std ~40); W5 through the exact-fp32 table GEMM changed nothing (1.14e-3).  Asserted: < 1.5e-3.
       f16x3 (`Options('f16x3')`, the fp32-tolerance fast mode): the head's weights AND activations as half pairs (three MFMAs per
-      product, head_fused_x3.hip), fp32 trunk / tables, half cs_attn contractions: |delta| < 1e-3 on EVERY stored pixel, rms <= 5e-5,
-      both PSNR gates."""
+      product, head_fused_wide.hip), fp32 trunk / tables, half cs_attn contractions: |delta| < 1e-3 on EVERY stored pixel, rms <= 5e-5,
+      both PSNR gates (measured: max 2.7e-5, rms 2.1e-6).
+      f16x3-fast: the same head on the f16-pairs trunk (half activations in the dense layers): max 4.0e-4, rms 4.6e-5 -- still inside
+      both bounds, at 2/3 of the time."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.metrics import psnr_tensors
@@ -908,12 +910,13 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     lq, gt = synthetic_pair(192, 192, 4)
     opt = {'fp32': hip_ops.Options('fp32'), 'fp32-direct': hip_ops.Options('fp32', dense_direct=1), 'bf16': hip_ops.Options('bf16'),
            'bf16-single': hip_ops.Options('bf16', bf16_single=1), 'f16': hip_ops.Options('f16'),
-           'f16-pairs': hip_ops.Options('f16-pairs'), 'f16x3': hip_ops.Options('f16x3')}[precision]
+           'f16-pairs': hip_ops.Options('f16-pairs'), 'f16x3': hip_ops.Options('f16x3'), 'f16x3-fast': hip_ops.Options('f16x3-fast')}[precision]
     with hip_ops.profile():
         out = model.restore(lq.to(dev), options=opt).cpu()
     prof = hip_ops.profile.results()
-    if precision == 'f16x3':
-        for tag in ('enc_dense_wino', 'csa_attn_v_f16', 'csa_scores_f16', 'head_logit_table', 'head_kv_fused_f16x3', 'head_decode_fused_f16x3'):
+    if precision in ('f16x3', 'f16x3-fast'):
+        for tag in ('enc_dense_wino' if precision == 'f16x3' else 'enc_dense_f16', 'csa_attn_v_f16', 'csa_scores_f16', 'head_logit_table',
+                    'head_kv_fused_f16x3', 'head_decode_fused_f16x3'):
             assert tag in prof, (tag, sorted(prof))
     elif precision in ('fp32', 'fp32-direct'):
         for tag in ('enc_dense_wino' if precision == 'fp32' else 'enc_dense_gather', 'csa_attn_v_edge', 'head_logit_table'):
@@ -943,10 +946,12 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         assert d_psnr <= 0.01 and d_psnr30 <= 0.001, (d_psnr, d_psnr30)
         assert max(errs.values()) < NORTH_STAR_TOL, errs
         assert mean_err < 1e-5 and rms < 1e-5, (mean_err, rms)
-    elif precision == 'f16x3':
+    elif precision in ('f16x3', 'f16x3-fast'):
         assert d_psnr <= 0.01 and d_psnr30 <= 0.01, (d_psnr, d_psnr30)
         assert max(errs.values()) < NORTH_STAR_TOL, errs          # the fp32 tolerance, on every stored pixel
         assert rms <= 5e-5 and mean_err < 1e-5, (rms, mean_err)
+        if precision == 'f16x3':
+            assert max(errs.values()) < 1e-4 and rms < 1e-5, (errs, rms)     # fp32 trunk: a decade inside
     elif precision == 'f16-pairs':
         assert d_psnr <= 0.01 and d_psnr30 <= 0.01, (d_psnr, d_psnr30)
         assert max(errs.values()) < 1.5e-3, errs      # measured 1.04e-3: just above the fp32 bound (see the docstring)
