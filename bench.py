@@ -124,6 +124,7 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         # the same layers in Winograd F(2x2, 3x3) form: ALGORITHMIC flops are the direct convolution's (the kernel executes 1/2.25 of them,
         # so its fraction of the fp32 MFMA peak on algorithmic work can exceed 1)
         'enc_dense_wino': (dense, 'flop'),
+        'enc_dense_wino4': (dense, 'flop'),           # F(4x4, 3x3): executes 1/4 of the direct convolution's flops
         'enc_conv1x1': (blocks * 2.0 * HW * (C + C * layers) * C + 2.0 * HW * C * blocks * C, 'flop'),
         # the blocks' local feature fusion in f16 mode: memory-bound (16-bit rows in, fp32 residual in, two fp32 + one 16-bit rows out)
         'enc_conv1x1_bf16': (blocks * HW * ((C + C * layers) * 2.0 + C * 4.0 + 2 * C * 4.0 + C * 2.0), 'byte'),
@@ -147,6 +148,8 @@ def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     if not half:
         if base in ('enc_dense_wino', 'head_logit_table'):
             return 16.0 / 36.0
+        if base == 'enc_dense_wino4':
+            return 36.0 / 144.0
         if base == 'csa_scores' and HW >= 4096:
             side = HW ** 0.5
             items = -(-side // 8) * -(-side // 16) * -(-(side / 2) // 4) * -(-(side / 2) // 16)
@@ -559,7 +562,7 @@ def main():
                           'head_kv_fused': 'head_kv_fused_kernel', 'head_fused': 'head_fused_kernel',
                           'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_h16_kernel',
                           'head_kv_fused_f16': 'head_kv_fused_h16_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
-                          'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel'}
+                          'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel', 'enc_dense_wino4': 'dense_wino4_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
                 pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (4, 3))
                                  if os.path.exists(q)), '')

@@ -53,7 +53,8 @@ HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG = 1, 2, 4, 8
 
 class ConvT(C.Structure):
     _fields_ = [('weight', C.c_void_p), ('bias', C.c_void_p), ('cin', C.c_int), ('cout', C.c_int), ('ksize', C.c_int),
-                ('frag16', C.c_void_p), ('frag16_lo', C.c_void_p), ('frag', C.c_void_p), ('frag_wino', C.c_void_p)]
+                ('frag16', C.c_void_p), ('frag16_lo', C.c_void_p), ('frag', C.c_void_p), ('frag_wino', C.c_void_p),
+                ('frag_wino4', C.c_void_p)]
 
 
 class RdnWeightsT(C.Structure):

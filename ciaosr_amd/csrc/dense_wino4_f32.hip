@@ -1,0 +1,366 @@
+// fp32 dense-block convolution for big maps in Winograd F(4x4, 3x3) form (round 4): the same 3x3 dense layer as dense_wino_f32.hip
+// (mmedit RDB.layers[l].conv over cat(x, d_0 .. d_{l-1}), called from ciaosr_net.py:330-337) with 36 multiplies per 4x4 output tile and
+// (ci, co) pair instead of 144 (direct) or 64 (F(2x2, 3x3)): 2.25 MFMA-units per output pixel against 4.
+//
+//   Y = A^T [ (G g G^T) . (B^T d B) ] A        g 3x3 weights, d the 6x6 input tile whose top-left is the output tile's (-1, -1)
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]      (applied on the host in fp64, rounded once)
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 throughout on the exact-fp32 MFMA.  Not bitwise a direct fmaf chain (products of transformed operands; the transforms multiply
+// by up to 5 / 8): measured against the oracle in the tests, selectable against F(2x2) and the direct kernel per call.
+//
+// Why it is cut differently from the F(2x2) kernel.  There a wave transforms its own operands in registers beside its MFMAs; with 36
+// positions the six-row window transient does not fit beside the accumulators, and a VALU instruction beside an fp32
+// MFMA costs the SIMD's pipe ~6-20 cycles (tools/ubench/mfma_valu.hip).  So the two kinds of work are SEPARATED IN TIME:
+//   * workgroup = 16 x 32 output pixels = 4 x 8 Winograd tiles = the 32 columns of one MFMA tile, x all 64 output channels; 4 waves, one
+//     per SIMD; a step = 8 input channels;
+//   * T phase (all 256 threads, thread = (tile, channel)): 36 scalar LDS reads of the 6x6 window from the halo patch, B^T d B with
+//     144 VALU operations (the 12-operation form of B^T x, applied to 6 columns and 6 rows), 36 scalar LDS writes into
+//     V[pos][tile][8 ch] -- no MFMA is in flight, so the VALU instructions cost their own 2-4 cycles;
+//   * one barrier;
+//   * M phase: wave (nt, h) owns positions (3h .. 3h+2, 0 .. 5) of output-channel half nt = 18 accumulator tiles (288 registers): 18
+//     V fragments (ds_read_b128) against 18 weight fragments (1 KB each, straight from L2) = 72 MFMAs with nothing between them; every
+//     weight register is re-requested for the NEXT step right behind its last MFMA, so the L2 round trip has a whole step to complete;
+//   * the 18 x 34-pixel halo patch of a step's 8 channels (2 x 16-B chunks per pixel) comes by LDS-DMA two steps ahead into one of two
+//     buffers; its chunks are XOR-swizzled with ((P >> 2) & 3) << 1 (P = pixel index) so that the T phase's scalar reads -- four
+//     tiles x eight channels per 32-lane group, tiles four pixels apart -- hit 32 distinct banks;
+//   * V and the patch are double-buffered, which leaves ONE barrier per step (T(n) | barrier | M(n), T(n+1) | barrier | ...).
+// The output transform runs once per layer: A^T along j in registers, the row half through LDS between the two waves of a channel half.
+#include "ops.h"
+
+namespace ciaosr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int W4TH = 16, W4TW = 32;              // output tile (pixels)
+constexpr int W4PH = W4TH + 2, W4PW = W4TW + 2;  // patch with the 1-pixel halo
+constexpr int W4NP = W4PH * W4PW;                // 612 pixels
+constexpr int W4PIECES = (2 * W4NP + 63) / 64;   // 20 DMA pieces of 64 chunks (16 B each)
+constexpr int W4PATCH = W4PIECES * 1024;         // 20 480 B per buffer
+constexpr int W4VROW = 48;                       // bytes per (position, tile) row of V: 8 channels + 16 B of padding (conflict-free b128 reads)
+constexpr int W4VPOS = 32 * W4VROW;              // 1536
+constexpr int W4V = 36 * W4VPOS;                 // 55 296 B per buffer
+constexpr int W4V0 = 2 * W4PATCH;                // LDS: [patch 0][patch 1][V 0][V 1]
+constexpr size_t kWino4Lds = 2 * (size_t)W4PATCH + 2 * (size_t)W4V;      // 151 552 B
+static_assert(4 * 8 * 4 * 64 * 16 <= kWino4Lds, "output-transform exchange must fit");
+constexpr unsigned kOobW4 = 0xFFFFFFF0u;
+
+struct DenseWino4P {
+    float* x; int ldx;                           // the block buffer [n_img][H*W][ldx]: input groups and the output group
+    unsigned x_bytes;
+    int H, W, tiles_x;
+    int groups;                                  // 64-channel input groups
+    const float4* wf;                            // 36 fragment arrays [2][nj][64 lanes] float4, one per transformed position, back to back
+    int nj; long pos_stride;                     // nj = cin / 8; float4 per position array
+    const float* bias;
+    int col_out;
+};
+
+// y = B^T x for the 6-vector x (12 operations)
+#define W4_BT(x0, x1, x2, x3, x4, x5, y0, y1, y2, y3, y4, y5)                          \
+    do {                                                                               \
+        const float t1_ = __builtin_fmaf(-4.f, x2, x4), t2_ = __builtin_fmaf(-4.f, x1, x3); \
+        const float t3_ = x4 - x2, t4_ = x3 - x1;                                      \
+        y0 = __builtin_fmaf(4.f, x0, __builtin_fmaf(-5.f, x2, x4));                   \
+        y1 = t1_ + t2_;                                                                \
+        y2 = t1_ - t2_;                                                                \
+        y3 = __builtin_fmaf(2.f, t4_, t3_);                                            \
+        y4 = __builtin_fmaf(-2.f, t4_, t3_);                                           \
+        y5 = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));                   \
+    } while (0)
+
+__global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds4[];
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    const int nt = w & 1, h = w >> 1;            // M phase: output-channel half, rows 3h .. 3h+2 of the 6x6 transformed domain
+    const int ty0 = (blockIdx.x / p.tiles_x) * W4TH, tx0 = (blockIdx.x % p.tiles_x) * W4TW;
+    const int img = blockIdx.y;
+    const unsigned img_off = (unsigned)((size_t)img * p.H * p.W * p.ldx * 4);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds4;
+
+    // ---- patch DMA: piece i = w + 4 s (i < 20) fills LDS bytes [1024 i, 1024 i + 1024) of a patch buffer; lane -> LDS chunk q' = 64 i + lane,
+    // which holds chunk q = q' ^ (((q' >> 3) & 3) << 1) of the unswizzled order q = 2 P + half (pixel P = py * 34 + px, half = channels 4 half ..)
+    constexpr int W4DS = W4PIECES / 4;           // 5 per wave
+    unsigned goff[W4DS];
+#pragma unroll
+    for (int s = 0; s < W4DS; ++s) {
+        const int qs = 64 * (w + 4 * s) + lane;
+        const int q = qs ^ (((qs >> 3) & 3) << 1);
+        const int P = q >> 1, half = q & 1;
+        const int py = P / W4PW, px = P - py * W4PW;
+        const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+        const bool ok = P < W4NP && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        goff[s] = ok ? (img_off + (unsigned)(gy * p.W + gx) * (unsigned)p.ldx * 4u + (unsigned)half * 16u) : kOobW4;
+    }
+    const int rot = p.groups > 1 ? (int)(blockIdx.x % (unsigned)p.groups) : 0;
+    auto phys = [&](int g) -> int { const int x = g + rot; return x >= p.groups ? x - p.groups : x; };
+    const i32x4 desc = {(int)(unsigned)(size_t)p.x, (int)(((size_t)p.x >> 32) & 0xFFFFu), (int)p.x_bytes, 0x00020000};
+    const int N = 8 * p.groups;                  // steps
+    auto step_ch = [&](int n) -> int { return 64 * phys(n >> 3) + 8 * (n & 7); };     // first input channel of step n
+    auto dma_patch = [&](int n) {                // patch of step n -> buffer n & 1
+        const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)step_ch(n) * 4u);
+#pragma unroll
+        for (int s = 0; s < W4DS; ++s) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((n & 1) * W4PATCH) + 1024u * (unsigned)(w + 4 * s));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(goff[s]), "s"(dst), "s"(desc), "s"(soff) : "memory");
+        }
+    };
+
+    // ---- T phase addressing: thread = (tile, channel); window pixel (a, b) of the tile at P = P0 + 34 a + b, P0 = 136 tyw + 4 txw (a
+    // multiple of 4), chunk q = 2 P + half, swizzle key ((P >> 2) & 3) << 1 = ((k0 + ((34 a + b) >> 2)) & 3) << 1 with k0 = (P0 >> 2) & 3:
+    // byte address = tbase + 32 ((34 a + b) & ~3) + 32 (((34 a + b) & 3) ^ K_c), K_c = (k0 + c) & 3, c = ((34 a + b) >> 2) & 3.
+    // The 16 values ty[m][c] = tbase + 32 (m ^ K_c) are kept in registers; the rest is an immediate.
+    const int tch = t & 7, ttile = t >> 3;
+    const int ttyw = ttile >> 3, ttxw = ttile & 7;
+    int ty[4][4];
+    {
+        const int P0 = 4 * W4PW * ttyw + 4 * ttxw;
+        const int k0 = (P0 >> 2) & 3;
+        const int tbase = 32 * P0 + 16 * (tch >> 2) + 4 * (tch & 3);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ty[m][c] = tbase + 32 * (m ^ ((k0 + c) & 3));
+    }
+    const int tvoff = ttile * W4VROW + tch * 4;                 // + pos * 1536: this thread's element of V
+
+    // ---- weights: fragment (position 18 h + pp, nt) of k-chunk jc, through a buffer descriptor with the fragment index as scalar offset.
+    // The loads are INLINE ASM and their waits are counted by hand: hipcc cannot see the patch DMA (asm as well) in the vector-memory
+    // queue, and where its own count of the weight loads merges over the loop's paths it falls back to `s_waitcnt vmcnt(0)` in front
+    // of an MFMA -- which, vmcnt retiring in order, waits for the DMA pieces issued a few MFMAs earlier to come back from HBM.
+    // Queue order in the steady state (oldest first) at the top of M(n): W0(n) W1(n) W2(n) [6 loads each: rows 0 / 1 / 2 of step n];
+    // row 0 issues the 5 DMA pieces of patch n + 2, row 1 re-requests W0(n + 1), row 2 W1(n + 1), the top of T(n + 1) W2(n + 1).
+    const i32x4 wdesc = {(int)(unsigned)(size_t)p.wf, (int)(((size_t)p.wf >> 32) & 0xFFFFu), (int)0xFFFFFFFFu, 0x00020000};
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const unsigned pos_bytes = (unsigned)p.pos_stride * 16u;
+    auto wload = [&](float4& dst, int pp, int n) __attribute__((always_inline)) {
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(18 * h + pp) * pos_bytes + (unsigned)(nt * p.nj + (step_ch(n) >> 3)) * 1024u);
+        i32x4 x;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(x) : "v"(lane16), "s"(wdesc), "s"(so) : "memory");
+        dst = make_float4(__int_as_float(x.x), __int_as_float(x.y), __int_as_float(x.z), __int_as_float(x.w));
+    };
+
+    f32x16 acc[18];
+#pragma unroll
+    for (int pp = 0; pp < 18; ++pp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
+
+    // prologue: patches of steps 0 and 1, weights of step 0
+    dma_patch(0);
+    if (N > 1) dma_patch(1);
+    float4 wr[18];
+#pragma unroll
+    for (int pp = 0; pp < 18; ++pp) wload(wr[pp], pp, 0);
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");           // the DMA pieces are older than the 18 weight requests
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int vfo = li * W4VROW + lh * 16;                       // this lane's float4 of a V row (M phase)
+    bool n_next_w2 = false;                                      // row 2's weights are still to be requested for the coming step
+#pragma unroll 1
+    for (int n = 0; n < N; ++n) {
+        // ================= T(n): B^T d B of this thread's (tile, channel) =========================================================
+#ifndef W4_ABL
+#define W4_ABL 0
+#endif
+        if (n_next_w2 && !(W4_ABL & 8)) {          // row 2's weights of this step (their registers were in use to the end of the last M phase)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) wload(wr[12 + j], 12 + j, n);
+        }
+        if (!(W4_ABL & 1)) {
+            const unsigned char* pb = lds4 + (n & 1) * W4PATCH;
+            unsigned char* vb = lds4 + W4V0 + (n & 1) * W4V + tvoff;
+            float d[6][6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int o = W4PW * a + b;                  // compile-time
+                    d[a][b] = *reinterpret_cast<const float*>(pb + ty[o & 3][(o >> 2) & 3] + 32 * (o & ~3));
+                }
+            float r[6][6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+                W4_BT(d[0][b], d[1][b], d[2][b], d[3][b], d[4][b], d[5][b], r[0][b], r[1][b], r[2][b], r[3][b], r[4][b], r[5][b]);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float v0, v1, v2, v3, v4, v5;
+                W4_BT(r[i][0], r[i][1], r[i][2], r[i][3], r[i][4], r[i][5], v0, v1, v2, v3, v4, v5);
+                *reinterpret_cast<float*>(vb + (6 * i + 0) * W4VPOS) = v0;
+                *reinterpret_cast<float*>(vb + (6 * i + 1) * W4VPOS) = v1;
+                *reinterpret_cast<float*>(vb + (6 * i + 2) * W4VPOS) = v2;
+                *reinterpret_cast<float*>(vb + (6 * i + 3) * W4VPOS) = v3;
+                *reinterpret_cast<float*>(vb + (6 * i + 4) * W4VPOS) = v4;
+                *reinterpret_cast<float*>(vb + (6 * i + 5) * W4VPOS) = v5;
+            }
+        }
+        // every DMA piece of patch n + 1 (issued before the 18 weight requests of the previous M phase) has landed
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= M(n): 18 positions x 4 MFMAs of this wave =================================================================
+        // One wave per SIMD issues in order: a memory instruction placed BEHIND a block of MFMAs is issued only once the block has
+        // been issued, and the next MFMA waits for it -- measured (ablations): the 18 weight reloads of a step cost 1570 cycles, the
+        // 5 DMA pieces 970, of an 8000-cycle step with 4608 cycles of MFMA issue.  So every memory instruction of the step is placed
+        // right behind ONE MFMA (whose 64 pipe cycles cover its issue): the V fragments of row r + 1 and the DMA pieces of patch
+        // n + 2 (buffer n & 1: free, every wave is past T(n)) inside row 0, the reloads of row r - 1's weights inside row r; row 2's
+        // weights are re-requested at the top of the next T phase, under its LDS reads.  VMEM order: DMA pieces, then 18 reloads.
+        {
+            const unsigned char* vb = lds4 + W4V0 + (n & 1) * W4V + 18 * h * W4VPOS + vfo;
+            float4 vf[2][6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vf[0][j] = *reinterpret_cast<const float4*>(vb + j * W4VPOS);
+            const bool more = n + 1 < N, dma = n + 2 < N && !(W4_ABL & 4);
+            const unsigned dsoff = __builtin_amdgcn_readfirstlane((unsigned)step_ch(n + 2 < N ? n + 2 : n) * 4u);
+            const unsigned ddst = lds0 + (unsigned)((n & 1) * W4PATCH) + 1024u * (unsigned)w;
+            auto mma = [&](int pp, float a, float bq) __attribute__((always_inline)) {
+                // 18 accumulator tiles are 288 registers, 32 more than the accumulator file: tiles 16 and 17 are PINNED in VGPRs (asm
+                // operand class "v"), the other sixteen fill the 256 AGPRs (left to itself hipcc shuffles accumulators between the files)
+                if (pp < 16) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[pp], 0, 0, 0);
+                else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pp]) : "v"(a), "v"(bq));
+            };
+            const bool steady = n + 2 < N;         // both the DMA of row 0 and the reloads of rows 1 / 2 are issued in this step
+#pragma unroll
+            for (int r3 = 0; r3 < 3; ++r3) {
+                // this row's weights have landed once at most the younger requests are outstanding: row 0: W1 W2 = 12; row 1: W2 + the 5
+                // DMA pieces = 11; row 2: the DMA pieces + W0(n + 1) = 11.  The last two steps (no DMA / no reloads) just drain.
+                if (steady) {
+                    if (r3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int slot = 0; slot < 24; ++slot) {
+                    const int c = slot / 6, j = slot % 6, pp = 6 * r3 + j;
+                    const float4 wv = wr[pp], bv = vf[r3 & 1][j];
+                    if (!(W4_ABL & 2)) mma(pp, c == 0 ? wv.x : c == 1 ? wv.y : c == 2 ? wv.z : wv.w, c == 0 ? bv.x : c == 1 ? bv.y : c == 2 ? bv.z : bv.w);
+                    if ((slot & 3) == 0 && r3 + 1 < 3)            // V fragment slot / 4 of the next row
+                        vf[(r3 + 1) & 1][slot >> 2] = *reinterpret_cast<const float4*>(vb + (6 * (r3 + 1) + (slot >> 2)) * W4VPOS);
+                    if ((slot & 3) == 2) {
+                        const int k = slot >> 2;
+                        if (r3 == 0) {
+                            if (dma && k < W4DS) {                // DMA piece w + 4 k of patch n + 2
+                                const unsigned dst = __builtin_amdgcn_readfirstlane(ddst + 4096u * (unsigned)k);
+                                unsigned keep;
+                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                                             : "=&s"(keep) : "v"(goff[k]), "s"(dst), "s"(desc), "s"(dsoff) : "memory");
+                            }
+                        } else if (more && !(W4_ABL & 8)) {
+                            wload(wr[6 * (r3 - 1) + k], 6 * (r3 - 1) + k, n + 1);     // the previous row's weights: all four components issued
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        n_next_w2 = n + 1 < N;
+    }
+    __syncthreads();                             // every wave is done with V and the patches
+
+    // ---- output transform.  A^T along j in registers: t[r][x]; row half: part[y][x] = sum over this wave's rows A^T[y][3h + r] t[r][x];
+    // the wave keeps y = 2h, 2h + 1 and hands y = 2 (1 - h), 2 (1 - h) + 1 to its partner (same nt) through LDS.
+    //   xch[w][k = 2 (y & 1) + ... ][q][lane]: k = 4 (y & 1) + x
+    float4* xch = reinterpret_cast<float4*>(lds4);
+    f32x16 own[2][4];                            // part[y = 2h + yy][x]
+    {
+        f32x16 tt[3][4];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const f32x16 &m0 = acc[6 * r], &m1 = acc[6 * r + 1], &m2 = acc[6 * r + 2], &m3 = acc[6 * r + 3], &m4 = acc[6 * r + 4], &m5 = acc[6 * r + 5];
+            const f32x16 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            tt[r][0] = m0 + s1 + s2;
+            tt[r][1] = d1 + 2.f * d2;
+            tt[r][2] = s1 + 4.f * s2;
+            tt[r][3] = d1 + 8.f * d2 + m5;
+        }
+        // A^T columns of this wave's rows: h = 0: i = 0, 1, 2 -> y0: 1 1 1, y1: 0 1 -1, y2: 0 1 1, y3: 0 1 -1
+        //                                  h = 1: i = 3, 4, 5 -> y0: 1 1 0, y1: 2 -2 0, y2: 4 4 0, y3: 8 -8 1
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            f32x16 py0, py1, py2, py3;
+            if (h == 0) {
+                py0 = tt[0][x] + tt[1][x] + tt[2][x];
+                py1 = tt[1][x] - tt[2][x];
+                py2 = tt[1][x] + tt[2][x];
+                py3 = py1;
+            } else {
+                const f32x16 s = tt[0][x] + tt[1][x], dd = tt[0][x] - tt[1][x];
+                py0 = s;
+                py1 = 2.f * dd;
+                py2 = 4.f * s;
+                py3 = 8.f * dd + tt[2][x];
+            }
+            // keep y = 2h, 2h + 1; send the other two
+            const f32x16 keep0 = h == 0 ? py0 : py2, keep1 = h == 0 ? py1 : py3;
+            const f32x16 send0 = h == 0 ? py2 : py0, send1 = h == 0 ? py3 : py1;
+            own[0][x] = keep0;
+            own[1][x] = keep1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xch[((w * 8 + x) * 4 + q) * 64 + lane] = make_float4(send0[4 * q], send0[4 * q + 1], send0[4 * q + 2], send0[4 * q + 3]);
+                xch[((w * 8 + 4 + x) * 4 + q) * 64 + lane] = make_float4(send1[4 * q], send1[4 * q + 1], send1[4 * q + 2], send1[4 * q + 3]);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int pw = w ^ 2;                    // partner: same nt, other row half
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
+        const int tyw = li >> 3, txw = li & 7;
+        float4 bias4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int y = ty0 + 4 * tyw + 2 * h + yy, xx = tx0 + 4 * txw + x;
+                const bool ok = y < p.H && xx < p.W;
+                const unsigned pix = img_off + (unsigned)(y * p.W + xx) * (unsigned)p.ldx * 4u + (unsigned)(p.col_out + 32 * nt + 4 * lh) * 4u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 o = xch[((pw * 8 + 4 * yy + x) * 4 + q) * 64 + lane];
+                    float4 v;
+                    v.x = fmaxf(own[yy][x][4 * q] + o.x + bias4[q].x, 0.f);
+                    v.y = fmaxf(own[yy][x][4 * q + 1] + o.y + bias4[q].y, 0.f);
+                    v.z = fmaxf(own[yy][x][4 * q + 2] + o.z + bias4[q].z, 0.f);
+                    v.w = fmaxf(own[yy][x][4 * q + 3] + o.w + bias4[q].w, 0.f);
+                    i32x4 iv;
+                    iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(iv, ors, (int)(ok ? pix + (unsigned)q * 32u : kOobW4), 0, 0);
+                }
+            }
+    }
+}
+
+int dense_wino4_tiles(int H, int W) { return ceil_div(H, W4TH) * ceil_div(W, W4TW); }
+
+// dense layer l of a block in Winograd F(4x4, 3x3) form; frag_wino4 = 36 fragment arrays of the transformed weights (encoder_hip.py)
+int dense_layer_wino4_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino4, const float* bias, int n_img, hipStream_t s) {
+    CIAOSR_CHECK_ARG(X && frag_wino4 && bias && (ldx & 3) == 0 && aligned16(X) && aligned16(frag_wino4) && aligned16(bias));
+    const size_t x_bytes = (size_t)n_img * H * W * ldx * 4;
+    CIAOSR_CHECK_ARG(n_img >= 1 && n_img <= 65535 && x_bytes < 0xFFFFFF00ull);
+    DenseWino4P p;
+    p.x = X; p.ldx = ldx; p.x_bytes = (unsigned)x_bytes;
+    p.H = H; p.W = W; p.tiles_x = ceil_div(W, W4TW);
+    p.groups = l + 1;
+    p.wf = reinterpret_cast<const float4*>(frag_wino4);
+    p.nj = 64 * (l + 1) / 8;
+    p.pos_stride = (long)2 * p.nj * 64;
+    p.bias = bias;
+    p.col_out = 64 * (l + 1);
+    CIAOSR_CHECK_ARG((size_t)36 * p.pos_stride * 16 < 0xFFFFFF00ull);
+    CIAOSR_BIG_LDS(dense_wino4_f32_kernel, kWino4Lds);
+    ProfScope prof("enc_dense_wino4", s);
+    hipLaunchKernelGGL(dense_wino4_f32_kernel, dim3(dense_wino4_tiles(H, W), n_img), dim3(256), kWino4Lds, s, p);
+    return launch_status("dense_wino4_f32");
+}
+
+}  // namespace ciaosr

@@ -140,8 +140,12 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
     bool dense32 = fits32 && !dense16 && C == 64 && G == 64 && min_tiles > 0 && dense_f32_tiles(H, W) >= min_tiles;
     for (int i = 0; i < NB * NL && dense32; ++i) dense32 = w->dense[i].frag != nullptr;
     // ... in Winograd F(2x2, 3x3) form when the transformed weights are there (2.25x fewer MFMAs; dense_wino_f32.hip)
-    bool wino32 = dense32 && !(opt && opt->dense_direct);
+    const int dd = opt ? opt->dense_direct : 0;       // 0 = best Winograd form available, 1 = direct, 2 = F(2x2)
+    bool wino32 = dense32 && dd != 1;
     for (int i = 0; i < NB * NL && wino32; ++i) wino32 = w->dense[i].frag_wino != nullptr;
+    // ... or F(4x4, 3x3): 4x fewer MFMAs than the direct form (dense_wino4_f32.hip)
+    bool wino4 = dense32 && dd == 0;
+    for (int i = 0; i < NB * NL && wino4; ++i) wino4 = w->dense[i].frag_wino4 != nullptr;
     // f16 mode: the local feature fusion (1x1 over the block's 576 channels) too reads the 16-bit copy of the block buffer, on the
     // 16-bit GEMM with bias + residual in its epilogue; the dense layers then need no fp32 copy of their outputs, and the epilogue
     // writes the next block's 16-bit input group.  (bf16 mode keeps the fp32 lff: its weights would need the hi + lo pair.)
@@ -193,7 +197,8 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
             for (int l = 0; l < NL; ++l) {
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
-                if (wino32) RUN(dense_layer_wino_f32(x, cb, H, W, l, c.frag_wino, c.bias, B, s));
+                if (wino4) RUN(dense_layer_wino4_f32(x, cb, H, W, l, c.frag_wino4, c.bias, B, s));
+                else if (wino32) RUN(dense_layer_wino_f32(x, cb, H, W, l, c.frag_wino, c.bias, B, s));
                 else RUN(dense_layer_f32(x, cb, H, W, l, c.frag, c.bias, B, s));
             }
         } else if (w->scatter_weight && w->scatter_bias && C == 64 && G == 64) {

@@ -237,7 +237,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
         const bool table16 = bf16 && !x3 && (p.D & 7) == 0;
         if (table16) RUN(transpose_cast_h16(w->k.weight[last], w->k.ld[last], p.D, 256, W5T, prec == kF16, s));
         // fp32, C = 64: nine Winograd convolutions of the product maps Pi_o = F . shift_o(F) (same sums as the GEMM rows below,
-        // re-associated through the transform; 20x fewer multiplies).  The maps live where the GEMM would keep its row chunk.
+        // re-associated through the transform; 2.25x fewer multiplies).  The maps live where the GEMM would keep its row chunk.
         const bool table_wino = (prec == kF32 || x3) && w->k_out_wino && !(route & CIAOSR_HEAD_TABLE_GEMM) && p.C == 64 && !w->no_unfold &&
                                 p.HW >= 512 && p.HW <= kQkChunk;
         if (table_wino) {

@@ -47,6 +47,21 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False, widen=None
     st.frag16_lo = None
     st.frag = None
     st.frag_wino = None
+    st.frag_wino4 = None
+    if frag16 and kh == 3 and co == 64 and ci % 64 == 0:
+        # Winograd F(4x4, 3x3) form (dense_wino4_f32.hip): U = G g G^T with the 6x3 G of F(4, 3), in fp64, rounded once; position
+        # p = 6 i + j as its own [co][ci] matrix in MFMA fragment order, the 36 arrays back to back
+        G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                           [0, 0, 1]], dtype=torch.float64, device=w.device)
+        g4 = w.view(co, 3, 3, ci).double()
+        U4 = torch.einsum('ia,oabc,jb->ijoc', G4, g4, G4).float().contiguous()           # [6][6][co][ci]
+        nfl4 = _lib.load().ciaosr_fragment_floats(co, ci)
+        fw4 = torch.empty(36 * nfl4, dtype=torch.float32, device=w.device)
+        for pos in range(36):
+            up = U4[pos // 6, pos % 6]
+            _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(up), ci, co, ci, C.c_void_p(fw4.data_ptr() + 4 * pos * nfl4), hip_ops.stream_ptr())
+        keep += [fw4]
+        st.frag_wino4 = fw4.data_ptr()
     if frag16 and kh == 3 and co == 64 and ci % 64 == 0:
         # Winograd F(2x2, 3x3) form of the weights for the fp32 big-map kernel (dense_wino_f32.hip): U = G g G^T per (co, ci), in
         # fp64, rounded once; position p = 4 i + j as its own [co][ci] matrix in MFMA fragment order, the 16 arrays back to back

@@ -84,9 +84,10 @@ typedef struct ciaosr_options {
                              * lo = bf16(w - hi): 16 mantissa bits, two MFMAs per product); 1 = hi only (one MFMA, 8 bits).
                              * Rounding WEIGHTS to 8 bits is a fixed perturbation whose response is spatially coherent and
                              * fails the 0.01 dB PSNR gate on smooth features; activations stay single bf16 */
-    int dense_direct;       /* _f32 RDN trunk, big maps: 0 (default) = dense layers in Winograd F(2x2, 3x3) form when ciaosr_conv_t.frag_wino
-                             * is given (fp32 arithmetic on transformed operands: not bitwise a direct convolution, within 1e-5 of it);
-                             * 1 = the direct halo-resident kernel (exact fmaf chains, 2.8x the MFMA cycles) */
+    int dense_direct;       /* _f32 RDN trunk, big maps: 0 (default) = dense layers in Winograd form -- F(4x4, 3x3) when ciaosr_conv_t.frag_wino4
+                             * is given, else F(2x2, 3x3) when frag_wino is (fp32 arithmetic on transformed operands: not bitwise a direct
+                             * convolution; the trunk stays within 2e-4 x its scale of the direct form, tests/test_hip_parity.py);
+                             * 1 = the direct halo-resident kernel (exact fmaf chains); 2 = F(2x2, 3x3) even when frag_wino4 is given */
     int csa_scores_gemm;    /* _f32 cs_attn with 32 match channels: 0 (default) = correlation scores as a 3x3 diagonal box sum of the
                              * per-pixel correlation (K = 32, no patch rows); 1 = the 288-wide patch-row GEMM.  Same fp32 products, other order */
     int reserved[2];        /* must be 0 (checked by every entry point that takes the struct: a non-zero word is CIAOSR_ERR_BAD_ARG) */
@@ -323,6 +324,9 @@ typedef struct ciaosr_conv {
                           * U[p] = (G g G^T)[p], p = 4 i + j = 0..15, each [cout][cin] matrix packed by ciaosr_pack_fragments_f32, the 16
                           * arrays back to back; lets ciaosr_rdn_forward_f32 run the dense layers of big maps with 2.25x fewer MFMAs
                           * (dense_wino_f32.hip).  NULL = the direct halo-resident kernel (`frag`) */
+    const float* frag_wino4; /* optional (same layers): the Winograd F(4x4, 3x3) form, U[p] = (G g G^T)[p], p = 6 i + j = 0..35, each
+                          * [cout][cin] matrix packed by ciaosr_pack_fragments_f32, the 36 arrays back to back (dense_wino4_f32.hip: 4x fewer
+                          * MFMAs than the direct form); preferred over frag_wino when given, see ciaosr_options_t.dense_direct */
 } ciaosr_conv_t;
 
 typedef struct ciaosr_rdn_weights {

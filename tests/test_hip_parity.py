@@ -648,13 +648,18 @@ def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw):
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() < 2e-4 * max(scale, 1.0), ((got - want).abs().max().item(), scale)
     assert (got - scatter).abs().max().item() < 2e-4 * max(scale, 1.0)
-    # the default big-map route: the same layers in Winograd F(2x2, 3x3) form (dense_wino_f32.hip; ragged 8x16 tiles here)
+    # the same layers in Winograd F(2x2, 3x3) form (dense_wino_f32.hip; ragged 8x16 tiles here) ...
     with hip_ops.profile():
-        wino = gen.gen_feature(x.to(dev), hip_ops.Options(dense_min_tiles=1))[0].cpu()
-    assert 'enc_dense_wino' in hip_ops.profile.results(), 'Winograd fp32 dense kernel did not run'
-    ew, ed = (wino - want).abs().max().item(), (got - want).abs().max().item()
-    print(f'rdn trunk {hw}: max|d| vs oracle: winograd {ew:.3e}, direct {ed:.3e} (scale {scale:.3f})')
+        wino = gen.gen_feature(x.to(dev), hip_ops.Options(dense_min_tiles=1, dense_direct=2))[0].cpu()
+    assert 'enc_dense_wino' in hip_ops.profile.results(), 'Winograd F(2x2) fp32 dense kernel did not run'
+    # ... and in F(4x4, 3x3) form, the default big-map route (dense_wino4_f32.hip; ragged 16x32 tiles here)
+    with hip_ops.profile():
+        wino4 = gen.gen_feature(x.to(dev), hip_ops.Options(dense_min_tiles=1))[0].cpu()
+    assert 'enc_dense_wino4' in hip_ops.profile.results() and 'enc_dense_wino' not in hip_ops.profile.results()
+    ew, e4, ed = (wino - want).abs().max().item(), (wino4 - want).abs().max().item(), (got - want).abs().max().item()
+    print(f'rdn trunk {hw}: max|d| vs oracle: F(4x4) {e4:.3e}, F(2x2) {ew:.3e}, direct {ed:.3e} (scale {scale:.3f})')
     assert ew < 2e-4 * max(scale, 1.0), (ew, scale)
+    assert e4 < 2e-4 * max(scale, 1.0), (e4, scale)
     # third implementation of the same layers: the generic tap-major convolution in scatter form (conv_f32.hip)
     generic = gen.gen_feature(x.to(dev), hip_ops.Options(scatter_small_max=-1))[0].cpu()
     assert (generic - want).abs().max().item() < 2e-4 * max(scale, 1.0)
@@ -871,7 +876,7 @@ def _tile192_checks(out, fx, tol):
     return errs
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'fp32-direct', 'bf16', 'bf16-single', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'])
+@pytest.mark.parametrize('precision', ['fp32', 'fp32-wino2', 'fp32-direct', 'bf16', 'bf16-single', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'])
 def test_e2e_full_c3_tile_vs_reference(dev, precision):
     """One full C3 tile: 192x192 LR -> 768x768 through CiaoSR.forward_test (clip_test with one tile; RDN trunk on the
     halo-resident dense kernels, cs_attn on the composed tail, 589 824 queries = 20 reference eval_bsize chunks) against
@@ -908,18 +913,18 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     assert sha == str(fx['sha'])
     model = model.to(dev)
     lq, gt = synthetic_pair(192, 192, 4)
-    opt = {'fp32': hip_ops.Options('fp32'), 'fp32-direct': hip_ops.Options('fp32', dense_direct=1), 'bf16': hip_ops.Options('bf16'),
+    opt = {'fp32': hip_ops.Options('fp32'), 'fp32-wino2': hip_ops.Options('fp32', dense_direct=2), 'fp32-direct': hip_ops.Options('fp32', dense_direct=1), 'bf16': hip_ops.Options('bf16'),
            'bf16-single': hip_ops.Options('bf16', bf16_single=1), 'f16': hip_ops.Options('f16'),
            'f16-pairs': hip_ops.Options('f16-pairs'), 'f16x3': hip_ops.Options('f16x3'), 'f16x3-fast': hip_ops.Options('f16x3-fast')}[precision]
     with hip_ops.profile():
         out = model.restore(lq.to(dev), options=opt).cpu()
     prof = hip_ops.profile.results()
     if precision in ('f16x3', 'f16x3-fast'):
-        for tag in ('enc_dense_wino' if precision == 'f16x3' else 'enc_dense_f16', 'csa_attn_v_f16', 'csa_scores_f16', 'head_logit_table',
+        for tag in ('enc_dense_wino4' if precision == 'f16x3' else 'enc_dense_f16', 'csa_attn_v_f16', 'csa_scores_f16', 'head_logit_table',
                     'head_kv_fused_f16x3', 'head_decode_fused_f16x3'):
             assert tag in prof, (tag, sorted(prof))
-    elif precision in ('fp32', 'fp32-direct'):
-        for tag in ('enc_dense_wino' if precision == 'fp32' else 'enc_dense_gather', 'csa_attn_v_edge', 'head_logit_table'):
+    elif precision in ('fp32', 'fp32-wino2', 'fp32-direct'):
+        for tag in ({'fp32': 'enc_dense_wino4', 'fp32-wino2': 'enc_dense_wino', 'fp32-direct': 'enc_dense_gather'}[precision], 'csa_attn_v_edge', 'head_logit_table'):
             assert tag in prof, (tag, sorted(prof))
     else:
         sfx = '_f16' if precision.startswith('f16') else '_bf16'
@@ -942,7 +947,7 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
     d_psnr30 = abs(psnr30(got_s4) - psnr30(ref_s4))
     print(f'tile192 {precision}: max|d| {errs}, rms|d| {rms:.3e}, PSNR(build,GT) {psnr_build:.4f} vs ref {float(fx["psnr_ref_gt"]):.4f} '
           f'(delta {d_psnr:.5f} dB), at 30 dB: PSNR(ref,GT\') {psnr30(ref_s4):.3f}, delta {d_psnr30:.5f} dB, |mean delta| {mean_err:.2e}')
-    if precision in ('fp32', 'fp32-direct'):        # default = Winograd dense layers; 'fp32-direct' = the direct kernel (dense_direct=1)
+    if precision in ('fp32', 'fp32-wino2', 'fp32-direct'):   # default = Winograd F(4x4) dense layers; 'fp32-wino2' = F(2x2); 'fp32-direct' = the direct kernel
         assert d_psnr <= 0.01 and d_psnr30 <= 0.001, (d_psnr, d_psnr30)
         assert max(errs.values()) < NORTH_STAR_TOL, errs
         assert mean_err < 1e-5 and rms < 1e-5, (mean_err, rms)
@@ -1064,7 +1069,7 @@ def test_encoder_batch_beyond_32bit_offsets_runs_as_sub_batches(dev, precision):
     x = (randn((8, 3, 368, 368), 5) * 0.25).to(dev)
     with hip_ops.profile():
         feats = enc.forward_hwc_batch(x, opt)
-    assert ('enc_dense_wino' if precision == 'fp32' else 'enc_dense_f16') in hip_ops.profile.results()
+    assert ('enc_dense_wino4' if precision == 'fp32' else 'enc_dense_f16') in hip_ops.profile.results()
     assert feats.shape == (8, 368, 368, 64) and bool(torch.isfinite(feats).all())
     for i in (0, 6, 7):
         assert torch.equal(feats[i], enc.forward_hwc(x[i], opt)), i
