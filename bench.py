@@ -327,7 +327,7 @@ def main():
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
                          'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product); f16x3: the fp32-tolerance '
                          'fast mode -- head weights AND activations as half pairs (three MFMAs per product), fp32 trunk and tables')
-    ap.add_argument('--tile-batch', type=int, default=0, help='developer: test_cfg.tile_batch (0 = the default 8)')
+    ap.add_argument('--tile-batch', type=int, default=0, help='developer: test_cfg.tile_batch (0 = the default: 7 with the fp32 trunk, else 8)')
     ap.add_argument('--encoder-ahead', action='store_true', help='test_cfg.encoder_ahead: trunk of the next tile batch on a side stream under the heads of the current one (bitwise the same image; per-kernel timings then overlap)')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')

@@ -27,10 +27,12 @@
 //   * V and the patch are double-buffered, which leaves ONE barrier per step (T(n) | barrier | M(n), T(n+1) | barrier | ...).
 // The output transform runs once per layer: A^T along j in registers, the row half through LDS between the two waves of a channel half.
 #include "ops.h"
+#include <type_traits>
 
 namespace ciaosr {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int W4TH = 16, W4TW = 32;              // output tile (pixels)
@@ -38,12 +40,15 @@ constexpr int W4PH = W4TH + 2, W4PW = W4TW + 2;  // patch with the 1-pixel halo
 constexpr int W4NP = W4PH * W4PW;                // 612 pixels
 constexpr int W4PIECES = (2 * W4NP + 63) / 64;   // 20 DMA pieces of 64 chunks (16 B each)
 constexpr int W4PATCH = W4PIECES * 1024;         // 20 480 B per buffer
-constexpr int W4VROW = 48;                       // bytes per (position, tile) row of V: 8 channels + 16 B of padding (conflict-free b128 reads)
-constexpr int W4VPOS = 32 * W4VROW;              // 1536
-constexpr int W4V = 36 * W4VPOS;                 // 55 296 B per buffer
+constexpr int W4VROW = 32;                       // bytes per (position, tile) row of V: 8 channels = two 16-B chunks; chunk (2 tile + half) is kept at
+                                                 // chunk ^ ((tile >> 3) & 1): the M phase's b128 reads (16 lanes = 16 tiles of one half per pass)
+                                                 // and the T phase's dword writes (8 tiles x 8 channels per wave) both touch every bank once
+constexpr int W4VPOS = 32 * W4VROW;              // 1024
+constexpr int W4V = 36 * W4VPOS;                 // 36 864 B per buffer
 constexpr int W4V0 = 2 * W4PATCH;                // LDS: [patch 0][patch 1][V 0][V 1]
-constexpr size_t kWino4Lds = 2 * (size_t)W4PATCH + 2 * (size_t)W4V;      // 151 552 B
-static_assert(4 * 8 * 4 * 64 * 16 <= kWino4Lds, "output-transform exchange must fit");
+constexpr size_t kWino4Xch = 4 * 8 * 4 * 64 * 16;                        // output-transform exchange: 131 072 B
+constexpr size_t kWino4Loop = 2 * (size_t)W4PATCH + 2 * (size_t)W4V;     // 114 688 B
+constexpr size_t kWino4Lds = kWino4Loop > kWino4Xch ? kWino4Loop : kWino4Xch;
 constexpr unsigned kOobW4 = 0xFFFFFFF0u;
 
 struct DenseWino4P {
@@ -70,8 +75,21 @@ struct DenseWino4P {
         y5 = __builtin_fmaf(4.f, x1, __builtin_fmaf(-5.f, x3, x5));                   \
     } while (0)
 
+#ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/wino4_probe.py): s_memtime stamps of the last launch's workgroups
+__device__ unsigned long long g_w4probe[1024 * 8];
+#define W4PROBE(slot) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) g_w4probe[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#define W4PROBE_ADD(slot, t0) do { w4acc##slot += __builtin_readcyclecounter() - (t0); } while (0)
+#else
+#define W4PROBE(slot) do { } while (0)
+#define W4PROBE_ADD(slot, t0) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds4[];
+    W4PROBE(0);
+#ifdef CIAOSR_PROBE
+    unsigned long long w4acc5 = 0, w4acc6 = 0;
+#endif
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
     const int nt = w & 1, h = w >> 1;            // M phase: output-channel half, rows 3h .. 3h+2 of the 6x6 transformed domain
     const int ty0 = (blockIdx.x / p.tiles_x) * W4TH, tx0 = (blockIdx.x % p.tiles_x) * W4TW;
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) ty[m][c] = tbase + 32 * (m ^ ((k0 + c) & 3));
     }
-    const int tvoff = ttile * W4VROW + tch * 4;                 // + pos * 1536: this thread's element of V
+    const int tvoff = ((2 * ttile + (tch >> 2)) ^ ((ttile >> 3) & 1)) * 16 + (tch & 3) * 4;     // + pos * 1024: this thread's element of V
 
     // ---- weights: fragment (position 18 h + pp, nt) of k-chunk jc, through a buffer descriptor with the fragment index as scalar offset.
     // The loads are INLINE ASM and their waits are counted by hand: hipcc cannot see the patch DMA (asm as well) in the vector-memory
@@ -136,53 +154,57 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     const i32x4 wdesc = {(int)(unsigned)(size_t)p.wf, (int)(((size_t)p.wf >> 32) & 0xFFFFu), (int)0xFFFFFFFFu, 0x00020000};
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned pos_bytes = (unsigned)p.pos_stride * 16u;
-    auto wload = [&](float4& dst, int pp, int n) __attribute__((always_inline)) {
+    auto wload = [&](f32x4& dst, int pp, int n) __attribute__((always_inline)) {
         const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(18 * h + pp) * pos_bytes + (unsigned)(nt * p.nj + (step_ch(n) >> 3)) * 1024u);
-        i32x4 x;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(x) : "v"(lane16), "s"(wdesc), "s"(so) : "memory");
-        dst = make_float4(__int_as_float(x.x), __int_as_float(x.y), __int_as_float(x.z), __int_as_float(x.w));
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(lane16), "s"(wdesc), "s"(so) : "memory");
     };
 
+    // prologue: patches of steps 0 and 1, weights of step 0; the accumulators are cleared under their latency
+    dma_patch(0);
+    if (N > 1) dma_patch(1);
+    f32x4 wr[18];
+#pragma unroll
+    for (int pp = 0; pp < 18; ++pp) wload(wr[pp], pp, 0);
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc[18];
 #pragma unroll
     for (int pp = 0; pp < 18; ++pp)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
-
-    // prologue: patches of steps 0 and 1, weights of step 0
-    dma_patch(0);
-    if (N > 1) dma_patch(1);
-    float4 wr[18];
-#pragma unroll
-    for (int pp = 0; pp < 18; ++pp) wload(wr[pp], pp, 0);
     asm volatile("s_waitcnt vmcnt(18)" ::: "memory");           // the DMA pieces are older than the 18 weight requests
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
-    const int vfo = li * W4VROW + lh * 16;                       // this lane's float4 of a V row (M phase)
-    bool n_next_w2 = false;                                      // row 2's weights are still to be requested for the coming step
+    W4PROBE(1);
+    // The 36 window values of this thread's (tile, channel) of step n + 1 are read from the patch DURING M(n), one ds_read behind an
+    // MFMA each (measured: the same reads at the top of the T phase cost 800 of a 6800-cycle step -- LDS latency and the 4 waves'
+    // 2-way bank conflicts with nothing to cover them).  Patch n + 1 has landed by the barrier in front of M(n).
+    float dn[36];
+    auto patch_value = [&](int n, int o36) __attribute__((always_inline)) -> float {
+        const int a = o36 / 6, b = o36 - 6 * a, o = W4PW * a + b;
+        return *reinterpret_cast<const float*>(lds4 + (n & 1) * W4PATCH + ty[o & 3][(o >> 2) & 3] + 32 * (o & ~3));
+    };
+#pragma unroll
+    for (int o36 = 0; o36 < 36; ++o36) dn[o36] = patch_value(0, o36);
+    const int vfo = ((2 * li + lh) ^ ((li >> 3) & 1)) * 16;      // this lane's float4 of a V row (M phase)
 #pragma unroll 1
     for (int n = 0; n < N; ++n) {
         // ================= T(n): B^T d B of this thread's (tile, channel) =========================================================
-#ifndef W4_ABL
-#define W4_ABL 0
+#ifdef CIAOSR_PROBE
+        const unsigned long long tstep = __builtin_readcyclecounter();
 #endif
-        if (n_next_w2 && !(W4_ABL & 8)) {          // row 2's weights of this step (their registers were in use to the end of the last M phase)
+        if (n > 0) {                               // row 2's weights of this step (their registers were in use to the end of the last M phase)
 #pragma unroll
             for (int j = 0; j < 6; ++j) wload(wr[12 + j], 12 + j, n);
         }
-        if (!(W4_ABL & 1)) {
-            const unsigned char* pb = lds4 + (n & 1) * W4PATCH;
+        // (re-requesting five of them in the M phase's last slots instead measured the same step time)
+        {
             unsigned char* vb = lds4 + W4V0 + (n & 1) * W4V + tvoff;
-            float d[6][6];
+            float d[6][6];                                       // read during M(n - 1) (step 0: behind the prologue's barrier)
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int o = W4PW * a + b;                  // compile-time
-                    d[a][b] = *reinterpret_cast<const float*>(pb + ty[o & 3][(o >> 2) & 3] + 32 * (o & ~3));
-                }
+                for (int b = 0; b < 6; ++b) d[a][b] = dn[6 * a + b];
             float r[6][6];
 #pragma unroll
             for (int b = 0; b < 6; ++b)
@@ -201,7 +223,9 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
         }
         // every DMA piece of patch n + 1 (issued before the 18 weight requests of the previous M phase) has landed
         asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        W4PROBE_ADD(5, tstep);                   // T phase up to the barrier
         __syncthreads();
+        W4PROBE_ADD(6, tstep);                   // ... and through it
         __builtin_amdgcn_sched_barrier(0);
         // ================= M(n): 18 positions x 4 MFMAs of this wave =================================================================
         // One wave per SIMD issues in order: a memory instruction placed BEHIND a block of MFMAs is issued only once the block has
@@ -215,8 +239,10 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
             float4 vf[2][6];
 #pragma unroll
             for (int j = 0; j < 6; ++j) vf[0][j] = *reinterpret_cast<const float4*>(vb + j * W4VPOS);
-            const bool more = n + 1 < N, dma = n + 2 < N && !(W4_ABL & 4);
-            const unsigned dsoff = __builtin_amdgcn_readfirstlane((unsigned)step_ch(n + 2 < N ? n + 2 : n) * 4u);
+            // Past the last step the requests repeat step N - 1 (same weights, the same patch into a buffer nobody reads any more): every
+            // step then issues the same 23 vector-memory requests and the waits below are constants.
+            const int n1 = n + 1 < N ? n + 1 : N - 1, n2 = n + 2 < N ? n + 2 : N - 1;
+            const unsigned dsoff = __builtin_amdgcn_readfirstlane((unsigned)step_ch(n2) * 4u);
             const unsigned ddst = lds0 + (unsigned)((n & 1) * W4PATCH) + 1024u * (unsigned)w;
             auto mma = [&](int pp, float a, float bq) __attribute__((always_inline)) {
                 // 18 accumulator tiles are 288 registers, 32 more than the accumulator file: tiles 16 and 17 are PINNED in VGPRs (asm
@@ -224,57 +250,71 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
                 if (pp < 16) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[pp], 0, 0, 0);
                 else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[pp]) : "v"(a), "v"(bq));
             };
-            const bool steady = n + 2 < N;         // both the DMA of row 0 and the reloads of rows 1 / 2 are issued in this step
 #pragma unroll
             for (int r3 = 0; r3 < 3; ++r3) {
                 // this row's weights have landed once at most the younger requests are outstanding: row 0: W1 W2 = 12; row 1: W2 + the 5
-                // DMA pieces = 11; row 2: the DMA pieces + W0(n + 1) = 11.  The last two steps (no DMA / no reloads) just drain.
-                if (steady) {
-                    if (r3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
+                // DMA pieces = 11; row 2: the DMA pieces + W0(n + 1) = 11.
+                if (r3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int slot = 0; slot < 24; ++slot) {
                     const int c = slot / 6, j = slot % 6, pp = 6 * r3 + j;
-                    const float4 wv = wr[pp], bv = vf[r3 & 1][j];
-                    if (!(W4_ABL & 2)) mma(pp, c == 0 ? wv.x : c == 1 ? wv.y : c == 2 ? wv.z : wv.w, c == 0 ? bv.x : c == 1 ? bv.y : c == 2 ? bv.z : bv.w);
+                    const f32x4 wv = wr[pp];
+                    const float4 bv = vf[r3 & 1][j];
+                    mma(pp, c == 0 ? wv.x : c == 1 ? wv.y : c == 2 ? wv.z : wv.w, c == 0 ? bv.x : c == 1 ? bv.y : c == 2 ? bv.z : bv.w);
                     if ((slot & 3) == 0 && r3 + 1 < 3)            // V fragment slot / 4 of the next row
                         vf[(r3 + 1) & 1][slot >> 2] = *reinterpret_cast<const float4*>(vb + (6 * (r3 + 1) + (slot >> 2)) * W4VPOS);
-                    if ((slot & 3) == 2) {
-                        const int k = slot >> 2;
-                        if (r3 == 0) {
-                            if (dma && k < W4DS) {                // DMA piece w + 4 k of patch n + 2
-                                const unsigned dst = __builtin_amdgcn_readfirstlane(ddst + 4096u * (unsigned)k);
-                                unsigned keep;
-                                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                                             : "=&s"(keep) : "v"(goff[k]), "s"(dst), "s"(desc), "s"(dsoff) : "memory");
-                            }
-                        } else if (more && !(W4_ABL & 8)) {
-                            wload(wr[6 * (r3 - 1) + k], 6 * (r3 - 1) + k, n + 1);     // the previous row's weights: all four components issued
-                        }
+                    // window values of step n + 1: the odd slots of rows 0 and 1, the first 12 slots of row 2 that carry no reload -- the
+                    // last one is issued 8 MFMAs before the T phase that uses it (past the end: a stale buffer, unused)
+                    if (r3 < 2) {
+                        if (slot & 1) dn[12 * r3 + (slot >> 1)] = patch_value(n + 1, 12 * r3 + (slot >> 1));
+                    } else if (slot < 18 && slot % 3 != 2) {
+                        dn[24 + 2 * (slot / 3) + slot % 3] = patch_value(n + 1, 24 + 2 * (slot / 3) + slot % 3);
                     }
+                    if (r3 == 0 && (slot & 3) == 2 && (slot >> 2) < W4DS) {           // DMA piece w + 4 k of patch n + 2
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ddst + 4096u * (unsigned)(slot >> 2));
+                        unsigned keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep) : "v"(goff[slot >> 2]), "s"(dst), "s"(desc), "s"(dsoff) : "memory");
+                    }
+                    // weights of step n + 1, each register re-requested at least 8 MFMAs behind its last use: row 0's inside row 1, row 1's in
+                    // the first 18 slots of row 2; row 2's own at the top of the next T phase
+                    if (r3 == 1 && (slot & 3) == 2) wload(wr[slot >> 2], slot >> 2, n1);
+                    if (r3 == 2 && slot < 18 && slot % 3 == 2) wload(wr[6 + slot / 3], 6 + slot / 3, n1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            // The repeated requests of the last step must have landed INSIDE the loop.  Behind it the 18 weight registers are dead for
+            // hipcc, which hands them to the output transform's temporaries -- and register-only code moves freely across an asm wait
+            // placed behind the loop, so the late loads landed in the middle of the transform: images that differed from run to run once
+            // a second stream loaded the memory system, and wrong images always when requests sat in the M phase's last slots
+            // (profiles/r4_wino4_inflight_loads.txt).  Nothing of the epilogue can be scheduled into the loop body.
+            if (n + 1 == N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        n_next_w2 = n + 1 < N;
     }
+    W4PROBE(2);
+#ifdef CIAOSR_PROBE
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 1024) { g_w4probe[blockIdx.x * 8 + 5] = w4acc5; g_w4probe[blockIdx.x * 8 + 6] = w4acc6; }
+#endif
     __syncthreads();                             // every wave is done with V and the patches
 
     // ---- output transform.  A^T along j in registers: t[r][x]; row half: part[y][x] = sum over this wave's rows A^T[y][3h + r] t[r][x];
     // the wave keeps y = 2h, 2h + 1 and hands y = 2 (1 - h), 2 (1 - h) + 1 to its partner (same nt) through LDS.
     //   xch[w][k = 2 (y & 1) + ... ][q][lane]: k = 4 (y & 1) + x
     float4* xch = reinterpret_cast<float4*>(lds4);
-    f32x16 own[2][4];                            // part[y = 2h + yy][x]
-    {
-        f32x16 tt[3][4];
+    // Done in four passes over the accumulators' 4-element groups q (the float4 granularity of the exchange and of the stores): a pass
+    // holds 18 x 4 accumulator values, 12 t values and its 8 kept float4 -- the whole-tile form kept 12 f32x16 t tiles beside the 18
+    // accumulator tiles and spilled 32 registers.
+    f32x4 own[4][2][4];                          // [q][yy][x]: part[y = 2h + yy][x], elements 4q .. 4q+3
+    auto out_pass = [&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        auto grp = [&](const f32x16& v) __attribute__((always_inline)) -> f32x4 { return __builtin_shufflevector(v, v, 4 * q, 4 * q + 1, 4 * q + 2, 4 * q + 3); };
+        f32x4 tt[3][4];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const f32x16 &m0 = acc[6 * r], &m1 = acc[6 * r + 1], &m2 = acc[6 * r + 2], &m3 = acc[6 * r + 3], &m4 = acc[6 * r + 4], &m5 = acc[6 * r + 5];
-            const f32x16 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            const f32x4 m0 = grp(acc[6 * r]), m1 = grp(acc[6 * r + 1]), m2 = grp(acc[6 * r + 2]), m3 = grp(acc[6 * r + 3]), m4 = grp(acc[6 * r + 4]), m5 = grp(acc[6 * r + 5]);
+            const f32x4 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
             tt[r][0] = m0 + s1 + s2;
             tt[r][1] = d1 + 2.f * d2;
             tt[r][2] = s1 + 4.f * s2;
@@ -284,32 +324,26 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
         //                                  h = 1: i = 3, 4, 5 -> y0: 1 1 0, y1: 2 -2 0, y2: 4 4 0, y3: 8 -8 1
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            f32x16 py0, py1, py2, py3;
+            f32x4 keep0, keep1, send0, send1;    // keep y = 2h, 2h + 1; send the other two
             if (h == 0) {
-                py0 = tt[0][x] + tt[1][x] + tt[2][x];
-                py1 = tt[1][x] - tt[2][x];
-                py2 = tt[1][x] + tt[2][x];
-                py3 = py1;
+                const f32x4 d = tt[1][x] - tt[2][x], sm = tt[1][x] + tt[2][x];
+                keep0 = tt[0][x] + sm; keep1 = d; send0 = sm; send1 = d;
             } else {
-                const f32x16 s = tt[0][x] + tt[1][x], dd = tt[0][x] - tt[1][x];
-                py0 = s;
-                py1 = 2.f * dd;
-                py2 = 4.f * s;
-                py3 = 8.f * dd + tt[2][x];
+                const f32x4 sm = tt[0][x] + tt[1][x], d = tt[0][x] - tt[1][x];
+                send0 = sm; send1 = 2.f * d; keep0 = 4.f * sm; keep1 = 8.f * d + tt[2][x];
             }
-            // keep y = 2h, 2h + 1; send the other two
-            const f32x16 keep0 = h == 0 ? py0 : py2, keep1 = h == 0 ? py1 : py3;
-            const f32x16 send0 = h == 0 ? py2 : py0, send1 = h == 0 ? py3 : py1;
-            own[0][x] = keep0;
-            own[1][x] = keep1;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                xch[((w * 8 + x) * 4 + q) * 64 + lane] = make_float4(send0[4 * q], send0[4 * q + 1], send0[4 * q + 2], send0[4 * q + 3]);
-                xch[((w * 8 + 4 + x) * 4 + q) * 64 + lane] = make_float4(send1[4 * q], send1[4 * q + 1], send1[4 * q + 2], send1[4 * q + 3]);
-            }
+            own[q][0][x] = keep0;
+            own[q][1][x] = keep1;
+            xch[((w * 8 + x) * 4 + q) * 64 + lane] = make_float4(send0[0], send0[1], send0[2], send0[3]);
+            xch[((w * 8 + 4 + x) * 4 + q) * 64 + lane] = make_float4(send1[0], send1[1], send1[2], send1[3]);
         }
-    }
+    };
+    out_pass(std::integral_constant<int, 0>{});
+    out_pass(std::integral_constant<int, 1>{});
+    out_pass(std::integral_constant<int, 2>{});
+    out_pass(std::integral_constant<int, 3>{});
     __syncthreads();
+    W4PROBE(3);
     {
         const int pw = w ^ 2;                    // partner: same nt, other row half
         const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
@@ -317,27 +351,40 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
         float4 bias4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
+        // the partner's halves come back through LDS one (yy, x) ahead of the stores that use them
+        float4 o[2][4];
 #pragma unroll
-        for (int yy = 0; yy < 2; ++yy)
+        for (int q = 0; q < 4; ++q) o[0][q] = xch[((pw * 8 + 0) * 4 + q) * 64 + lane];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int y = ty0 + 4 * tyw + 2 * h + yy, xx = tx0 + 4 * txw + x;
-                const bool ok = y < p.H && xx < p.W;
-                const unsigned pix = img_off + (unsigned)(y * p.W + xx) * (unsigned)p.ldx * 4u + (unsigned)(p.col_out + 32 * nt + 4 * lh) * 4u;
+        for (int it = 0; it < 8; ++it) {
+            const int yy = it >> 2, x = it & 3;
+            if (it + 1 < 8) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 o = xch[((pw * 8 + 4 * yy + x) * 4 + q) * 64 + lane];
-                    float4 v;
-                    v.x = fmaxf(own[yy][x][4 * q] + o.x + bias4[q].x, 0.f);
-                    v.y = fmaxf(own[yy][x][4 * q + 1] + o.y + bias4[q].y, 0.f);
-                    v.z = fmaxf(own[yy][x][4 * q + 2] + o.z + bias4[q].z, 0.f);
-                    v.w = fmaxf(own[yy][x][4 * q + 3] + o.w + bias4[q].w, 0.f);
-                    i32x4 iv;
-                    iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
-                    __builtin_amdgcn_raw_buffer_store_b128(iv, ors, (int)(ok ? pix + (unsigned)q * 32u : kOobW4), 0, 0);
-                }
+                for (int q = 0; q < 4; ++q) o[(it + 1) & 1][q] = xch[((pw * 8 + it + 1) * 4 + q) * 64 + lane];
             }
+            const int y = ty0 + 4 * tyw + 2 * h + yy, xx = tx0 + 4 * txw + x;
+            const bool ok = y < p.H && xx < p.W;
+            const unsigned pix = img_off + (unsigned)(y * p.W + xx) * (unsigned)p.ldx * 4u + (unsigned)(p.col_out + 32 * nt + 4 * lh) * 4u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 ov = o[it & 1][q];
+                float4 v;
+                v.x = fmaxf(own[q][yy][x][0] + ov.x + bias4[q].x, 0.f);
+                v.y = fmaxf(own[q][yy][x][1] + ov.y + bias4[q].y, 0.f);
+                v.z = fmaxf(own[q][yy][x][2] + ov.z + bias4[q].z, 0.f);
+                v.w = fmaxf(own[q][yy][x][3] + ov.w + bias4[q].w, 0.f);
+                i32x4 iv;
+                iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
+                __builtin_amdgcn_raw_buffer_store_b128(iv, ors, (int)(ok ? pix + (unsigned)q * 32u : kOobW4), 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    W4PROBE(4);
+#ifdef CIAOSR_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    W4PROBE(7);                                  // stores acknowledged
+#endif
 }
 
 int dense_wino4_tiles(int H, int W) { return ceil_div(H, W4TH) * ceil_div(W, W4TW); }
@@ -364,3 +411,9 @@ int dense_layer_wino4_f32(float* X, int ldx, int H, int W, int l, const float* f
 }
 
 }  // namespace ciaosr
+
+#ifdef CIAOSR_PROBE
+extern "C" int ciaosr_debug_probe_w4_read(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::g_w4probe), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -156,10 +156,10 @@ class CiaoSR(BasicRestorer):
         E = torch.zeros(b, c, h * sf, w * sf, dtype=torch.float32, device=img_lq.device)
         Wt = torch.zeros_like(E)
         n_streams = int(self.test_cfg.get('tile_streams', 1) or 1)
-        n_batch = min(int(self.test_cfg.get('tile_batch', 8) or 1), 16)      # 32-bit buffer offsets into the batched block buffer
+        n_batch = self.tile_batch(options)
         if (tile_fn is None and n_streams <= 1 and n_batch > 1 and b == 1 and len(origins) > 1 and img_lq.is_cuda and
                 hasattr(getattr(self.generator, '_encoder_hip', None), 'forward_hwc_batch')):
-            # `test_cfg.tile_batch` (an extension; default 8) consecutive tiles share the encoder's dense-layer launches; every tile
+            # `test_cfg.tile_batch` (an extension; default 7 or 8, see tile_batch()) consecutive tiles share the encoder's dense-layer launches; every tile
             # is bitwise the one-at-a-time result and the blend order is the reference's
             if self.test_cfg.get('encoder_ahead', False) and getattr(self.generator, '_head', None) is not None:
                 return self._clip_test_encoder_ahead(img_lq, tile, origins, n_batch, sf, E, Wt, options)
@@ -254,6 +254,18 @@ class CiaoSR(BasicRestorer):
         if key not in cache:
             cache[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
         return cache[key]
+
+    def tile_batch(self, options=None):
+        """Tiles per encoder call (`test_cfg.tile_batch`, an extension; at most 16: 32-bit buffer offsets into the batched block buffer).
+        Default 8 -- except where the trunk's dense layers run the F(4x4, 3x3) Winograd kernel (fp32 trunk, dense_direct = 0), whose
+        workgroup covers 16 x 32 pixels: a 192 x 192 tile is 72 workgroups, 8 tiles are 576 = 2.25 rounds of the 256 CUs (a third
+        round at a quarter of the chip), 7 tiles are 504 = 1.97."""
+        v = self.test_cfg.get('tile_batch', None)
+        if v is None:
+            opt = self.options(options)
+            fp32_trunk = opt.precision == 'fp32' or (opt.precision == 'f16' and opt.f16_pairs == 2)       # 'f16x3' keeps the fp32 trunk
+            v = 7 if fp32_trunk and not opt.dense_direct else 8
+        return min(int(v or 1), 16)
 
     def options(self, options=None):
         """The hip_ops.Options a call runs with: the explicit argument if given, else `test_cfg.precision`

@@ -276,7 +276,7 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
     # tile in the driver's order, so sends, receives and the blend order are unchanged.
     gen = restorer.generator
     enc = getattr(gen, '_encoder_hip', None)
-    n_batch = min(int(cfg.get('tile_batch', 8) or 1), 16)
+    n_batch = restorer.tile_batch(opt)
     if (n_batch > 1 and x_norm.is_cuda and x_norm.shape[0] == 1 and enc is not None and hasattr(enc, 'forward_hwc_batch')
             and enc.supported() and getattr(gen, '_head', None) is not None):
         tile_sz, origins = tile_grid(x_norm.shape[-2], x_norm.shape[-1], cfg.get('tile'), cfg.get('tile_overlap'))
