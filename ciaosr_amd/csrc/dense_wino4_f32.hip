@@ -62,6 +62,29 @@ struct DenseWino4P {
     int col_out;
 };
 
+// What goes out behind the MFMA of slot `slot` (0 .. 23) of row r3 (0 .. 2) of an M phase.  Per step and wave: 6 + 6 V fragments (rows 1, 2;
+// row 0's are read in front of the row), 36 window values of the next step, 6 weight requests of row 2 of THIS step, 5 DMA pieces, 12
+// weight requests of rows 0 / 1 of the next step = 71 memory instructions behind 72 MFMAs.  Order constraints: row 2's weights go out
+// BEFORE the DMA pieces (the wait in front of row 2 then does not ask for the patch), a row's weights are re-requested >= 8 MFMAs behind
+// their last use, the last window value is read >= 8 MFMAs before the T phase.
+struct W4Slot { int vfrag, window, w2, dma, wnext; };
+constexpr W4Slot w4_slot_plan(int r3, int slot) {
+    W4Slot s = {-1, -1, -1, -1, -1};
+    if (r3 < 2 && slot % 4 == 0) s.vfrag = slot / 4;                          // rows 0 and 1: 0 4 .. 20
+    if (r3 < 2 && slot % 2 == 1) s.window = 12 * r3 + slot / 2;               // rows 0 and 1: the 12 odd slots -> 0 .. 23
+    if (r3 == 0 && slot < 6) s.w2 = slot;                                     // 0 .. 5
+    if (r3 == 0 && slot >= 6 && slot % 4 == 2) s.dma = (slot - 6) / 4;        // 6 10 14 18 22
+    if (r3 == 1 && slot % 4 == 2) s.wnext = slot / 4;                         // row 0's weights: 2 6 .. 22
+    if (r3 == 2 && slot < 18) {
+        if (slot % 3 == 2) s.wnext = 6 + slot / 3;                            // row 1's weights: 2 5 .. 17
+        else s.window = 24 + 2 * (slot / 3) + slot % 3;                       // 12 slots -> 24 .. 35
+    }
+    return s;
+}
+// (A plan with at most one memory instruction per slot -- row 2's weights on row 0's even slots, the window reads spread over all
+// three rows -- measured 90 cycles per step SLOWER; what an M phase pays for is the vector-memory instruction itself, ~70 cycles each
+// even behind an MFMA: the same six requests cost 340 cycles at the top of the T phase and 440 inside row 0.)
+
 // y = B^T x for the 6-vector x (12 operations)
 #define W4_BT(x0, x1, x2, x3, x4, x5, y0, y1, y2, y3, y4, y5)                          \
     do {                                                                               \
@@ -149,8 +172,11 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     // The loads are INLINE ASM and their waits are counted by hand: hipcc cannot see the patch DMA (asm as well) in the vector-memory
     // queue, and where its own count of the weight loads merges over the loop's paths it falls back to `s_waitcnt vmcnt(0)` in front
     // of an MFMA -- which, vmcnt retiring in order, waits for the DMA pieces issued a few MFMAs earlier to come back from HBM.
-    // Queue order in the steady state (oldest first) at the top of M(n): W0(n) W1(n) W2(n) [6 loads each: rows 0 / 1 / 2 of step n];
-    // row 0 issues the 5 DMA pieces of patch n + 2, row 1 re-requests W0(n + 1), row 2 W1(n + 1), the top of T(n + 1) W2(n + 1).
+    // Queue order in the steady state (oldest first) at the top of M(n): W0(n) W1(n) [6 loads each: rows 0 / 1 of step n]; row 0
+    // requests W2(n) (row 2 of the SAME step: its registers are free since the end of M(n - 1), and two rows = ~3000 cycles cover an L2
+    // round trip) and then the 5 DMA pieces of patch n + 2, row 1 re-requests W0(n + 1), row 2 W1(n + 1).  The T phase carries no
+    // vector-memory request: at its top six of them cost ~340 cycles of issue (one wave per SIMD, nothing to hide them behind), behind
+    // its V writes they filled the 4 waves' shared address unit right in front of the M phase (+450 cycles there).
     const i32x4 wdesc = {(int)(unsigned)(size_t)p.wf, (int)(((size_t)p.wf >> 32) & 0xFFFFu), (int)0xFFFFFFFFu, 0x00020000};
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned pos_bytes = (unsigned)p.pos_stride * 16u;
@@ -164,14 +190,14 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     if (N > 1) dma_patch(1);
     f32x4 wr[18];
 #pragma unroll
-    for (int pp = 0; pp < 18; ++pp) wload(wr[pp], pp, 0);
+    for (int pp = 0; pp < 12; ++pp) wload(wr[pp], pp, 0);       // rows 0 and 1; row 2's are requested inside row 0 of every step
     __builtin_amdgcn_sched_barrier(0);
     f32x16 acc[18];
 #pragma unroll
     for (int pp = 0; pp < 18; ++pp)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
-    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");           // the DMA pieces are older than the 18 weight requests
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");           // the DMA pieces are older than the 12 weight requests
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 
@@ -193,11 +219,6 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
 #ifdef CIAOSR_PROBE
         const unsigned long long tstep = __builtin_readcyclecounter();
 #endif
-        if (n > 0) {                               // row 2's weights of this step (their registers were in use to the end of the last M phase)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) wload(wr[12 + j], 12 + j, n);
-        }
-        // (re-requesting five of them in the M phase's last slots instead measured the same step time)
         {
             unsigned char* vb = lds4 + W4V0 + (n & 1) * W4V + tvoff;
             float d[6][6];                                       // read during M(n - 1) (step 0: behind the prologue's barrier)
@@ -221,8 +242,8 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
                 *reinterpret_cast<float*>(vb + (6 * i + 5) * W4VPOS) = v5;
             }
         }
-        // every DMA piece of patch n + 1 (issued before the 18 weight requests of the previous M phase) has landed
-        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+        // every DMA piece of patch n + 1 (issued before the 12 weight requests of rows 1 and 2 of the previous M phase) has landed
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         W4PROBE_ADD(5, tstep);                   // T phase up to the barrier
         __syncthreads();
         W4PROBE_ADD(6, tstep);                   // ... and through it
@@ -252,9 +273,10 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
             };
 #pragma unroll
             for (int r3 = 0; r3 < 3; ++r3) {
-                // this row's weights have landed once at most the younger requests are outstanding: row 0: W1 W2 = 12; row 1: W2 + the 5
-                // DMA pieces = 11; row 2: the DMA pieces + W0(n + 1) = 11.
-                if (r3 == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                // this row's weights have landed once at most the younger requests are outstanding: row 0: W1 = 6; row 1: row 0's W2 + 5
+                // DMA pieces = 11; row 2: the DMA pieces + W0(n + 1) = 11 (W2 goes out in slots 0 .. 5, AHEAD of the DMA pieces, so that
+                // this wait does not ask for the patch to be back from HBM).
+                if (r3 == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -263,25 +285,20 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
                     const f32x4 wv = wr[pp];
                     const float4 bv = vf[r3 & 1][j];
                     mma(pp, c == 0 ? wv.x : c == 1 ? wv.y : c == 2 ? wv.z : wv.w, c == 0 ? bv.x : c == 1 ? bv.y : c == 2 ? bv.z : bv.w);
-                    if ((slot & 3) == 0 && r3 + 1 < 3)            // V fragment slot / 4 of the next row
-                        vf[(r3 + 1) & 1][slot >> 2] = *reinterpret_cast<const float4*>(vb + (6 * (r3 + 1) + (slot >> 2)) * W4VPOS);
-                    // window values of step n + 1: the odd slots of rows 0 and 1, the first 12 slots of row 2 that carry no reload -- the
-                    // last one is issued 8 MFMAs before the T phase that uses it (past the end: a stale buffer, unused)
-                    if (r3 < 2) {
-                        if (slot & 1) dn[12 * r3 + (slot >> 1)] = patch_value(n + 1, 12 * r3 + (slot >> 1));
-                    } else if (slot < 18 && slot % 3 != 2) {
-                        dn[24 + 2 * (slot / 3) + slot % 3] = patch_value(n + 1, 24 + 2 * (slot / 3) + slot % 3);
-                    }
-                    if (r3 == 0 && (slot & 3) == 2 && (slot >> 2) < W4DS) {           // DMA piece w + 4 k of patch n + 2
-                        const unsigned dst = __builtin_amdgcn_readfirstlane(ddst + 4096u * (unsigned)(slot >> 2));
+                    // ---- the memory instruction(s) of this slot (w4_slot_plan): at most one vector-memory request per slot, and an LDS read
+                    // shares a slot with one only where the table says so
+                    const W4Slot sp = w4_slot_plan(r3, slot);        // folded: both loops are fully unrolled
+                    if (sp.vfrag >= 0)                            // V fragment of the NEXT row
+                        vf[(r3 + 1) & 1][sp.vfrag] = *reinterpret_cast<const float4*>(vb + (6 * (r3 + 1) + sp.vfrag) * W4VPOS);
+                    if (sp.window >= 0) dn[sp.window] = patch_value(n + 1, sp.window);    // window value of step n + 1 (past the end: stale, unused)
+                    if (sp.w2 >= 0) wload(wr[12 + sp.w2], 12 + sp.w2, n);               // row 2's weights of THIS step: two rows to land
+                    if (sp.dma >= 0) {                                                    // DMA piece w + 4 k of patch n + 2
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ddst + 4096u * (unsigned)sp.dma);
                         unsigned keep;
                         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep) : "v"(goff[slot >> 2]), "s"(dst), "s"(desc), "s"(dsoff) : "memory");
+                                     : "=&s"(keep) : "v"(goff[sp.dma]), "s"(dst), "s"(desc), "s"(dsoff) : "memory");
                     }
-                    // weights of step n + 1, each register re-requested at least 8 MFMAs behind its last use: row 0's inside row 1, row 1's in
-                    // the first 18 slots of row 2; row 2's own at the top of the next T phase
-                    if (r3 == 1 && (slot & 3) == 2) wload(wr[slot >> 2], slot >> 2, n1);
-                    if (r3 == 2 && slot < 18 && slot % 3 == 2) wload(wr[6 + slot / 3], 6 + slot / 3, n1);
+                    if (sp.wnext >= 0) wload(wr[sp.wnext], sp.wnext, n1);                // weights of step n + 1, >= 8 MFMAs behind their last use
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
