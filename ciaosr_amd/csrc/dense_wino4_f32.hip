@@ -14,17 +14,23 @@
 // MFMA costs the SIMD's pipe ~6-20 cycles (tools/ubench/mfma_valu.hip).  So the two kinds of work are SEPARATED IN TIME:
 //   * workgroup = 16 x 32 output pixels = 4 x 8 Winograd tiles = the 32 columns of one MFMA tile, x all 64 output channels; 4 waves, one
 //     per SIMD; a step = 8 input channels;
-//   * T phase (all 256 threads, thread = (tile, channel)): 36 scalar LDS reads of the 6x6 window from the halo patch, B^T d B with
-//     144 VALU operations (the 12-operation form of B^T x, applied to 6 columns and 6 rows), 36 scalar LDS writes into
-//     V[pos][tile][8 ch] -- no MFMA is in flight, so the VALU instructions cost their own 2-4 cycles;
+//   * T phase (all 256 threads, thread = (tile, channel)): B^T d B of the thread's 6x6 window -- the 12-operation form of B^T x on 6
+//     columns (as column PAIRS in packed fp32) and 6 rows: 108 VALU instructions -- and 36 dword LDS writes into V[pos][tile][8 ch].
+//     No MFMA is in flight (the VALU instructions cost their own 4 cycles) and NO memory request is issued: the window values were
+//     read from the patch during the previous M phase (the same reads at the top of this phase cost 800 cycles of a 6800-cycle step);
 //   * one barrier;
 //   * M phase: wave (nt, h) owns positions (3h .. 3h+2, 0 .. 5) of output-channel half nt = 18 accumulator tiles (288 registers): 18
-//     V fragments (ds_read_b128) against 18 weight fragments (1 KB each, straight from L2) = 72 MFMAs with nothing between them; every
-//     weight register is re-requested for the NEXT step right behind its last MFMA, so the L2 round trip has a whole step to complete;
+//     V fragments (ds_read_b128) against 18 weight fragments (1 KB each, straight from L2) = 72 MFMAs.  One wave per SIMD issues in
+//     order: a memory instruction placed behind a BLOCK of MFMAs is issued once the block has been issued, and the next MFMA waits for
+//     it (first version: 1570 cycles for the 18 weight requests, 970 for the 5 DMA pieces of an 8000-cycle step).  So every memory
+//     instruction of a step sits behind ONE MFMA (w4_slot_plan below): V fragments of the next row, window values of the next step,
+//     row 2's weights of THIS step (inside row 0: two rows to land), the DMA pieces of patch n + 2, rows 0 / 1's weights of step n + 1,
+//     each weight register re-requested >= 8 MFMAs behind its last use;
 //   * the 18 x 34-pixel halo patch of a step's 8 channels (2 x 16-B chunks per pixel) comes by LDS-DMA two steps ahead into one of two
-//     buffers; its chunks are XOR-swizzled with ((P >> 2) & 3) << 1 (P = pixel index) so that the T phase's scalar reads -- four
-//     tiles x eight channels per 32-lane group, tiles four pixels apart -- hit 32 distinct banks;
+//     buffers; its chunks are XOR-swizzled with ((P >> 2) & 3) << 1 (P = pixel index) so that the window reads -- four tiles x eight
+//     channels per 32-lane group, tiles four pixels apart -- hit 32 distinct banks;
 //   * V and the patch are double-buffered, which leaves ONE barrier per step (T(n) | barrier | M(n), T(n+1) | barrier | ...).
+// Measured (tools/wino4_probe.py, tools/wino4_fit.py): 6103 cycles per step = T 580 + barrier 77 + M 5505 (MFMA issue 4608).
 // The output transform runs once per layer: A^T along j in registers, the row half through LDS between the two waves of a channel half.
 #include "ops.h"
 #include <type_traits>
