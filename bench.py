@@ -469,7 +469,10 @@ def main():
             del ref
         del out
 
-    # warm-up; the last warm-up step is fully profiled (per-kernel HIP events) to find the dominant kernel
+    # warm-up; the last warm-up step is fully profiled (per-kernel HIP events) to find the dominant kernel.  The weights are packed
+    # first (Restorer.prepare: once per model, what the first call would do), so that the profiled step lists a steady-state step's
+    # kernels and not the 6900 one-time pack_fragments launches of the Winograd weight sets
+    model.prepare(opt)
     for _ in range(max(args.warmup - 1, 0)):
         step()
     with hip_ops.profile():
