@@ -628,7 +628,7 @@ def test_staged_local_attention_kernel(dev):
 # ------------------------------------------------------------------------------------------------
 # encoder trunks (implicit-GEMM convolutions)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('hw', [(37, 53), (48, 48)])
+@pytest.mark.parametrize('hw', [(37, 53), (48, 48), (70, 21), (16, 32)])
 def test_rdn_trunk_halo_resident_fp32_dense_layers(dev, hw):
     """The big-map fp32 dense-layer kernel (dense_f32.hip, gather form, 12x12 tiles, K-sliced waves) forced onto small
     ragged maps, against the torch-CPU trunk and against the default scatter-form path."""
