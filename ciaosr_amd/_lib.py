@@ -45,7 +45,7 @@ class OptionsT(C.Structure):
     """ciaosr_options_t: per-call route options (include/ciaosr_hip.h)."""
     _fields_ = [('head_route', C.c_int), ('csa_composed_min', C.c_int), ('dense_min_tiles', C.c_int),
                 ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('bf16_single', C.c_int),
-                ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('reserved', C.c_int * 2), ('f16_pairs', C.c_int)]
+                ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('csa_attn_tile128', C.c_int), ('reserved', C.c_int * 1), ('f16_pairs', C.c_int)]
 
 
 HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG = 1, 2, 4, 8

@@ -193,7 +193,12 @@ static int cs_attn(const float* feat_hwc, int ld_feat, int H, int W, const ciaos
         RUN(gemm_f32(PE, 9 * C, w->w_down_masked, 9 * C, false, Pc, 9 * C, nullptr, (Hh + 3) * (Wh + 3), 9 * C, 9 * C, 1.f,
                      CIAOSR_ACT_NONE, 0.f, s, "csa_down_partial"));
         RUN(csa_gather_vprime(Pc, Hh, Wh, C, Vp, s));
-        RUN(gemm_f32_softmax_a(S, p.Lld, st, 1, Vp, 25 * C, true, O, 16 * C, HWp, 16 * C, p.L, nullptr, 0, s, "csa_attn_v"));
+        // attn.V: at a C3 tile's size (768 tiles of 192 x 256) one workgroup per CU, else -- or on request -- the 128 x 128 kernel; bitwise equal
+        if (!(opt && opt->csa_attn_tile128) && gemm_big_softmax_f32_ok(p.Lld, 25 * C, HWp, 16 * C, p.L, true) &&
+            ((size_t)(HWp - 1) * p.Lld + p.L) * sizeof(float) < 0xFFFFFF00ull)
+            RUN(gemm_big_softmax_f32(S, p.Lld, st, 1, Vp, 25 * C, O, 16 * C, HWp, 16 * C, p.L, s, "csa_attn_v"));
+        else
+            RUN(gemm_f32_softmax_a(S, p.Lld, st, 1, Vp, 25 * C, true, O, 16 * C, HWp, 16 * C, p.L, nullptr, 0, s, "csa_attn_v"));
         RUN(gemm_f32_softmax_a(S, p.Lld, st, 1, Vp + 16 * C, 25 * C, true, Otop, 4 * C, p.Wp, 4 * C, p.L, Y, p.n_Y, s, "csa_attn_v_edge"));
         RUN(gemm_f32_softmax_a(S, p.Wp * p.Lld, st, p.Wp, Vp + 20 * C, 25 * C, true, Oleft, 4 * C, p.Hp, 4 * C, p.L, Y, p.n_Y, s,
                                "csa_attn_v_edge"));

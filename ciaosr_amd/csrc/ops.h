@@ -58,6 +58,10 @@ int gemm_f32_splitk(const float* A, int lda, const float* B, int ldb, bool b_kn,
 // the plain kernel, else split-K.
 int gemm_f32_softmax_a(const float* A, int lda, const float* a_stats2, int a_stats_stride, const float* B, int ldb, bool b_kn, float* C, int ldc,
                        int M, int N, int K, float* partial, size_t partial_floats, hipStream_t stream, const char* tag);
+// the same contraction with one 192 x 256 workgroup tile per CU (gemm_big_f32.hip): [k][n] B, K a multiple of 16, >= 256 workgroup tiles
+bool gemm_big_softmax_f32_ok(int lda, int ldb, int M, int N, int K, bool b_kn);
+int gemm_big_softmax_f32(const float* A, int lda, const float* a_stats2, int a_stats_stride, const float* B, int ldb, float* C, int ldc,
+                         int M, int N, int K, hipStream_t stream, const char* tag);
 // gemm_small_f32.hip: few-MFLOP problems (no staging, K-sliced waves); gemm_small_ok tells whether a problem qualifies
 bool gemm_small_ok(int M, int N, int K, int lda, int ldw);
 int gemm_small_f32(const float* A, int lda, const float* W, int ldw, const float* bias, float* C, int ldc, float* C2, int ldc2,

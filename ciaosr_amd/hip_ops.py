@@ -200,7 +200,7 @@ class Options:
                MFMAs per product, fp32 trunk and tables, half cs_attn contractions): selects the _f32 / _bf16 / _f16 entry point.
     the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
     Immutable; `replace()` returns a modified copy."""
-    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'dense_direct', 'csa_scores_gemm', 'f16_pairs')
+    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'dense_direct', 'csa_scores_gemm', 'csa_attn_tile128', 'f16_pairs')
     __slots__ = ('precision',) + _C_FIELDS + ('_c',)
 
     def __init__(self, precision='fp32', **kw):

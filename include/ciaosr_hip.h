@@ -90,7 +90,10 @@ typedef struct ciaosr_options {
                              * 1 = the direct halo-resident kernel (exact fmaf chains); 2 = F(2x2, 3x3) even when frag_wino4 is given */
     int csa_scores_gemm;    /* _f32 cs_attn with 32 match channels: 0 (default) = correlation scores as a 3x3 diagonal box sum of the
                              * per-pixel correlation (K = 32, no patch rows); 1 = the 288-wide patch-row GEMM.  Same fp32 products, other order */
-    int reserved[2];        /* must be 0 (checked by every entry point that takes the struct: a non-zero word is CIAOSR_ERR_BAD_ARG) */
+    int csa_attn_tile128;   /* _f32 cs_attn, attn.V (softmax formed in the operand staging): 0 (default) = the 192 x 256 one-workgroup-per-CU kernel
+                             * (gemm_big_f32.hip) where the problem fills the chip (>= 256 workgroup tiles, K a multiple of 16), else and with 1 the
+                             * 128 x 128 kernel.  Bitwise the same result */
+    int reserved[1];        /* must be 0 (checked by every entry point that takes the struct: a non-zero word is CIAOSR_ERR_BAD_ARG) */
     int f16_pairs;          /* _f16 entries: 0 (default) = one IEEE-half weight per product; 1 = every dense-layer / head weight enters
                              * the MFMA as a half PAIR hi + lo (hi = half(w), lo = half(w - hi): ~20 mantissa bits, two MFMAs per product)
                              * and the layers the plain f16 mode runs with single 16-bit weights elsewhere (RDB local feature fusion,
