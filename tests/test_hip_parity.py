@@ -260,17 +260,18 @@ def test_csattn_never_reads_scratch_it_did_not_write(dev, precision):
         assert (y1.cpu()[0] - want).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize('hw', [(192, 192), (190, 187)])
-def test_csattn_attn_v_big_tile_kernel_is_bitwise_the_128_tile_kernel(dev, hw):
+@pytest.mark.parametrize('hw,channel', [((192, 192), 64), ((190, 187), 64), ((192, 192), 180)])
+def test_csattn_attn_v_big_tile_kernel_is_bitwise_the_128_tile_kernel(dev, hw, channel):
     """attn.V at a C3 tile's size runs the 192 x 256 one-workgroup-per-CU kernel (gemm_big_f32.hip; 768 workgroup tiles, K = 9216 = 192 k-tiles
     in a three-buffer pipeline); `Options(csa_attn_tile128=1)` keeps the 128 x 128 kernel.  Same products in the same order: the two must agree
     BITWISE -- on the even size and on one that is reflect-padded (ragged row tiles: 190 x 187 -> 190 x 188 = 35 720 rows = 186.04 row tiles)
-    -- and again with every scratch byte poisoned first (the kernel's clamped last loads and stale-buffer reads must not reach the result)."""
+    and at the SwinIR head's width (C = 180: N = 2880 = 11.25 column tiles, the last one ragged) -- and again with every scratch byte poisoned
+    first (the kernel's clamped last loads and stale-buffer reads must not reach the result)."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.nonlocal_attn import CrossScaleAttention
     torch.manual_seed(5)
-    att = CrossScaleAttention(channel=64, scale=2).to(dev)
-    x = (randn((1, 64) + hw, 91) * 0.5).to(dev)
+    att = CrossScaleAttention(channel=channel, scale=2).to(dev)
+    x = (randn((1, channel) + hw, 91) * 0.5).to(dev)
     with hip_ops.profile():
         big = att(x).clone()
     assert 'csa_attn_v' in hip_ops.profile.results()
