@@ -29,7 +29,7 @@ class MlpT(C.Structure):
 class HeadWeightsT(C.Structure):
     _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('nonlocal_max_scale', C.c_int), ('local_size', C.c_int),
                 ('no_unfold', C.c_int),
-                ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT), ('k_out_wino', C.c_void_p)]
+                ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT), ('k_out_wino', C.c_void_p), ('k_out_wino4', C.c_void_p)]
 
 
 class CsAttnWeightsT(C.Structure):
@@ -48,7 +48,7 @@ class OptionsT(C.Structure):
                 ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('csa_attn_tile128', C.c_int), ('reserved', C.c_int * 1), ('f16_pairs', C.c_int)]
 
 
-HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG = 1, 2, 4, 8
+HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG, HEAD_TABLE_WINO2 = 1, 2, 4, 8, 16
 
 
 class ConvT(C.Structure):

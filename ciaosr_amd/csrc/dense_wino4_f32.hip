@@ -65,8 +65,12 @@ struct DenseWino4P {
     int groups;                                  // 64-channel input groups
     const float4* wf;                            // 36 fragment arrays [2][nj][64 lanes] float4, one per transformed position, back to back
     int nj; long pos_stride;                     // nj = cin / 8; float4 per position array
-    const float* bias;
+    const float* bias;                           // nullptr (TABLE): no bias, no ReLU
     int col_out;
+    // TABLE form (the fused head's logit table, nine 3x3 convolutions of product maps without bias): the output goes elsewhere
+    float* out; unsigned out_bytes;              // [H*W][ld_out] per (image = map o, channel block z): byte offset o * out_img_bytes, channel 64 z
+    int ld_out; unsigned out_img_bytes;
+    unsigned wf_block_bytes;                     // weight fragments of channel block z start wf_block_bytes * z bytes further
 };
 
 // What goes out behind the MFMA of slot `slot` (0 .. 23) of row r3 (0 .. 2) of an M phase.  Per step and wave: 6 + 6 V fragments (rows 1, 2;
@@ -114,6 +118,7 @@ __device__ unsigned long long g_w4probe[1024 * 8];
 #define W4PROBE_ADD(slot, t0) do { } while (0)
 #endif
 
+template <bool TABLE>
 __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds4[];
     W4PROBE(0);
@@ -188,7 +193,8 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned pos_bytes = (unsigned)p.pos_stride * 16u;
     auto wload = [&](f32x4& dst, int pp, int n) __attribute__((always_inline)) {
-        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(18 * h + pp) * pos_bytes + (unsigned)(nt * p.nj + (step_ch(n) >> 3)) * 1024u);
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(18 * h + pp) * pos_bytes + (unsigned)(nt * p.nj + (step_ch(n) >> 3)) * 1024u +
+                                                           (TABLE ? (unsigned)blockIdx.z * p.wf_block_bytes : 0u));
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(lane16), "s"(wdesc), "s"(so) : "memory");
     };
 
@@ -385,11 +391,15 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
     W4PROBE(3);
     {
         const int pw = w ^ 2;                    // partner: same nt, other row half
-        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ors = TABLE ? __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000)
+                                                 : __builtin_amdgcn_make_buffer_rsrc(p.x, 0, p.x_bytes, 0x00020000);
+        const unsigned o_img = TABLE ? (unsigned)img * p.out_img_bytes : img_off;
+        const unsigned o_ld = TABLE ? (unsigned)p.ld_out : (unsigned)p.ldx;
+        const int o_col = TABLE ? 64 * (int)blockIdx.z : p.col_out;
         const int tyw = li >> 3, txw = li & 7;
         float4 bias4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
+        for (int q = 0; q < 4; ++q) bias4[q] = TABLE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
         // the partner's halves come back through LDS one (yy, x) ahead of the stores that use them
         float4 o[2][4];
 #pragma unroll
@@ -403,15 +413,19 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
             }
             const int y = ty0 + 4 * tyw + 2 * h + yy, xx = tx0 + 4 * txw + x;
             const bool ok = y < p.H && xx < p.W;
-            const unsigned pix = img_off + (unsigned)(y * p.W + xx) * (unsigned)p.ldx * 4u + (unsigned)(p.col_out + 32 * nt + 4 * lh) * 4u;
+            const unsigned pix = o_img + (unsigned)(y * p.W + xx) * o_ld * 4u + (unsigned)(o_col + 32 * nt + 4 * lh) * 4u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 ov = o[it & 1][q];
                 float4 v;
-                v.x = fmaxf(own[q][yy][x][0] + ov.x + bias4[q].x, 0.f);
-                v.y = fmaxf(own[q][yy][x][1] + ov.y + bias4[q].y, 0.f);
-                v.z = fmaxf(own[q][yy][x][2] + ov.z + bias4[q].z, 0.f);
-                v.w = fmaxf(own[q][yy][x][3] + ov.w + bias4[q].w, 0.f);
+                if (TABLE) {                       // plain sums: the table's bias and the softmax come later (head.hip)
+                    v.x = own[q][yy][x][0] + ov.x; v.y = own[q][yy][x][1] + ov.y; v.z = own[q][yy][x][2] + ov.z; v.w = own[q][yy][x][3] + ov.w;
+                } else {
+                    v.x = fmaxf(own[q][yy][x][0] + ov.x + bias4[q].x, 0.f);
+                    v.y = fmaxf(own[q][yy][x][1] + ov.y + bias4[q].y, 0.f);
+                    v.z = fmaxf(own[q][yy][x][2] + ov.z + bias4[q].z, 0.f);
+                    v.w = fmaxf(own[q][yy][x][3] + ov.w + bias4[q].w, 0.f);
+                }
                 i32x4 iv;
                 iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
                 __builtin_amdgcn_raw_buffer_store_b128(iv, ors, (int)(ok ? pix + (unsigned)q * 32u : kOobW4), 0, 0);
@@ -443,10 +457,35 @@ int dense_layer_wino4_f32(float* X, int ldx, int H, int W, int l, const float* f
     p.bias = bias;
     p.col_out = 64 * (l + 1);
     CIAOSR_CHECK_ARG((size_t)36 * p.pos_stride * 16 < 0xFFFFFF00ull);
-    CIAOSR_BIG_LDS(dense_wino4_f32_kernel, kWino4Lds);
+    p.out = nullptr; p.out_bytes = 0; p.ld_out = 0; p.out_img_bytes = 0; p.wf_block_bytes = 0;
+    CIAOSR_BIG_LDS(dense_wino4_f32_kernel<false>, kWino4Lds);
     ProfScope prof("enc_dense_wino4", s);
-    hipLaunchKernelGGL(dense_wino4_f32_kernel, dim3(dense_wino4_tiles(H, W), n_img), dim3(256), kWino4Lds, s, p);
+    hipLaunchKernelGGL(dense_wino4_f32_kernel<false>, dim3(dense_wino4_tiles(H, W), n_img), dim3(256), kWino4Lds, s, p);
     return launch_status("dense_wino4_f32");
+}
+
+// Nine 3x3 convolutions 64 -> 64 n_blk channels without bias in F(4x4, 3x3) form: out[(pix * 9 + o) * ldg + n] = sum_{k, c} Pi[o][pix + k][c] w[n][c][k]
+// (the logit table of the fused head, head.hip; wino_table_f32 of dense_wino_f32.hip is the F(2x2) form).  Pi: [9][H*W][64]; frag_wino4: 36
+// arrays of the transformed [64 n_blk][64] weights in fragment order.
+int wino4_table_f32(const float* Pi, int H, int W, const float* frag_wino4, int n_blk, float* out, int ldg, hipStream_t s) {
+    CIAOSR_CHECK_ARG(Pi && frag_wino4 && out && n_blk >= 1 && (ldg & 3) == 0 && aligned16(Pi) && aligned16(frag_wino4) && aligned16(out));
+    const size_t in_bytes = (size_t)9 * H * W * 64 * 4, out_bytes = (size_t)9 * H * W * ldg * 4;
+    CIAOSR_CHECK_ARG(in_bytes < 0xFFFFFF00ull && out_bytes < 0xFFFFFF00ull);
+    DenseWino4P p;
+    p.x = const_cast<float*>(Pi); p.ldx = 64; p.x_bytes = (unsigned)in_bytes;       // the nine maps = nine "images" of one 64-channel group
+    p.H = H; p.W = W; p.tiles_x = ceil_div(W, W4TW);
+    p.groups = 1;
+    p.wf = reinterpret_cast<const float4*>(frag_wino4);
+    p.nj = 8;
+    p.pos_stride = (long)2 * n_blk * p.nj * 64;                                      // float4 per position: 2 n_blk channel halves x 8 k-chunks x 64 lanes
+    p.wf_block_bytes = 2u * 8u * 1024u;                                              // one 64-channel block = two halves
+    p.bias = nullptr; p.col_out = 0;
+    p.out = out; p.out_bytes = (unsigned)out_bytes; p.ld_out = 9 * ldg; p.out_img_bytes = (unsigned)ldg * 4u;
+    CIAOSR_CHECK_ARG((size_t)36 * p.pos_stride * 16 < 0xFFFFFF00ull);
+    CIAOSR_BIG_LDS(dense_wino4_f32_kernel<true>, kWino4Lds);
+    ProfScope prof("head_logit_table", s);
+    hipLaunchKernelGGL(dense_wino4_f32_kernel<true>, dim3(dense_wino4_tiles(H, W), 9, n_blk), dim3(256), kWino4Lds, s, p);
+    return launch_status("wino4_table_f32");
 }
 
 }  // namespace ciaosr

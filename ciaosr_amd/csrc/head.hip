@@ -242,7 +242,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                                 p.HW >= 512 && p.HW <= kQkChunk;
         if (table_wino) {
             RUN(qk_maps(feat_hwc, p.C, p.C, H, W, QK, s));
-            RUN(wino_table_f32(QK, H, W, w->k_out_wino, 4, G, kLdG, s));
+            if (w->k_out_wino4 && !(route & CIAOSR_HEAD_TABLE_WINO2)) RUN(wino4_table_f32(QK, H, W, w->k_out_wino4, 4, G, kLdG, s));
+            else RUN(wino_table_f32(QK, H, W, w->k_out_wino, 4, G, kLdG, s));
             RUN(qk_rows(U, p.Dv, p.D, H, W, 0, (int)total, w->k.bias[last], nullptr, G, kLdG, 3, s));
         }
         for (long r0 = 0; r0 < total && !table_wino; r0 += kQkChunk) {

@@ -74,6 +74,7 @@ int dense_wino4_tiles(int H, int W);
 int dense_layer_wino4_f32(float* X, int ldx, int H, int W, int l, const float* frag_wino4, const float* bias, int n_img, hipStream_t s);
 // nine 3x3 convolutions 64 -> 64 n_blk of the maps Pi[9][H*W][64] into out[(pix * 9 + o) * ldg + n] (logit table of the fused head)
 int wino_table_f32(const float* Pi, int H, int W, const float* frag_wino, int n_blk, float* out, int ldg, hipStream_t s);
+int wino4_table_f32(const float* Pi, int H, int W, const float* frag_wino4, int n_blk, float* out, int ldg, hipStream_t s);   // dense_wino4_f32.hip
 // csa_scores_f32.hip: fp32 cs_attn correlation scores as a 3x3 diagonal box sum of the per-pixel correlation (Ch = 32)
 bool csa_scores_box_ok(int Ch, int ldm, int ldr);
 int csa_scores_box_f32(const float* M, int ldm, int Hp, int Wp, const float* R, int ldr, int Hl, int Wl, int Ch, float alpha, float floor_,

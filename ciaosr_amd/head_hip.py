@@ -136,6 +136,7 @@ class PackedHead:
         nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
         st.k, kk, sk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
         st.k_out_wino = None
+        st.k_out_wino4 = None
         w5 = self._last_wb[0]                                   # imnet_k's output layer [9C][256], rows in device order (tap, c)
         if unfold and Cc == 64 and tuple(w5.shape) == (576, 256):
             # the logit table as nine 3x3 convolutions (head.hip): g[n][c][a][b] = W5[(3a+b) C + c][n] in Winograd F(2x2, 3x3) form,
@@ -149,6 +150,16 @@ class PackedHead:
                           C.c_void_p(fw.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
             kk = kk + [fw]
             st.k_out_wino = fw.data_ptr()
+            # ... and in F(4x4, 3x3) form (dense_wino4_f32.hip's table kernel): 36 positions
+            G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                               [0, 0, 1]], dtype=torch.float64, device=dev)
+            Uw4 = torch.einsum('ia,abcn,jb->ijnc', G4, w5.view(3, 3, 64, 256).double(), G4).float().contiguous()   # [6][6][256][64]
+            fw4 = torch.empty(36 * nfl, dtype=torch.float32, device=dev)
+            for pos in range(36):
+                _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(Uw4[pos // 6, pos % 6]), 64, 256, 64,
+                          C.c_void_p(fw4.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
+            kk = kk + [fw4]
+            st.k_out_wino4 = fw4.data_ptr()
         st.v, kv, sv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
         st.q, kq, sq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
         self._q_last = self._last_wb

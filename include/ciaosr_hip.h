@@ -70,6 +70,7 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
                                        * (head_fused_wide.hip: half the weight stream per MFMA) instead of two 128-row workgroups per CU;
                                        * same result up to the fp32 summation order of the logit dot product, measured equal in time
                                        * (f16x3 always runs its 128-row two-array form of that kernel) */
+#define CIAOSR_HEAD_TABLE_WINO2 16    /* head_route bit 4: _f32 logit table in Winograd F(2x2, 3x3) form even when k_out_wino4 is given */
 typedef struct ciaosr_options {
     int head_route;         /* CIAOSR_HEAD_* bits; 0 = automatic */
     int csa_composed_min;   /* cs_attn: LR pixels (after padding) from which the composed fold+down tail applies;
@@ -236,6 +237,10 @@ typedef struct ciaosr_head_weights {
      * table of maps of 512 .. 65536 LR pixels as nine convolutions of product maps instead of a 576-deep GEMM row per
      * (pixel, key offset): 9 x 2.25 fewer multiplies (head_ops.hip qk_maps, dense_wino_f32.hip).  NULL = the GEMM */
     const float* k_out_wino;
+    /* optional, same layer: the F(4x4, 3x3) form, U[p] = (G g G^T)[p] with the 6x3 G of F(4, 3), p = 6 i + j = 0..35, each [256][64] matrix
+     * packed by ciaosr_pack_fragments_f32, the 36 arrays back to back (dense_wino4_f32.hip: 2.25x fewer MFMAs than the F(2x2) form);
+     * preferred over k_out_wino unless head_route has CIAOSR_HEAD_TABLE_WINO2.  NULL = the F(2x2) form (or the GEMM) */
+    const float* k_out_wino4;
 } ciaosr_head_weights_t;
 
 /* Grid-centre coordinates and cells of an Ht x Wt target: coord[q] = (seq_y[i], seq_x[j]) with
