@@ -181,22 +181,37 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 }
 
+// The bias of a layer is its accumulators' INITIAL value (round 4; the 16-bit kernels did this since round 2): the 64 moves that cleared the
+// accumulators load the bias instead and the layer's epilogue is one v_max_f32 per value -- every VALU instruction of these kernels costs the
+// shared SIMD ~5 matrix-pipe cycles.  bias + sum of products instead of sum of products + bias: the last bit may differ.
 template <int MT>
-__device__ __forceinline__ void store_relu_tile(float* X, const f32x16 (&acc)[MT][2], const float* __restrict__ bias,
-                                                int w, int li, int lh) {
+__device__ __forceinline__ void bias_acc(f32x16 (&acc)[MT][2], const float* __restrict__ bias, int w, int lh) {
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + 64 * w + 32 * ni + 8 * g + 4 * lh);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                acc[mi][ni][4 * g] = b.x; acc[mi][ni][4 * g + 1] = b.y; acc[mi][ni][4 * g + 2] = b.z; acc[mi][ni][4 * g + 3] = b.w;
+            }
+        }
+}
+
+template <int MT>
+__device__ __forceinline__ void store_relu_tile(float* X, const f32x16 (&acc)[MT][2], int w, int li, int lh) {
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int col = 64 * w + 32 * ni + 8 * g + 4 * lh;
-            const float4 b = *reinterpret_cast<const float4*>(bias + col);
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
                 float4 o;
-                o.x = fmaxf(acc[mi][ni][4 * g] + b.x, 0.f);
-                o.y = fmaxf(acc[mi][ni][4 * g + 1] + b.y, 0.f);
-                o.z = fmaxf(acc[mi][ni][4 * g + 2] + b.z, 0.f);
-                o.w = fmaxf(acc[mi][ni][4 * g + 3] + b.w, 0.f);
+                o.x = fmaxf(acc[mi][ni][4 * g], 0.f);
+                o.y = fmaxf(acc[mi][ni][4 * g + 1], 0.f);
+                o.z = fmaxf(acc[mi][ni][4 * g + 2], 0.f);
+                o.w = fmaxf(acc[mi][ni][4 * g + 3], 0.f);
                 *reinterpret_cast<float4*>(X + (32 * mi + li) * FLD + col) = o;
             }
         }
@@ -207,10 +222,10 @@ __device__ __forceinline__ void hidden_layer(float* X, const void* __restrict__ 
                                              int w, int lane) {
     const int li = lane & 31, lh = lane >> 5;
     f32x16 acc[MT][2];
-    zero_acc<MT, 2>(acc);
+    bias_acc<MT>(acc, bias, w, lh);
     mma_pass_u<MT, 2, FNJ>(X + li * FLD + 4 * lh, frag_rsrc(frag), (unsigned)lane * 16u, (unsigned)(2 * w) * (FNJ * 1024u), FNJ * 1024u, acc);
     __syncthreads();   // every wave has finished reading X
-    store_relu_tile<MT>(X, acc, bias, w, li, lh);
+    store_relu_tile<MT>(X, acc, w, li, lh);
     __syncthreads();
 }
 
@@ -222,15 +237,20 @@ __device__ __forceinline__ void build_rows(float* X, const FusedChain& c, const 
     float4 tw[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) tw[e] = *reinterpret_cast<const float4*>(c.tail + (size_t)(4 * n4 + e) * c.ld_tail);
+    // the four coordinate terms as PACKED fp32 FMAs on column pairs (round 4): 8 + 4 instead of 16 + 4 VALU instructions per float4, the same
+    // FMA chain per element (tv + w_ry ry, + w_rx rx, + w_sy sy, + w_sx sx); broadcast / same-lane source selections only (Makefile)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 wy01 = {tw[0].x, tw[1].x}, wy23 = {tw[2].x, tw[3].x}, wx01 = {tw[0].y, tw[1].y}, wx23 = {tw[2].y, tw[3].y};
+    const f32x2 vy01 = {tw[0].z, tw[1].z}, vy23 = {tw[2].z, tw[3].z}, vx01 = {tw[0].w, tw[1].w}, vx23 = {tw[2].w, tw[3].w};
     for (int r = t >> 6; r < 32 * MT; r += 4) {
         const float4 tv = reinterpret_cast<const float4*>(c.table + (size_t)s_kpix[r] * FH)[n4];
-        const float ry = s_t4[4 * r], rx = s_t4[4 * r + 1], sy = s_t4[4 * r + 2], sx = s_t4[4 * r + 3];
-        float4 o;
-        o.x = fmaxf(tv.x + tw[0].x * ry + tw[0].y * rx + tw[0].z * sy + tw[0].w * sx, 0.f);
-        o.y = fmaxf(tv.y + tw[1].x * ry + tw[1].y * rx + tw[1].z * sy + tw[1].w * sx, 0.f);
-        o.z = fmaxf(tv.z + tw[2].x * ry + tw[2].y * rx + tw[2].z * sy + tw[2].w * sx, 0.f);
-        o.w = fmaxf(tv.w + tw[3].x * ry + tw[3].y * rx + tw[3].z * sy + tw[3].w * sx, 0.f);
-        *reinterpret_cast<float4*>(X + r * FLD + 4 * n4) = o;
+        const float4 t4 = *reinterpret_cast<const float4*>(s_t4 + 4 * r);        // rel_y rel_x scale_y scale_x
+        const f32x2 ry = {t4.x, t4.x}, rx = {t4.y, t4.y}, sy = {t4.z, t4.z}, sx = {t4.w, t4.w};
+        f32x2 a = __builtin_elementwise_fma(wy01, ry, f32x2{tv.x, tv.y}), b = __builtin_elementwise_fma(wy23, ry, f32x2{tv.z, tv.w});
+        a = __builtin_elementwise_fma(wx01, rx, a); b = __builtin_elementwise_fma(wx23, rx, b);
+        a = __builtin_elementwise_fma(vy01, sy, a); b = __builtin_elementwise_fma(vy23, sy, b);
+        a = __builtin_elementwise_fma(vx01, sx, a); b = __builtin_elementwise_fma(vx23, sx, b);
+        *reinterpret_cast<float4*>(X + r * FLD + 4 * n4) = make_float4(fmaxf(a.x, 0.f), fmaxf(a.y, 0.f), fmaxf(b.x, 0.f), fmaxf(b.y, 0.f));
     }
 }
 
@@ -437,7 +457,12 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
                 for (int mi = 0; mi < MT; ++mi) vv[mi][g] = bload4(rs_u, doff == kOobF ? kOobF : voff[mi] + doff);
             }
             f32x16 acc[MT][1];
-            zero_acc<MT, 1>(acc);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {      // the output layer's bias as the accumulators' initial value
+                    acc[mi][0][4 * g] = bv[g].x; acc[mi][0][4 * g + 1] = bv[g].y; acc[mi][0][4 * g + 2] = bv[g].z; acc[mi][0][4 * g + 3] = bv[g].w;
+                }
             mma_pass_u<MT, 1, FNJ>(X + li * FLD + 4 * lh, frag_rsrc(p.v.frag_out), (unsigned)lane * 16u, (unsigned)u * (FNJ * 1024u), 0u, acc);
             // z[d] = sum_j a_j * (value_j[d] * (w_v,j[d] + b[d]))   (ciaosr_net.py:206,215): the 4 samples of a
             // query sit in 4 adjacent lanes -> quad reduction, then lane j stores channel group j as one float4
@@ -447,10 +472,10 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_kernel(FusedKVP p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float4 z;
-                    z.x = av[mi] * (vv[mi][g].x * (acc[mi][0][4 * g] + bv[g].x));
-                    z.y = av[mi] * (vv[mi][g].y * (acc[mi][0][4 * g + 1] + bv[g].y));
-                    z.z = av[mi] * (vv[mi][g].z * (acc[mi][0][4 * g + 2] + bv[g].z));
-                    z.w = av[mi] * (vv[mi][g].w * (acc[mi][0][4 * g + 3] + bv[g].w));
+                    z.x = av[mi] * (vv[mi][g].x * acc[mi][0][4 * g]);
+                    z.y = av[mi] * (vv[mi][g].y * acc[mi][0][4 * g + 1]);
+                    z.z = av[mi] * (vv[mi][g].z * acc[mi][0][4 * g + 2]);
+                    z.w = av[mi] * (vv[mi][g].w * acc[mi][0][4 * g + 3]);
                     z.x += quad_xor1(z.x); z.y += quad_xor1(z.y); z.z += quad_xor1(z.z); z.w += quad_xor1(z.w);
                     z.x += quad_xor2(z.x); z.y += quad_xor2(z.y); z.z += quad_xor2(z.z); z.w += quad_xor2(z.w);
                     if (jsel == g) zsel = z;
@@ -483,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
     const __amdgpu_buffer_rsrc_t rs_zin =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Z), 0, (unsigned)((size_t)p.nq * p.ldz * 4), 0x00020000);
     f32x16 acc[MT][2];
-    zero_acc<MT, 2>(acc);
+    bias_acc<MT>(acc, p.bias_in, w, lh);
     for (int k0 = 0; k0 < p.Dv; k0 += FH) {
         const int kc = min(FH, p.Dv - k0);          // multiple of 8
         if (k0 > 0) __syncthreads();                 // previous chunk fully consumed
@@ -511,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_kernel(FusedQP p) {
                         kc >> 3, (long)p.nj_in * 64, acc);
     }
     __syncthreads();
-    store_relu_tile<MT>(X, acc, p.bias_in, w, li, lh);
+    store_relu_tile<MT>(X, acc, w, li, lh);
     __syncthreads();
     for (int l = 0; l < p.n_hidden; ++l) hidden_layer<MT>(X, p.frag_hidden[l], p.bias_hidden[l], w, lane);
 
