@@ -17,6 +17,11 @@ template <int KIND> __global__ __launch_bounds__(256) void k(float* out, int ite
             a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
             a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
             a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+        } else if (KIND == 2) {       // dependent chain: every MFMA accumulates into the same tile
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a0, 0, 0, 0);
         } else {
             a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hx, hy, a1, 0, 0, 0);
@@ -48,6 +53,7 @@ template <int KIND> void run(const char* name, int wgs, int iters, int cyc) {
 int main() {
     for (int wgs : {1, 64, 256}) run<0>("fp32 MFMA", wgs, 200000, 64);
     for (int wgs : {1, 256}) run<1>("f16 MFMA", wgs, 400000, 32);
+    run<2>("fp32 dep.", 1, 200000, 64);           // four MFMAs in a row on ONE accumulator tile: does the dependent issue cost anything?
     // sustained: 2 s of fp32 MFMA on every CU
     run<0>("fp32 2s", 256, 4000000, 64);
     return 0;
