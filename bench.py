@@ -56,7 +56,50 @@ def self_launch(argv):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def rccl_probe_child():
+    """`python bench.py --rccl-probe-child PORT`: a fresh process that creates a 1-rank 'nccl' (= RCCL) group on cuda:0 and runs
+    `tile_shard.rccl_self_probe` (ranks counted by an all-reduce over the communicator; a 7-MB tile through one grouped isend +
+    irecv behind queued work, stream-ordered, bitwise).  Prints one JSON line.  Started by the N = 1 bench AFTER its timed region."""
+    from ciaosr_amd.tile_shard import rccl_env_defaults
+    rccl_env_defaults()                          # before the first HIP call (HSA reads HSA_ENABLE_IPC_MODE_LEGACY at init)
+    import torch
+    import torch.distributed as dist
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    port = int(sys.argv[sys.argv.index('--rccl-probe-child') + 1])
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+    from ciaosr_amd.tile_shard import rccl_self_probe
+    res = rccl_self_probe(dev)
+    torch.cuda.synchronize(dev)
+    print('RCCL_PROBE ' + json.dumps(res), flush=True)
+    dist.destroy_process_group()
+
+
+def rccl_probe(timeout_s=240):
+    """Run `rccl_probe_child` as a child process (bounded; its failure is reported, never raised)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'CIAOSR_DIST_BACKEND')}
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--rccl-probe-child', str(port)], capture_output=True, text=True,
+                             timeout=timeout_s, env=env, cwd=REPO)
+        lines = [l for l in out.stdout.splitlines() if l.startswith('RCCL_PROBE ')]
+        if out.returncode != 0 or not lines:
+            return dict(ok=False, error=f'rc {out.returncode}: {out.stderr[-400:]}')
+        res = json.loads(lines[-1][len('RCCL_PROBE '):])
+        res['ok'] = bool(res['ranks'] == 1 and all(res[k]['tile_bitwise'] and res[k]['consumer_bitwise'] for k in ('cold', 'warm')))
+        return res
+    except Exception as e:      # noqa: BLE001 - the probe must never take the bench line down
+        return dict(ok=False, error=repr(e)[:400])
+
+
 if __name__ == '__main__':
+    if '--rccl-probe-child' in sys.argv:
+        rccl_probe_child()
+        sys.exit(0)
     self_launch(sys.argv[1:])
 
 import torch                                    # noqa: E402 - after self_launch on purpose
@@ -95,7 +138,9 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         # fused kernels: phi_k + phi_v layers 2..5 per (query, shift) row; phi_q all layers per query
         # (imnet_k's output layer is folded exactly into the 9-rows-per-LR-pixel logit table: 'head_logit_table')
         'head_kv_fused': (2.0 * R * (6 * hidden * hidden + hidden * Dv), 'flop'),
-        'head_logit_table': (2.0 * 9 * HW * D * hidden, 'flop'),
+        'head_logit_table': (2.0 * 9 * HW * D * hidden, 'flop'),           # GEMM form of the table
+        'head_logit_table_w2': (2.0 * 9 * HW * D * hidden, 'flop'),        # nine Winograd F(2x2) convolutions of the product maps
+        'head_logit_table_w4': (2.0 * 9 * HW * D * hidden, 'flop'),        # ... in F(4x4) form (the fp32 / f16x3 default)
         'head_logit_table_bf16': (2.0 * 9 * HW * D * hidden, 'flop16'),
         'head_decode_fused': (2.0 * Q * (Dv * hidden + 3 * hidden * hidden + 3 * hidden), 'flop'),
         'head_kv_fused_bf16': (2.0 * R * (6 * hidden * hidden + hidden * Dv), 'flop16'),
@@ -146,9 +191,9 @@ def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     base = tag[:-5] if tag.endswith('_bf16') else (tag[:-4] if tag.endswith('_f16') else tag)
     half = base != tag
     if not half:
-        if base in ('enc_dense_wino', 'head_logit_table'):
+        if base in ('enc_dense_wino', 'head_logit_table_w2'):
             return 16.0 / 36.0
-        if base == 'enc_dense_wino4':
+        if base in ('enc_dense_wino4', 'head_logit_table_w4'):
             return 36.0 / 144.0
         if base == 'csa_scores' and HW >= 4096:
             side = HW ** 0.5
@@ -275,7 +320,7 @@ def live_pmc_traffic(kernel_substr, unit_workload, precision, timeout_s=300):
         d = tempfile.mkdtemp(prefix='ciaosr_pmc_', dir='/tmp')
         cmd = ['rocprofv3', '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'p', '--',
                sys.executable, os.path.join(REPO, 'bench.py'), '--workload', unit_workload, '--precision', precision, '--steps', '1',
-               '--warmup', '1', '--no-cpu-baseline', '--no-extras', '--no-live-pmc']
+               '--warmup', '1', '--no-cpu-baseline', '--no-extras', '--no-live-pmc', '--no-rccl-probe']
         try:
             subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), timeout=timeout_s, check=True,
                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
@@ -322,6 +367,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-live-pmc', action='store_true', help='do not spawn the two rocprofv3 --pmc child passes that measure roofline.traffic')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
+    ap.add_argument('--no-rccl-probe', action='store_true', help='N = 1: do not start the child that creates a 1-rank RCCL communicator on this GPU '
+                    '(counts `rccl_ranks`, runs one grouped self send / receive of a 7-MB tile behind queued work) after the timed region')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
@@ -351,7 +398,9 @@ def main():
     assert world == args.gpus, f'WORLD_SIZE {world} != --gpus {args.gpus}'
     if world > 1 and args.workload in ('c2', 'c3tile'):
         raise SystemExit(f'--workload {args.workload} is a single-tile, single-GPU measurement (use c3 / c3s for tile sharding, c2q for query sharding)')
-    n_dev = torch.cuda.device_count()
+    from ciaosr_amd.tile_shard import rccl_env_defaults
+    p2p_channels_env = rccl_env_defaults()                     # BEFORE the first HIP call: ROCr reads HSA_ENABLE_IPC_MODE_LEGACY when it
+    n_dev = torch.cuda.device_count()                          # initialises (counting devices does not initialise it, set_device does)
     backend = os.environ.get('CIAOSR_DIST_BACKEND', 'nccl')   # 'gloo': rehearse the N-rank path on one GPU
     if backend == 'nccl' and world > n_dev:
         raise SystemExit(f'{world} ranks but only {n_dev} GPUs visible (RCCL needs one GPU per rank)')
@@ -363,9 +412,9 @@ def main():
     watchdog = None
     if world > 1:
         import datetime
-        from ciaosr_amd.tile_shard import StepDeadline, ensure_communicator, rccl_env_defaults
+        from ciaosr_amd.tile_shard import StepDeadline, ensure_communicator
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        p2p_channels = rccl_env_defaults()            # before the communicator exists: RCCL reads its environment at init
+        p2p_channels = p2p_channels_env               # set before the communicator exists: RCCL reads its environment at init
         # bounded waits: a step (incl. the profiled / checked ones) past the deadline ends THIS rank with exit code 3, and the
         # launcher then ends the others; collectives time out on the same scale instead of the 10 / 30-minute defaults
         deadline_s = float(os.environ.get('CIAOSR_STEP_DEADLINE_S', '900'))
@@ -706,6 +755,12 @@ def main():
                     extras[f'c3s_6tiles_fp32_ms_tile_streams_{ns}'] = round(time_steps(lambda: model.restore(c3s), 2, dev), 2)
                 model.test_cfg['tile_streams'] = 1
             line['extras'] = extras
+        if world == 1 and not args.no_rccl_probe:
+            # N = 1: `rccl_ranks` as a communicator counts them -- a fresh child creates a 1-rank RCCL group on this GPU and hands a tile to
+            # itself through the exchange code (tile_shard.rccl_self_probe); None when RCCL could not be brought up
+            probe = rccl_probe()
+            line['rccl_probe'] = probe
+            line['rccl_ranks'] = probe.get('ranks') if probe.get('ok') else None
         if world == 1 and not args.no_cpu_baseline:
             if args.workload in ('c2', 'c2q'):
                 line['cpu_baseline'] = cpu_baseline_c2(scale)

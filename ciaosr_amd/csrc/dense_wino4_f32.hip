@@ -483,7 +483,7 @@ int wino4_table_f32(const float* Pi, int H, int W, const float* frag_wino4, int 
     p.out = out; p.out_bytes = (unsigned)out_bytes; p.ld_out = 9 * ldg; p.out_img_bytes = (unsigned)ldg * 4u;
     CIAOSR_CHECK_ARG((size_t)36 * p.pos_stride * 16 < 0xFFFFFF00ull);
     CIAOSR_BIG_LDS(dense_wino4_f32_kernel<true>, kWino4Lds);
-    ProfScope prof("head_logit_table", s);
+    ProfScope prof("head_logit_table_w4", s);   // F(4x4) form: 36 / 144 of the direct form's MFMAs (bench.py executed_ratio)
     hipLaunchKernelGGL(dense_wino4_f32_kernel<true>, dim3(dense_wino4_tiles(H, W), 9, n_blk), dim3(256), kWino4Lds, s, p);
     return launch_status("wino4_table_f32");
 }

@@ -369,7 +369,7 @@ int wino_table_f32(const float* Pi, int H, int W, const float* frag_wino, int n_
     p.bias = nullptr;
     p.col_out = 0;
     CIAOSR_BIG_LDS(dense_wino_f32_kernel<true>, kWinoTableLds);
-    ProfScope prof("head_logit_table", s);
+    ProfScope prof("head_logit_table_w2", s);   // F(2x2) form: 16 / 36
     hipLaunchKernelGGL(dense_wino_f32_kernel<true>, dim3(dense_wino_tiles(H, W), 9, n_blk / per_wg), dim3(512), kWinoTableLds, s, p);
     return launch_status("wino_table_f32");
 }

@@ -16,16 +16,25 @@ the CPU tests and the one-GPU rehearsals):
 * rank 0 blends a round's tiles one round later (they have had a whole tile time to arrive), always in the
   reference order (h outer, w inner), so the result is bitwise equal to the 1-GPU run.
 
-Nothing is all-gathered: a peer holds only its own not-yet-delivered tiles, rank 0 two rounds of receive
-buffers, and exchange + blend hide under compute except for the last round.  Both sides use the grouped
-form (`dist.batch_isend_irecv`), i.e. the process group's ONE communicator (created eagerly by
-`init_process_group(device_id=...)`): no per-pair communicator is built lazily inside the timed region.
+Nothing is all-gathered: a peer holds only its own not-yet-delivered tiles; rank 0 holds the receive buffers
+posted since its previous own tile -- two rounds (2 (R - 1) tiles, 99 MB at R = 8) while it joins every round,
+and up to the peer tiles between two of its own tiles when `rank0_share` < 1 (share 0: every peer tile of the
+image, n_tiles x 7 MB, posted at the start) -- and exchange + blend hide under compute except for the last
+round.  Both sides use the grouped form (`dist.batch_isend_irecv`), i.e. the process group's ONE communicator
+(created eagerly by `init_process_group(device_id=...)`): no per-pair communicator is built lazily inside the
+timed region.
+
+`loopback=True` (world size 1, an initialised 1-rank group) runs the SAME exchange code on one GPU: every second
+tile is treated as a peer's, computed here, and delivered to this rank by a grouped isend + irecv to itself -- the
+RCCL branches (`_Mover` with device tensors, the stream-ordered `wait`) execute without a second GPU
+(tests/test_rccl_single_gpu.py).
 """
 import math
 import os
 import sys
 import threading
 import time
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -34,10 +43,13 @@ from .restorer import tile_grid
 
 
 def rccl_env_defaults(env=None):
-    """Environment defaults for the tile exchange, applied with setdefault BEFORE the communicator exists (RCCL reads them at
-    init): one point-to-point channel -- a 7-MB tile per peer and round needs ~0.3 ms of one channel, and every further channel is
-    one more workgroup of the receive kernel resident on rank 0's CUs beside its own tile; dmabuf IPC (this driver's only mode).
-    Returns the p2p channel count in force (reported by bench.py)."""
+    """Environment defaults for the tile exchange, applied with setdefault.  NCCL_*: read by RCCL when the communicator is
+    created -- one point-to-point channel: a 7-MB tile per peer and round needs ~0.3 ms of one channel, and every further channel
+    is one more workgroup of the receive kernel resident on rank 0's CUs beside its own tile.  HSA_ENABLE_IPC_MODE_LEGACY=0
+    (dmabuf IPC, this driver's only mode): read by ROCr when HSA initialises, i.e. at the FIRST HIP call of the process -- so this
+    function must run before anything touches the GPU (`torch.cuda.set_device`, a tensor on the device; counting devices does
+    not): bench.py, tools/test.py and the test children call it first thing in main().  Returns the p2p channel count in force
+    (reported by bench.py)."""
     env = os.environ if env is None else env
     env.setdefault('NCCL_MIN_P2P_NCHANNELS', '1')
     env.setdefault('NCCL_MAX_P2P_NCHANNELS', '1')
@@ -102,22 +114,30 @@ def partition(n_tiles, world, rank0_share=1.0):
     return [[t for t in range(n_tiles) if owners[t] == r] for r in range(world)]
 
 
-_warm_groups = set()
+_warm_groups = {}          # id(group) -> (weak reference to the group object, device type the communicator was counted on)
 
 
 def ensure_communicator(group=None, device=None):
     """The group's communicator must exist before the first grouped point-to-point call that only SOME ranks take part in
     (torch.distributed.batch_isend_irecv: 'if this is the first collective call in the group, all ranks must participate'): one
-    all-reduce of ones, once per group, by every rank.  Returns the rank count as the communicator counts it."""
+    all-reduce of ones, once per group OBJECT, by every rank.  Returns the rank count as the communicator counts it.
+    The cache holds weak references and is re-validated against the live object: after destroy_process_group() + a second
+    init_process_group() in the same interpreter a new group may reuse the id of a dead one, and skipping the all-reduce for it
+    would leave the first partial grouped call to create the communicator lazily."""
     if not dist.is_initialized():
+        _warm_groups.clear()
         return 1
-    key = id(group if group is not None else dist.distributed_c10d._get_default_group())
-    if key in _warm_groups:
-        return dist.get_world_size(group)
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
     on_gpu = device is not None and torch.device(device).type == 'cuda' and dist.get_backend(group) != 'gloo'
+    kind = 'cuda' if on_gpu else 'cpu'
+    hit = _warm_groups.get(id(pg))
+    if hit is not None and hit[0]() is pg and hit[1] == kind:
+        return dist.get_world_size(group)
+    for k in [k for k, v in _warm_groups.items() if v[0]() is None]:
+        del _warm_groups[k]
     ones = torch.ones(1, dtype=torch.int32, device=device if on_gpu else 'cpu')
     dist.all_reduce(ones, group=group)
-    _warm_groups.add(key)
+    _warm_groups[id(pg)] = (weakref.ref(pg), kind)
     return int(ones.item())
 
 
@@ -130,19 +150,47 @@ class _Mover:
         self.via_host = device is not None and torch.device(device).type == 'cuda' and dist.get_backend(group) == 'gloo'
         self.pending = []          # (works, tensors kept alive)
 
-    def send(self, t, dst):
+    def _send_ops(self, t, dst):
         buf = t.cpu() if self.via_host else t.contiguous()
-        works = dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, dst, self.group)])
-        self.pending.append((works, buf))
+        return [dist.P2POp(dist.isend, buf, dst, self.group)], buf
+
+    def _recv_ops(self, like_shape, srcs, device):
+        bufs = [torch.empty(like_shape, dtype=torch.float32, device='cpu' if self.via_host else device) for _ in srcs]
+        return [dist.P2POp(dist.irecv, b, s, self.group) for b, s in zip(bufs, srcs)], bufs
+
+    def _reap(self):
         # drop what has been delivered: a peer never holds more than its in-flight tiles
         while self.pending and all(w.is_completed() for w in self.pending[0][0]):
             self.pending.pop(0)
 
+    def send(self, t, dst):
+        ops, buf = self._send_ops(t, dst)
+        works = dist.batch_isend_irecv(ops)
+        self.pending.append((works, buf))
+        self._reap()
+
     def recv_many(self, like_shape, srcs, device):
         """One grouped receive of len(srcs) equally shaped tiles (RCCL: ONE kernel on the communicator's stream, ordered behind
         what the compute stream holds at this moment).  Returns a batch handle for `take`."""
-        bufs = [torch.empty(like_shape, dtype=torch.float32, device='cpu' if self.via_host else device) for _ in srcs]
-        works = dist.batch_isend_irecv([dist.P2POp(dist.irecv, b, s, self.group) for b, s in zip(bufs, srcs)])
+        ops, bufs = self._recv_ops(like_shape, srcs, device)
+        works = dist.batch_isend_irecv(ops)
+        return dict(works=works, bufs=bufs, waited=False)
+
+    def loop_many(self, tiles, me, device):
+        """Loopback (one rank acting as its own peers): the sends of `tiles` to this rank and their receives as ONE grouped call
+        -- a send to oneself only completes inside the group that also holds its receive.  Same handle as `recv_many`.
+        gloo has no pair to itself: there (CPU tests of the driver logic only) the hand-over is a host copy."""
+        if dist.get_backend(self.group) == 'gloo':
+            return dict(works=[], bufs=[t.detach().cpu().clone() if self.via_host else t.detach().clone() for t in tiles], waited=False)
+        sends, kept = [], []
+        for t in tiles:
+            ops, buf = self._send_ops(t, me)
+            sends += ops
+            kept.append(buf)
+        recvs, bufs = self._recv_ops(tuple(tiles[0].shape), [me] * len(tiles), device)
+        works = dist.batch_isend_irecv(sends + recvs)
+        self.pending.append((works, kept))
+        self._reap()
         return dict(works=works, bufs=bufs, waited=False)
 
     def take(self, batch, i, device):
@@ -160,9 +208,69 @@ class _Mover:
         self.pending = []
 
 
+def rccl_self_probe(device, tile_shape=(1, 768 * 768, 3), busy_ms=40.0):
+    """What one GPU can show about the exchange: inside an initialised 1-rank 'nccl' (= RCCL) group, count the communicator's
+    ranks with an all-reduce on the device, then run the hand-off `sharded_clip_test` relies on -- a tile-sized tensor produced by
+    work still QUEUED on the compute stream goes through ONE grouped isend + irecv to this rank, `wait()` orders the current
+    stream behind the copy without blocking the host, and a consumer kernel reads the receive buffer -- with no host
+    synchronisation anywhere between producer and consumer.  Returns a dict (bitwise flags, host / GPU times); the caller asserts.
+    Used by tests/rccl_child.py and by `bench.py`'s N = 1 probe child."""
+    dev = torch.device(device)
+    ranks = ensure_communicator(None, dev)
+    n = 1
+    for d in tile_shape:
+        n *= int(d)
+    g = torch.Generator(device='cpu').manual_seed(17)
+    a = (torch.randn(2048, 2048, generator=g) / 45.0).to(dev)
+    x0 = torch.randn(2048, 2048, generator=g).to(dev)
+    reps = -(-n // x0.numel())
+
+    def producer(rounds):
+        x = x0
+        for _ in range(rounds):
+            x = torch.tanh(a @ x)                      # a chain of dependent kernels: the tile below exists only when it has run
+        return x.flatten().repeat(reps)[:n].view(tile_shape) + 0.5
+
+    producer(2)
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    producer(8)
+    ev[1].record()
+    torch.cuda.synchronize(dev)
+    rounds = max(8, int(8 * busy_ms / max(ev[0].elapsed_time(ev[1]), 1e-3)))
+    mover = _Mover(None, dev)
+    out = {}
+    for label in ('cold', 'warm'):                     # 'cold': the first grouped p2p of the communicator (connection set-up)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_host = time.perf_counter()
+        ev[0].record()
+        tile = producer(rounds)
+        ev[1].record()
+        batch = mover.loop_many([tile], dist.get_rank(), dev)
+        got = mover.take(batch, 0, dev)               # wait(): stream-ordered on RCCL, no host block
+        consumed = got * 2.0 + 1.0                    # consumer kernel on the current stream
+        ev[2].record()
+        t_host = (time.perf_counter() - t_host) * 1e3
+        torch.cuda.synchronize(dev)
+        mover.drain()
+        out[label] = dict(host_enqueue_ms=round(t_host, 3), producer_gpu_ms=round(ev[0].elapsed_time(ev[1]), 3),
+                          exchange_and_consumer_gpu_ms=round(ev[1].elapsed_time(ev[2]), 3),
+                          tile_bitwise=bool(torch.equal(got, tile)), consumer_bitwise=bool(torch.equal(consumed, tile * 2.0 + 1.0)),
+                          tile_nonconstant=bool(float(tile.std()) > 1e-3))
+    b = torch.arange(1024, dtype=torch.float32, device=dev)
+    dist.broadcast(b, src=0)
+    return dict(ranks=ranks, backend=dist.get_backend(), tile_mb=round(n * 4 / 1e6, 2), p2p_channels=os.environ.get('NCCL_MAX_P2P_NCHANNELS'),
+                ipc_mode_legacy=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'), broadcast_ok=bool(b[-1].item() == 1023.0), **out)
+
+
 def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_fn, rank, world, group=None,
-                      device=None, gather_to_all=False, mark=None, rank0_share=1.0):
+                      device=None, gather_to_all=False, mark=None, rank0_share=1.0, loopback=False):
     """Generic driver (device-agnostic so it can be exercised with gloo on CPU).
+
+    loopback (world == 1 inside an initialised 1-rank group): the schedule of a 2-rank run on ONE rank -- the tiles `tile_owners`
+    gives to rank 1 are computed here and handed to this rank's own receive buffers by a grouped isend + irecv to itself
+    (`_Mover.loop_many`), posted, waited for and blended exactly where a real peer's tiles are.  Same image, bitwise.
 
     mark(name): optional probe, called at 'start', at 'last_own_tile' (this rank's last tile has been queued) and, on rank 0,
     at 'finalized' (every tile blended and normalised) -- bench.py records stream events there to report the exposed tail.
@@ -177,10 +285,11 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
     th = tw = round(tile * sf)
     n = len(origins)
     shape = (b, th * tw, 3)
-    owners = tile_owners(n, world, rank0_share)
-    if world > 1:
+    loopback = bool(loopback) and world == 1 and dist.is_initialized()
+    owners = tile_owners(n, 2 if loopback else world, rank0_share)
+    if world > 1 or loopback:
         ensure_communicator(group, device)
-    mover = _Mover(group, device) if world > 1 else None
+    mover = _Mover(group, device) if (world > 1 or loopback) else None
     if mark is not None:
         mark('start')
 
@@ -204,10 +313,12 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
             """Grouped receive of every peer tile below `upto` that has none yet."""
             peer = [t for t in range(state['posted'], upto) if owners[t] != 0]
             state['posted'] = max(state['posted'], upto)
-            if peer:
+            if peer and loopback:
+                batch = mover.loop_many([tile_fn(origins[t][0], origins[t][1], tile) for t in peer], rank, device)
+            elif peer:
                 batch = mover.recv_many(shape, [owners[t] for t in peer], device)
-                for i, t in enumerate(peer):
-                    handles[t] = (batch, i)
+            for i, t in enumerate(peer):
+                handles[t] = (batch, i)
 
         def blend(t, out):
             hi, wi = origins[t]
@@ -238,6 +349,8 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
         result = finalize_fn(E, Wt)
         if mark is not None:
             mark('finalized')
+        if loopback:
+            mover.drain()
     if gather_to_all and world > 1:
         meta = [tuple(result.shape)] if rank == 0 else [None]
         dist.broadcast_object_list(meta, src=0, group=group)
@@ -253,10 +366,11 @@ def sharded_clip_test(img_shape, tile, overlap, sf, tile_fn, blend_fn, finalize_
 
 
 def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, gather_to_all=False, options=None, stats=None,
-                          rank0_share=None):
+                          rank0_share=None, loopback=False):
     """Tile-sharded counterpart of CiaoSR.clip_test on the GPUs of one node.
     `stats` (optional dict) receives a stream event per probe point of `sharded_clip_test` (bench.py's exposed-tail figure).
-    `rank0_share` (default `test_cfg.rank0_share` or 1): see `tile_owners`; every rank must pass the same value."""
+    `rank0_share` (default `test_cfg.rank0_share` or 1): see `tile_owners`; every rank must pass the same value.
+    `loopback` (1-rank group only): see `sharded_clip_test`."""
     from . import hip_ops
     rank = dist.get_rank(group) if rank is None else rank
     world = dist.get_world_size(group) if world is None else world
@@ -280,7 +394,7 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
     if (n_batch > 1 and x_norm.is_cuda and x_norm.shape[0] == 1 and enc is not None and hasattr(enc, 'forward_hwc_batch')
             and enc.supported() and getattr(gen, '_head', None) is not None):
         tile_sz, origins = tile_grid(x_norm.shape[-2], x_norm.shape[-1], cfg.get('tile'), cfg.get('tile_overlap'))
-        owners = tile_owners(len(origins), world, rank0_share)
+        owners = [0] * len(origins) if (loopback and world == 1) else tile_owners(len(origins), world, rank0_share)
         mine = [o for o, r in zip(origins, owners) if r == rank]
         pos = {o: i for i, o in enumerate(mine)}
         cache = {}
@@ -313,7 +427,7 @@ def clip_test_distributed(restorer, x_norm, rank=None, world=None, group=None, g
             stats[name] = ev
 
     return sharded_clip_test(tuple(x_norm.shape), cfg.get('tile'), cfg.get('tile_overlap'), sf, tile_fn, blend_fn,
-                             finalize_fn, rank, world, group, x_norm.device, gather_to_all, mark, rank0_share)
+                             finalize_fn, rank, world, group, x_norm.device, gather_to_all, mark, rank0_share, loopback)
 
 
 # ---------------------------------------------------------------------------------------------------------------

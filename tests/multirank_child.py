@@ -15,6 +15,8 @@ sys.path.insert(0, REPO)
 
 
 def main():
+    from ciaosr_amd.tile_shard import rccl_env_defaults
+    rccl_env_defaults()                  # before the first HIP call of the rank (HSA reads its IPC mode when it initialises)
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     n_dev = torch.cuda.device_count()
     backend = os.environ.get('CIAOSR_DIST_BACKEND') or ('nccl' if n_dev >= world else 'gloo')

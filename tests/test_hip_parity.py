@@ -501,7 +501,7 @@ def test_fused_and_staged_head_paths_agree(dev):
     with hip_ops.profile():                  # default route: fused kernels + logit table (9 rows per LR pixel) as nine Winograd
         fused = g._predict([feat], coord, cell, 30000, x).cpu()     # convolutions of the product maps (C = 64; ragged 8x16 tiles here)
     prof = hip_ops.profile.results()
-    assert 'head_kv_fused' in prof and 'head_logit_table' in prof and 'head_qk_maps' in prof, 'fused kernels / logit table did not run'
+    assert 'head_kv_fused' in prof and 'head_logit_table_w4' in prof and 'head_qk_maps' in prof, 'fused kernels / logit table did not run'
     tol = 5e-5 * max(1.0, staged.abs().max().item())
     print('fused - staged', (fused - staged).abs().max().item(), 'gemm table - staged', (fused_gemm - staged).abs().max().item(), 'tol', tol)
     assert (fused - staged).abs().max() < tol and (fused_mfma - staged).abs().max() < tol and (fused_gemm - staged).abs().max() < tol
@@ -946,11 +946,11 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         out = model.restore(lq.to(dev), options=opt).cpu()
     prof = hip_ops.profile.results()
     if precision in ('f16x3', 'f16x3-fast'):
-        for tag in ('enc_dense_wino4' if precision == 'f16x3' else 'enc_dense_f16', 'csa_attn_v_f16', 'csa_scores_f16', 'head_logit_table',
+        for tag in ('enc_dense_wino4' if precision == 'f16x3' else 'enc_dense_f16', 'csa_attn_v_f16', 'csa_scores_f16', 'head_logit_table_w4',
                     'head_kv_fused_f16x3', 'head_decode_fused_f16x3'):
             assert tag in prof, (tag, sorted(prof))
     elif precision in ('fp32', 'fp32-wino2', 'fp32-direct'):
-        for tag in ({'fp32': 'enc_dense_wino4', 'fp32-wino2': 'enc_dense_wino', 'fp32-direct': 'enc_dense_gather'}[precision], 'csa_attn_v_edge', 'head_logit_table'):
+        for tag in ({'fp32': 'enc_dense_wino4', 'fp32-wino2': 'enc_dense_wino', 'fp32-direct': 'enc_dense_gather'}[precision], 'csa_attn_v_edge', 'head_logit_table_w4'):
             assert tag in prof, (tag, sorted(prof))
     else:
         sfx = '_f16' if precision.startswith('f16') else '_bf16'

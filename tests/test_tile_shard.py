@@ -219,3 +219,47 @@ def test_image_sharded_eval_results_are_collected_in_dataset_order():
     single = [dict(eval_result=dict(PSNR=float(10 + i), SSIM=0.1 * i)) for i in range(7)]
     assert ret['out'] == single
     assert SRFolderDataset.evaluate(ret['out']) == SRFolderDataset.evaluate(single)
+
+
+def _loopback_worker(rank, world, port, ret):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    from ciaosr_amd import tile_shard
+    from ciaosr_amd.tile_shard import sharded_clip_test, ensure_communicator
+    torch.set_num_threads(4)
+    fx = load_golden('tiling_small')
+    tile_fn, shape = _tile_fn_factory(fx)
+    # a first 1-rank group, warmed and destroyed: the second group of the same interpreter must be counted again (its object may
+    # reuse the dead one's id; the cache holds weak references and re-validates them)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    assert ensure_communicator(None, None) == 1 and len(tile_shard._warm_groups) == 1
+    dist.destroy_process_group()
+    assert ensure_communicator(None, None) == 1 and not tile_shard._warm_groups          # no group: cache dropped
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    calls = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        out = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1, loopback=True)
+        assert len(calls) == 1                                                            # the NEW group was counted once
+        sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1, loopback=True, rank0_share=0.0)
+        assert len(calls) == 1                                                            # and only once
+    finally:
+        dist.all_reduce = real
+    ret['out'] = out
+    dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_loopback_on_a_one_rank_group_runs_the_exchange_code_and_is_bitwise():
+    """world size 1 with `loopback=True`: every second tile goes through `_Mover.loop_many` (grouped isend + irecv to oneself), is
+    waited for and blended where a peer's tile is -- the single-GPU rehearsal of the RCCL branches (tests/test_rccl_single_gpu.py
+    runs it over RCCL with device tensors); here over gloo.  Also: the communicator cache across destroy / re-init."""
+    from ciaosr_amd.tile_shard import sharded_clip_test
+    fx = load_golden('tiling_small')
+    tile_fn, shape = _tile_fn_factory(fx)
+    single = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_loopback_worker, args=(1, 29621, ret), nprocs=1, join=True)
+    assert torch.equal(ret['out'], single)

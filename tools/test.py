@@ -97,13 +97,13 @@ def main(argv=None):
     distributed = args.launcher != 'none'
     rank, world = 0, 1
     if distributed:
+        rccl_env_defaults()      # first: ROCr reads HSA_ENABLE_IPC_MODE_LEGACY at the first HIP call (set_device below), RCCL its NCCL_* at init
         rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
         torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', args.local_rank)) % max(torch.cuda.device_count(), 1))
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # CIAOSR_DIST_BACKEND=gloo: rehearse the N-rank path on fewer GPUs than ranks (host-staged copies)
         import datetime
         backend = os.environ.get('CIAOSR_DIST_BACKEND') or cfg.get('dist_params', {}).get('backend', 'nccl')
-        rccl_env_defaults()
         deadline_s = float(os.environ.get('CIAOSR_STEP_DEADLINE_S', '900'))          # per image; a lost peer ends the job, not hangs it
         kw = dict(device_id=torch.device('cuda', torch.cuda.current_device())) if backend == 'nccl' else {}
         dist.init_process_group(backend, timeout=datetime.timedelta(seconds=max(deadline_s, 60.0)), **kw)
