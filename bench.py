@@ -131,6 +131,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         tag = tag[:-6] + '_bf16'
     if tag.endswith('_f16'):               # IEEE-half kernels: the bf16 kernels' work and peak (same MFMA rate)
         tag = tag[:-4] + '_bf16'
+    if tag in ('head_kv_chain_bf16', 'head_kv_chain_pairs_bf16'):   # the weights-stationary form of the 16-bit kv kernel (round 5): same work
+        tag = 'head_kv_fused_bf16'
     D, Dv, R = 9 * C, 10 * C, Q * J
     side = HW ** 0.5
     dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
@@ -181,6 +183,14 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
 
 
 def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
+    if tag.startswith('head_kv_chain_pairs'):
+        return 2.0
+    if tag.startswith('head_kv_chain'):
+        return 1.0
+    return _executed_ratio(tag, HW, C, precision, bf16_single)
+
+
+def _executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     """MFMA flops a kernel EXECUTES / its algorithmic flops (`kernel_work`).  1 unless the kernel restructures the contraction:
     Winograd F(2x2, 3x3) issues 16 multiplies per 2x2 output tile and channel pair instead of 36 (dense layers, logit table:
     dense_wino_f32.hip); the fp32 correlation scores are a 3x3 diagonal box sum of a K = C/2 per-pixel correlation whose D blocks
@@ -206,10 +216,10 @@ def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     return 1.0
 
 
-def roofline_object(tag, total_ms, launches, Q, HW, n_tiles, precision='fp32', bf16_single=False):
+def roofline_object(tag, total_ms, launches, Q, HW, n_tiles, precision='fp32', bf16_single=False, C=64):
     """The `roofline` entry of one kernel tag from its HIP-event time: algorithmic work / time against the gfx950 peak, with the
     executed-work twin (`executed_frac` <= 1 is the matrix pipe's share; `frac` may exceed 1 for Winograd / box-sum kernels)."""
-    work = kernel_work(tag, Q, HW)
+    work = kernel_work(tag, Q, HW, C=C)
     if not work or total_ms <= 0:
         return None
     amount, kind = work[0] * n_tiles, work[1]
@@ -219,19 +229,39 @@ def roofline_object(tag, total_ms, launches, Q, HW, n_tiles, precision='fp32', b
                     traffic=None, algorithmic_bytes_per_launch=round(amount / max(launches, 1)))
     peak = PEAK_F32_MFMA_TFLOPS if kind == 'flop' else PEAK_BF16_MFMA_TFLOPS
     ach = amount / (total_ms * 1e-3) / 1e12
-    ratio = executed_ratio(tag, HW, precision=precision, bf16_single=bf16_single)
+    ratio = executed_ratio(tag, HW, C=C, precision=precision, bf16_single=bf16_single)
     return dict(bound='mfma', achieved=round(ach, 3), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4), traffic=None,
                 algorithmic_flop_per_launch=round(amount / max(launches, 1)),
                 executed_flop_per_launch=round(amount * ratio / max(launches, 1)),
                 executed_frac=round(ach * ratio / peak, 4))
 
 
-def _cores():
+def _avail_cores():
     try:
-        avail = len(os.sched_getaffinity(0))
+        return max(1, len(os.sched_getaffinity(0)))
     except AttributeError:
-        avail = os.cpu_count() or 1
-    return max(1, min(avail, 16))                    # small ops: more threads only add contention
+        return max(1, os.cpu_count() or 1)
+
+
+def _cores():
+    return max(1, min(_avail_cores(), 16))           # small ops: more threads only add contention
+
+
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _thread_counts():
+    """Thread counts the CPU baseline is timed at: 16 (beyond that the port's small ops only add contention on the hosts seen so far)
+    and every core this process may run on ('N = all physical cores'); the faster one is reported."""
+    a = _avail_cores()
+    return sorted({min(a, 16), a})
 
 
 def cpu_baseline_c2(scale=4):
@@ -251,8 +281,8 @@ def cpu_baseline_c2(scale=4):
         if sum(times) > 45:
             break
     t = sorted(times[1:] or times)[len(times[1:] or times) // 2]
-    return dict(value=round(out.shape[-1] * out.shape[-2] / 1e6 / t, 5), unit='Mpix/s', cores=torch.get_num_threads(),
-                kind='port', sample=f'same workload (1 LR 48x48 -> 192x192 image), median of {len(times) - 1} '
+    return dict(value=round(out.shape[-1] * out.shape[-2] / 1e6 / t, 5), unit='Mpix/s', cores=torch.get_num_threads(), cpu_model=_cpu_model(),
+                cores_available=_avail_cores(), kind='port', sample=f'same workload (1 LR 48x48 -> 192x192 image), median of {len(times) - 1} '
                 f'runs after 1 warm-up, {t * 1e3:.0f} ms/img, torch CPU fp32, reference-style per-chunk cs_attn')
 
 
@@ -269,28 +299,36 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
     params = {k[len('generator.'):]: v.detach() for k, v in model.state_dict().items()}
     lq, _ = synthetic_pair(tile, tile, scale)
     x = lq - torch.tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1)
-    torch.set_num_threads(_cores())
     Q = (tile * scale) ** 2
     coord = orc.make_coord((tile * scale, tile * scale)).unsqueeze(0)[:, :eval_bsize].contiguous()
     cell = orc.make_cell((tile * scale, tile * scale)).unsqueeze(0)[:, :eval_bsize].contiguous()
-    with torch.no_grad():
-        orc.encoder_features(x[..., :48, :48], params)                     # warm-up of the thread pool / allocator
-        t0 = time.perf_counter()
-        feat = orc.encoder_features(x, params)
-        t_enc = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        orc.query_rgb(feat, coord, cell, params)                           # one chunk as the reference runs it
-        t_chunk = time.perf_counter() - t0
-        nl = torch.zeros_like(feat)                                        # timing only: values do not matter
-        t0 = time.perf_counter()
-        orc.query_rgb(feat, coord, cell, params, nonlocal_map=nl)          # same chunk without the cs_attn recompute
-        t_head = time.perf_counter() - t0
-    t_csa = max(t_chunk - t_head, 0.0)
     n_chunks = -(-Q // eval_bsize)
     last = (Q - (n_chunks - 1) * eval_bsize) / eval_bsize
-    tile_ref = t_enc + (n_chunks - 1) * t_chunk + (t_csa + last * t_head)
+    tried, best = {}, None
+    for n_thr in _thread_counts():                                          # the bounded sample at 16 threads and at every core: the faster counts
+        torch.set_num_threads(n_thr)
+        with torch.no_grad():
+            orc.encoder_features(x[..., :48, :48], params)                     # warm-up of the thread pool / allocator
+            t0 = time.perf_counter()
+            feat = orc.encoder_features(x, params)
+            t_enc = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            orc.query_rgb(feat, coord, cell, params)                           # one chunk as the reference runs it
+            t_chunk = time.perf_counter() - t0
+            nl = torch.zeros_like(feat)                                        # timing only: values do not matter
+            t0 = time.perf_counter()
+            orc.query_rgb(feat, coord, cell, params, nonlocal_map=nl)          # same chunk without the cs_attn recompute
+            t_head = time.perf_counter() - t0
+        t_csa = max(t_chunk - t_head, 0.0)
+        ref_s = t_enc + (n_chunks - 1) * t_chunk + (t_csa + last * t_head)
+        tried[str(n_thr)] = round(ref_s, 2)
+        if best is None or ref_s < best[0]:
+            best = (ref_s, n_thr, t_enc, t_chunk, t_head, t_csa)
+    tile_ref, n_best, t_enc, t_chunk, t_head, t_csa = best
+    torch.set_num_threads(n_best)
     tile_hoist = t_enc + t_csa + (Q / eval_bsize) * t_head
-    return dict(value=round(out_pixels / 1e6 / (n_tiles * tile_ref), 6), unit='Mpix/s', cores=torch.get_num_threads(),
+    return dict(value=round(out_pixels / 1e6 / (n_tiles * tile_ref), 6), unit='Mpix/s', cores=n_best, cpu_model=_cpu_model(),
+                cores_available=_avail_cores(), seconds_per_tile_by_threads=tried,
                 kind='port',
                 sample=f'EXTRAPOLATED from a bounded sample of one {tile}x{tile} LR tile: RDN trunk {t_enc:.2f} s + one eval_bsize={eval_bsize} '
                        f'chunk of query_rgb incl. its cs_attn recompute {t_chunk:.2f} s (cs_attn {t_csa:.2f} s, head {t_head:.2f} s) '
@@ -337,6 +375,64 @@ def live_pmc_traffic(kernel_substr, unit_workload, precision, timeout_s=300):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return round(2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]), vals['FETCH_SIZE'][1]
+
+
+def other_configs(dev):
+    """C1 and C5 of BASELINE.json at their own sizes (random-init weights of the reference's config files / ctor arguments): ms per image
+    and, from one profiled pass, the per-kernel times with a roofline object for the dominant kernel the work table knows and for the
+    fused head's kv kernel."""
+    import ciaosr_amd
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.coords import make_coord, make_cell
+    from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+    out = {}
+    mk = lambda i, o: dict(type='MLPRefiner', in_dim=i, out_dim=o, hidden_list=[256, 256, 256, 256])
+    cases = [
+        ('c1', dict(type=ciaosr_amd.LocalImplicitSREDSR, encoder=dict(type='EDSR', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16),
+                    imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000), 2.0, 64, ('fp32',)),
+        ('c5', dict(type=ciaosr_amd.LocalImplicitSRSWINIR, window_size=8,
+                    encoder=dict(type='SwinIR', upscale=4, in_chans=3, img_size=48, window_size=8, img_range=1., depths=[6, 6, 6, 6, 6, 6],
+                                 embed_dim=180, num_heads=[6, 6, 6, 6, 6, 6], mlp_ratio=2, upsampler='pixelshuffle', resi_connection='1conv'),
+                    imnet_q=mk(4, 3), imnet_k=mk(64, 64), imnet_v=mk(64, 64), feat_unfold=True, eval_bsize=30000), 3.3, 180, ('fp32', 'f16', 'bf16')),
+    ]
+    for name, gen, sc, C, precisions in cases:
+        try:
+            m = ciaosr_amd.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss'), rgb_mean=(0.4488, 0.4371, 0.4040), rgb_std=(1., 1., 1.),
+                                  test_cfg=dict(scale=sc)).eval()
+            seeded_init_(m, seed=0, gain=1.0)
+            m = m.to(dev)
+            m.test_cfg['allow_f16_substitute'] = True      # C5 'bf16' = the f16 kernels (LocalImplicitSRSWINIR.effective_options); labelled as such below
+            lq = synthetic_pair(48, 48, 4)[0].to(dev)
+            ht = wt = round(48 * sc)
+            coord, cell = hip_ops.make_coord_cell(ht, wt, dev)
+            coord, cell = coord.unsqueeze(0), cell.unsqueeze(0)
+            Qc, HWc = ht * wt, 48 * 48
+            for prec in precisions:
+                o = hip_ops.Options(prec)
+                eff = m.generator.effective_options(o)
+                label = f'{name}_{prec}' if eff.precision == prec else f'{name}_{prec}_runs_as_{eff.precision}'
+                for _ in range(3):
+                    m.restore(lq, coord, cell, options=o)
+                t = time_steps(lambda: m.restore(lq, coord, cell, options=o), 10, dev)
+                out[f'{label}_ms'] = round(t, 4)
+                out[f'{label}_mpix_s'] = round(Qc / 1e6 / (t * 1e-3), 3)
+                with hip_ops.profile():
+                    m.restore(lq, coord, cell, options=o)
+                    torch.cuda.synchronize(dev)
+                pr = hip_ops.profile.results()
+                out[f'{label}_kernels_ms'] = {k: round(v['total_ms'], 4) for k, v in sorted(pr.items(), key=lambda kv: -kv[1]['total_ms'])[:8]}
+                known = [k for k in sorted(pr, key=lambda k_: -pr[k_]['total_ms']) if kernel_work(k, Qc, HWc, C=C)]
+                kv = [k for k in known if k.startswith('head_kv_')]
+                for what, tags in (('roofline', known[:1]), ('head_kv_roofline', kv[:1])):
+                    if tags:
+                        ro = roofline_object(tags[0], pr[tags[0]]['total_ms'], pr[tags[0]]['launches'], Qc, HWc, 1, eff.precision, C=C)
+                        if ro:
+                            ro.update(kernel=tags[0], share_of_step=round(pr[tags[0]]['total_ms'] / max(sum(v['total_ms'] for v in pr.values()), 1e-9), 3))
+                            out[f'{label}_{what}'] = ro
+            del m
+        except Exception as e:      # noqa: BLE001 - an extra must not take the headline down
+            out[f'{name}_error'] = repr(e)[:300]
+    return out
 
 
 WORKLOADS = {
@@ -613,7 +709,8 @@ def main():
                 tag2fn = {'enc_dense_scatter': 'dense_scatter_small_kernel', 'enc_rdb_fused': 'rdb_fused_kernel',
                           'head_kv_fused': 'head_kv_fused_kernel', 'head_fused': 'head_fused_kernel',
                           'head_decode_fused': 'head_decode_fused_kernel', 'head_kv_fused_bf16': 'head_kv_fused_h16_kernel',
-                          'head_kv_fused_f16': 'head_kv_fused_h16_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
+                          'head_kv_fused_f16': 'head_kv_fused_h16_kernel', 'head_kv_chain_f16': 'head_kv_chain_kernel',
+                          'head_kv_chain_pairs_f16': 'head_kv_chain_kernel', 'head_kv_chain_pairs_bf16': 'head_kv_chain_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
                           'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel', 'enc_dense_wino4': 'dense_wino4_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
                 pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (4, 3))
@@ -740,6 +837,10 @@ def main():
                         extras[f'c3_{nm}_encoder_ahead_ms'] = round(t_, 1)
                         extras[f'c3_{nm}_encoder_ahead_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
                     model.test_cfg['encoder_ahead'] = False
+                # (3) the other BASELINE configs, every round: C1 (EDSR-CiaoSR x2, LR 48x48 -> 96x96) and C5 (SwinIR-CiaoSR x3.3, LR 48x48 ->
+                # 158x158; its "bf16" = the precision the generator really runs, see `effective_precision`), each with the roofline object of its
+                # dominant known kernel and of the fused head's kv kernel at C = 180
+                extras.update(other_configs(dev))
                 c2 = synthetic_pair(48, 48, scale)[0].to(dev)
                 for _ in range(3):
                     model.restore(c2)

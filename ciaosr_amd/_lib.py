@@ -29,7 +29,8 @@ class MlpT(C.Structure):
 class HeadWeightsT(C.Structure):
     _fields_ = [('channels', C.c_int), ('nonlocal_channels', C.c_int), ('nonlocal_max_scale', C.c_int), ('local_size', C.c_int),
                 ('no_unfold', C.c_int),
-                ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT), ('k_out_wino', C.c_void_p), ('k_out_wino4', C.c_void_p)]
+                ('softmax_scale', C.c_float), ('q', MlpT), ('k', MlpT), ('v', MlpT), ('k_out_wino', C.c_void_p), ('k_out_wino4', C.c_void_p),
+                ('chain16', C.c_void_p), ('chain16_pairs', C.c_void_p)]
 
 
 class CsAttnWeightsT(C.Structure):
@@ -45,10 +46,10 @@ class OptionsT(C.Structure):
     """ciaosr_options_t: per-call route options (include/ciaosr_hip.h)."""
     _fields_ = [('head_route', C.c_int), ('csa_composed_min', C.c_int), ('dense_min_tiles', C.c_int),
                 ('scatter_small_max', C.c_int), ('kv_rows', C.c_int), ('decode_rows', C.c_int), ('bf16_single', C.c_int),
-                ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('csa_attn_tile128', C.c_int), ('reserved', C.c_int * 1), ('f16_pairs', C.c_int)]
+                ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('csa_attn_tile128', C.c_int), ('query_grid_w', C.c_int), ('f16_pairs', C.c_int)]
 
 
-HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG, HEAD_TABLE_WINO2 = 1, 2, 4, 8, 16
+HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG, HEAD_TABLE_WINO2, HEAD_NO_CHAIN = 1, 2, 4, 8, 16, 32
 
 
 class ConvT(C.Structure):
@@ -116,6 +117,9 @@ SIGNATURES = {
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_bf16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_f16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ciaosr_head_chain_bytes': (_S, [C.POINTER(HeadWeightsT), _I]),
+    'ciaosr_pack_head_chain_bf16': (_I, [C.POINTER(HeadWeightsT), _I, _P, _P]),
+    'ciaosr_pack_head_chain_f16': (_I, [C.POINTER(HeadWeightsT), _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
     'ciaosr_gather_rows_f32': (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),

@@ -55,11 +55,11 @@ static inline bool allow_big_lds(LdsAttrOnce& once, K kernel, size_t bytes) {
 
 int launch_status(const char* what);
 
-// ciaosr_options_t hygiene, checked by every entry point that takes one: the reserved words must be 0 (a caller built against a
-// later, longer layout -- or passing garbage -- is refused instead of being half-understood) and the enumerated fields in range.
+// ciaosr_options_t hygiene, checked by every entry point that takes one: unknown route bits and out-of-range fields are refused
+// (a caller built against a later layout -- or passing garbage -- is refused instead of being half-understood).
 static inline bool options_ok(const ciaosr_options_t* o) {
     if (!o) return true;
-    return o->reserved[0] == 0 && (o->csa_attn_tile128 == 0 || o->csa_attn_tile128 == 1) && (o->head_route & ~31) == 0 && (o->kv_rows == 0 || o->kv_rows == 32 || o->kv_rows == 64) &&
+    return o->query_grid_w >= 0 && (o->csa_attn_tile128 == 0 || o->csa_attn_tile128 == 1) && (o->head_route & ~63) == 0 && (o->kv_rows == 0 || o->kv_rows == 32 || o->kv_rows == 64) &&
            (o->decode_rows == 0 || o->decode_rows == 32 || o->decode_rows == 64) && (o->bf16_single == 0 || o->bf16_single == 1) &&
            (o->dense_direct >= 0 && o->dense_direct <= 2) && (o->csa_scores_gemm == 0 || o->csa_scores_gemm == 1) &&
            o->f16_pairs >= 0 && o->f16_pairs <= 3;

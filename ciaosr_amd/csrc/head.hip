@@ -53,6 +53,7 @@ static size_t head_ws_bytes(const HeadPlan& p) {
     n += (size_t)p.qc + R;                    // q_idx, k_idx (ints, same size as float)
     n += (size_t)p.HW * 9 * kLdG + (size_t)kQkChunk * p.D;   // logit table + one chunk of its GEMM rows
     n += (size_t)128 * p.D + 64;                             // bf16 mode: transposed bf16 copy of imnet_k's output layer
+    n += 64;                                                 // 16-bit chained kernel: its "redo with the 128-row kernel" flag
     return n * sizeof(float) + p.csa_bytes + 32 * 256;
 }
 
@@ -179,6 +180,7 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     float* G = ar.take<float>((size_t)p.HW * 9 * kLdG);
     float* QK = ar.take<float>((size_t)kQkChunk * p.D);
     unsigned short* W5T = reinterpret_cast<unsigned short*>(ar.take<float>((size_t)128 * p.D + 64));
+    int* chain_flag = ar.take<int>(64);
     char* csa_ws = ar.take<char>(p.csa_bytes);
     if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
 
@@ -274,6 +276,18 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             kp.Z = Z; kp.ldz = p.Dv;
             kp.rows_per_wg = opt ? opt->kv_rows : 0;
             kp.G = use_table ? G : nullptr; kp.ldg = kLdG; kp.g_bytes = (unsigned)((size_t)p.HW * 9 * kLdG * sizeof(float));
+            kp.gate = nullptr;
+            // 16-bit default: the weights-stationary, register-chained kernel (head_chain_h16.hip) where its weight stream is given and the
+            // logit table exists; the 128-row kernel is launched behind it, gated on the flag the chained kernel raises when a key leaves its
+            // query's 3x3 neighbourhood (cannot happen for 0 < cell < 1): it then redoes the launch, else it returns at once
+            const void* blob = lo ? w->chain16_pairs : w->chain16;
+            const bool chained = bf16 && !wide16 && !x3 && use_table && blob && !(route & CIAOSR_HEAD_NO_CHAIN) && h16_ops(prec).head_chain_ok(w) &&
+                                 (size_t)nq * p.Dv * 2 < 0xFFFFFF00ull;
+            if (chained) {
+                if (hipMemsetAsync(chain_flag, 0, sizeof(int), s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
+                RUN(h16_ops(prec).head_kv_chain(kp, w, blob, lo ? 1 : 0, opt ? opt->query_grid_w : 0, chain_flag, s));
+                kp.gate = chain_flag;
+            }
             RUN(wide16 ? wide::head_kv_fused_wide(kp, wide_mode, s) : bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;
@@ -388,4 +402,27 @@ extern "C" int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp
         cur = dst; ld_cur = ldd; k_cur = m->width[i];
     }
     return CIAOSR_OK;
+}
+
+// ---- weight stream of the weights-stationary 16-bit head (head_chain_h16.hip) ---------------------------------------------------------
+static bool chain_weights_ok(const ciaosr_head_weights_t* w) {
+    if (!w || !mlp_ok(w->k) || !mlp_ok(w->v)) return false;
+    return b16::head_chain_ok(w);
+}
+
+extern "C" size_t ciaosr_head_chain_bytes(const ciaosr_head_weights_t* w, int pairs) {
+    if (!chain_weights_ok(w)) return 0;
+    return b16::head_chain_bytes(w, pairs ? 1 : 0);
+}
+
+extern "C" int ciaosr_pack_head_chain_bf16(const ciaosr_head_weights_t* w, int pairs, void* out, void* stream) {
+    CIAOSR_CHECK_ARG(out && (pairs == 0 || pairs == 1));
+    if (!chain_weights_ok(w)) return CIAOSR_ERR_UNSUPPORTED;
+    return b16::pack_head_chain(w, pairs, out, (hipStream_t)stream);
+}
+
+extern "C" int ciaosr_pack_head_chain_f16(const ciaosr_head_weights_t* w, int pairs, void* out, void* stream) {
+    CIAOSR_CHECK_ARG(out && (pairs == 0 || pairs == 1));
+    if (!chain_weights_ok(w)) return CIAOSR_ERR_UNSUPPORTED;
+    return f16::pack_head_chain(w, pairs, out, (hipStream_t)stream);
 }

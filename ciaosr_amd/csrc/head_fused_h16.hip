@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void head_kv_fused_h16_kernel(FusedKVP p) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int qbase = blockIdx.x * (HBM_ / 4);
+    if (p.gate && __builtin_nontemporal_load(p.gate) == 0) return;       // fallback launch behind the chained kernel: nothing to redo
 
     HPROBE16(0);
     // ---- index math: row m = 32 j + q --------------------------------------------------------------------------

@@ -30,6 +30,7 @@ class PackedHead:
         self._keep = None
         self._st_f16 = None       # copy of the struct whose frag16 hold IEEE-half fragments (packed on first use)
         self._keep_f16 = None
+        self._grid_opts = {}      # (Options, grid width) -> Options carrying the traversal hint
 
     def _version_key(self):
         mods = [self.net.imnet_q, self.net.imnet_k, self.net.imnet_v]
@@ -94,6 +95,8 @@ class PackedHead:
             self._build()
             self._st_f16 = None
         if half != 'f16':
+            if half == 'bf16' and not self._st.chain16_pairs:
+                self._keep += self._pack_chain(self._st, 'bf16')
             return self._st
         if self._st_f16 is None:
             st = _lib.HeadWeightsT()
@@ -111,8 +114,29 @@ class PackedHead:
                     _lib.call('ciaosr_pack_fragments_f16_lo', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(lo), hip_ops.stream_ptr())
                     keep.append(lo)
                     m.frag16_lo[i] = lo.data_ptr()
+            keep += self._pack_chain(st, 'f16')
             self._st_f16, self._keep_f16 = st, keep
         return self._st_f16
+
+    @staticmethod
+    def _pack_chain(st, half):
+        """Weight stream of the weights-stationary 16-bit head kernel (csrc/head_chain_h16.hip) for both weight forms (single 16-bit
+        weights / hi + lo pairs), where the head has the shape it covers (hidden_list = [256] * 4); else the pointers stay NULL and
+        the 128-row kernels run."""
+        lib = _lib.load()
+        keep = []
+        st.chain16 = None
+        st.chain16_pairs = None
+        for pairs, field in ((0, 'chain16'), (1, 'chain16_pairs')):
+            n = lib.ciaosr_head_chain_bytes(C.byref(st), pairs)
+            if n == 0:
+                break
+            dev = torch.device('cuda', torch.cuda.current_device())
+            blob = torch.empty(n, dtype=torch.uint8, device=dev)
+            _lib.call('ciaosr_pack_head_chain_' + half, C.byref(st), pairs, hip_ops.ptr(blob), hip_ops.stream_ptr())
+            keep.append(blob)
+            setattr(st, field, blob.data_ptr())
+        return keep
 
     def _build(self):
         key = self._version_key()
@@ -137,6 +161,8 @@ class PackedHead:
         st.k, kk, sk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
         st.k_out_wino = None
         st.k_out_wino4 = None
+        st.chain16 = None
+        st.chain16_pairs = None
         w5 = self._last_wb[0]                                   # imnet_k's output layer [9C][256], rows in device order (tap, c)
         if unfold and Cc == 64 and tuple(w5.shape) == (576, 256):
             # the logit table as nine 3x3 convolutions (head.hip): g[n][c][a][b] = W5[(3a+b) C + c][n] in Winograd F(2x2, 3x3) form,
@@ -186,6 +212,15 @@ class PackedHead:
         Cc, H, W = feature_chw.shape
         Q = coord.shape[0]
         st = self.struct(opt.half)
+        gw = hip_ops.grid_width_of(coord) if (opt.half and not opt.query_grid_w) else 0
+        if gw:                        # traversal hint of the 16-bit chained head kernel: the queries are a make_coord grid
+            key = (opt, gw)
+            hinted = self._grid_opts.get(key)
+            if hinted is None:
+                if len(self._grid_opts) > 64:
+                    self._grid_opts.clear()
+                hinted = self._grid_opts[key] = opt.replace(query_grid_w=gw)
+            opt = hinted
         cs = None
         if net.non_local_attn:
             cs, _ = net.cs_attn.packed()

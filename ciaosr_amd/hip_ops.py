@@ -53,8 +53,19 @@ def make_coord_cell(ht, wt, device):
         _lib.call('ciaosr_make_coord_cell_f32', ptr(coord), ptr(cell), ht, wt, stream_ptr())
         if len(_coord_cache) > 16:
             _coord_cache.clear()
+            _grid_width.clear()
         hit = _coord_cache[key] = (coord, cell)
+        _grid_width[(coord.data_ptr(), ht * wt)] = wt
     return hit
+
+
+_grid_width = {}
+
+
+def grid_width_of(coord):
+    """Columns of the row-major target grid when `coord` [Q, 2] is (a view of) a tensor `make_coord_cell` produced, else 0: the
+    traversal hint ciaosr_options_t.query_grid_w of the 16-bit fused head (results do not depend on it)."""
+    return _grid_width.get((coord.data_ptr(), coord.shape[0]), 0)
 
 
 def ptr(t):
@@ -200,7 +211,7 @@ class Options:
                MFMAs per product, fp32 trunk and tables, half cs_attn contractions): selects the _f32 / _bf16 / _f16 entry point.
     the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
     Immutable; `replace()` returns a modified copy."""
-    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'dense_direct', 'csa_scores_gemm', 'csa_attn_tile128', 'f16_pairs')
+    _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'dense_direct', 'csa_scores_gemm', 'csa_attn_tile128', 'query_grid_w', 'f16_pairs')
     __slots__ = ('precision',) + _C_FIELDS + ('_c',)
 
     def __init__(self, precision='fp32', **kw):

@@ -90,6 +90,10 @@ class LocalImplicitSRNet(nn.Module):
         """The hip_ops.Options a call on THIS generator really runs with (subclasses may narrow what they accept)."""
         return hip_ops.as_options(options)
 
+    def bind_test_cfg(self, test_cfg):
+        """The restorer's test_cfg dict (kept by reference: later edits are seen), for the extensions a generator reads from it."""
+        object.__setattr__(self, '_test_cfg', test_cfg)
+
     def _require_hip_trunk(self, x):
         """No silent PyTorch trunk: CPU input or a trunk shape outside the HIP library's coverage is an error."""
         hip_ops.require_gpu(x.contiguous() if x.dtype == torch.float32 else x.float().contiguous())
@@ -204,20 +208,29 @@ class LocalImplicitSRSWINIR(LocalImplicitSRNet):
         return self._gen_feature_hip(img, options)
 
     _warned_bf16 = False
+    allow_f16_substitute = False
 
     def effective_options(self, options=None):
-        """`precision='bf16'` on the SwinIR-CiaoSR head (C = 180: 1620-wide logit dot products in front of the 4-way softmax) runs
-        the f16 kernels.  Measured against the reference at BASELINE config 5's own size: the bf16 mode's 8-bit ACTIVATIONS (weights as
-        pairs cannot help) leave rms 3.6e-3 = 0.060 dB at a 30-dB quality level, six times the 0.01 dB gate, where IEEE half -- same
-        MFMA rate, 11-bit activations -- measures 0.0007 dB.  A mode that misses the gate is not offered silently: one warning, then
-        f16 (the launch-bound SwinIR trunk is fp32 in every mode)."""
+        """`precision='bf16'` does not exist on the SwinIR-CiaoSR head (C = 180: 1620-wide logit dot products in front of the 4-way
+        softmax).  Measured against the reference at BASELINE config 5's own size, the bf16 mode's 8-bit ACTIVATIONS (weights as pairs
+        cannot help) leave rms 3.6e-3 = 0.060 dB at a 30-dB quality level, six times the 0.01 dB gate, where IEEE half -- same MFMA
+        rate, 11-bit activations -- measures 0.0007 dB.  A mode that misses the gate is not offered, and is not swapped silently either:
+        the call raises CiaoSRHipError unless the caller opts in to the substitution -- `test_cfg.allow_f16_substitute = True` (or the
+        generator attribute of the same name): one warning, then the f16 kernels, and `effective_options(opt).precision == 'f16'` is what
+        labels and ratios must be taken from (bench.py does).  The launch-bound SwinIR trunk is fp32 in every mode."""
         opt = hip_ops.as_options(options)
         if opt.precision != 'bf16':
             return opt
+        cfg = getattr(self, '_test_cfg', None)
+        if not (self.allow_f16_substitute or (cfg is not None and cfg.get('allow_f16_substitute', False))):
+            raise CiaoSRHipError("precision='bf16' is not offered on the SwinIR-CiaoSR head: its 8-bit activations in front of the local "
+                                 "attention measure 0.060 dB at 30 dB on BASELINE config 5, six times the 0.01 dB PSNR gate.  Use "
+                                 "precision='f16' (same MFMA rate, 0.0007 dB), or set test_cfg.allow_f16_substitute = True to have "
+                                 "'bf16' run the f16 kernels")
         if not LocalImplicitSRSWINIR._warned_bf16:
             import warnings
             warnings.warn("precision='bf16' on the SwinIR-CiaoSR head does not meet the 0.01 dB PSNR gate (8-bit activations in front of "
-                          "the local attention: 0.060 dB at 30 dB on BASELINE config 5); running the IEEE-half ('f16') kernels instead",
-                          RuntimeWarning, stacklevel=3)
+                          "the local attention: 0.060 dB at 30 dB on BASELINE config 5); running the IEEE-half ('f16') kernels instead "
+                          "(allow_f16_substitute)", RuntimeWarning, stacklevel=3)
             LocalImplicitSRSWINIR._warned_bf16 = True
         return opt.replace(precision='f16', bf16_single=0)

@@ -97,3 +97,34 @@ def synthetic_pair(h, w, scale, seed=1234):
     lq = torch.nn.functional.interpolate(gt, size=(h, w), mode='bicubic', antialias=True,
                                          align_corners=False).clamp(0, 1)
     return lq, gt
+
+
+@torch.no_grad()
+def trained_like_(module, seed=0, sigma=1.0, outlier_frac=0.01, outlier_scale=20.0, bias_std=0.2):
+    """Re-shape the TRUNK weights of an already `seeded_init_`-ed model towards the statistics of a trained network -- what the
+    Winograd forms of the dense layers are sensitive to and Gaussian weights do not show: every 4-D convolution weight outside the head
+    (`imnet_*`, `cs_attn*`) gets a log-normal scale per OUTPUT channel (exp(sigma z), normalised to unit mean square), `outlier_frac` of
+    its entries are multiplied by `outlier_scale`, and its bias a N(0, bias_std) offset: per-channel spread, a few large weights,
+    DC-offset features.  Deterministic per (seed, parameter name), like `seeded_init_`.  Returns the sha256 of the resulting weights."""
+    sd = module.state_dict()
+    for name in sorted(sd.keys()):
+        t = sd[name]
+        parts = name.split('.')
+        if not torch.is_floating_point(t) or any(p.startswith('imnet_') or p.startswith('cs_attn') for p in parts):
+            continue
+        g = _gen(seed + 7919, name)
+        if parts[-1] == 'weight' and t.dim() == 4:
+            z = torch.randn(t.shape[0], generator=g)
+            # E[scale^2] = 1.  exp() through Python's libm on doubles, rounded to fp32 once: torch.exp's vectorised fp32 path differs in
+            # the last bit between CPU generations (AVX2 / AVX-512), and the weights' sha256 must not depend on the host
+            scale = torch.tensor([math.exp(sigma * zv - sigma * sigma) for zv in z.double().tolist()], dtype=torch.float64).float()
+            mask = torch.rand(t.shape, generator=g) < outlier_frac
+            w = t * scale.view(-1, 1, 1, 1)
+            w = torch.where(mask, w * outlier_scale, w)
+            # expected rms unchanged, so that the gain keeps its meaning -- by the ANALYTIC factor (a measured rms would depend on the
+            # reduction order, i.e. on the host's thread count, and with it the last bit of every weight and the fixture's sha256)
+            w = w * (1.0 / math.sqrt(1.0 + outlier_frac * (outlier_scale * outlier_scale - 1.0)))
+            t.copy_(w)
+        elif parts[-1] == 'bias' and t.dim() == 1 and len(parts) >= 2 and 'norm' not in parts[-2]:
+            t.add_(torch.randn(t.shape, generator=g) * bias_std)
+    return state_dict_sha256(sd)

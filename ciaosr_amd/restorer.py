@@ -39,6 +39,9 @@ class BasicRestorer(nn.Module):
         self.test_cfg = _as_cfg(test_cfg)
         self.fp16_enabled = False
         self.generator = build_backbone(generator)
+        # the generator sees the restorer's test_cfg (one dict, looked up per call): `allow_f16_substitute` is read from it
+        if hasattr(self.generator, 'bind_test_cfg'):
+            self.generator.bind_test_cfg(self.test_cfg)
         self.init_weights(pretrained)
         self.pixel_loss = build_loss(pixel_loss)
 

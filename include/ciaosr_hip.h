@@ -71,6 +71,10 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
                                        * same result up to the fp32 summation order of the logit dot product, measured equal in time
                                        * (f16x3 always runs its 128-row two-array form of that kernel) */
 #define CIAOSR_HEAD_TABLE_WINO2 16    /* head_route bit 4: _f32 logit table in Winograd F(2x2, 3x3) form even when k_out_wino4 is given */
+#define CIAOSR_HEAD_NO_CHAIN 32       /* head_route bit 5: _bf16 / _f16 entries: the 128-row kernels that stream every weight fragment from L2
+                                       * (head_fused_h16.hip) even when ciaosr_head_weights_t.chain16 is given; default = the weights-stationary,
+                                       * register-chained kernel (head_chain_h16.hip).  Same products, other fp32 summation order of the logit dot
+                                       * product and of z; the tail term of layer 0 enters through the MFMA as hi + lo pairs */
 typedef struct ciaosr_options {
     int head_route;         /* CIAOSR_HEAD_* bits; 0 = automatic */
     int csa_composed_min;   /* cs_attn: LR pixels (after padding) from which the composed fold+down tail applies;
@@ -94,7 +98,10 @@ typedef struct ciaosr_options {
     int csa_attn_tile128;   /* _f32 cs_attn, attn.V (softmax formed in the operand staging): 0 (default) = the 192 x 256 one-workgroup-per-CU kernel
                              * (gemm_big_f32.hip) where the problem fills the chip (>= 256 workgroup tiles, K a multiple of 16), else and with 1 the
                              * 128 x 128 kernel.  Bitwise the same result */
-    int reserved[1];        /* must be 0 (checked by every entry point that takes the struct: a non-zero word is CIAOSR_ERR_BAD_ARG) */
+    int query_grid_w;       /* traversal hint of the 16-bit fused head, >= 0 (a negative value is CIAOSR_ERR_BAD_ARG): W > 0 = the Q queries of
+                             * the call are the rows of a row-major grid with W columns (q = i W + j, Q a multiple of W: what
+                             * ciaosr_make_coord_cell_f32 produces); the chained kernel then walks them in 16 x 4 blocks so that a wave's rows
+                             * gather from a handful of LR pixels.  Results do not depend on it; 0 = walk them in index order */
     int f16_pairs;          /* _f16 entries: 0 (default) = one IEEE-half weight per product; 1 = every dense-layer / head weight enters
                              * the MFMA as a half PAIR hi + lo (hi = half(w), lo = half(w - hi): ~20 mantissa bits, two MFMAs per product)
                              * and the layers the plain f16 mode runs with single 16-bit weights elsewhere (RDB local feature fusion,
@@ -241,7 +248,22 @@ typedef struct ciaosr_head_weights {
      * packed by ciaosr_pack_fragments_f32, the 36 arrays back to back (dense_wino4_f32.hip: 2.25x fewer MFMAs than the F(2x2) form);
      * preferred over k_out_wino unless head_route has CIAOSR_HEAD_TABLE_WINO2.  NULL = the F(2x2) form (or the GEMM) */
     const float* k_out_wino4;
+    /* optional (16-bit entries; hidden_list = [256] * 4 for imnet_k and imnet_v): the weight stream of the weights-stationary head kernel,
+     * packed by ciaosr_pack_head_chain_bf16 / _f16 with pairs = 0 (chain16: one 16-bit weight per product) and pairs = 1 (chain16_pairs:
+     * every tile followed by its rounding residuals; read by the _bf16 entry unless opt->bf16_single, by the _f16 entry with
+     * opt->f16_pairs = 1).  ciaosr_head_chain_bytes() each.  NULL = the kernels that read ciaosr_mlp_t.frag16 */
+    const void* chain16;
+    const void* chain16_pairs;
 } ciaosr_head_weights_t;
+
+/* Weight stream of the weights-stationary 16-bit head (head_chain_h16.hip): [tail fragments of imnet_k | imnet_v layer 0: 8 KB each]
+ * [per 32-column tile of imnet_k layers 1-3, imnet_v layers 1-3 and imnet_v's output layer: 16 fragments [ks][lane][8 x 16 bit], lane
+ * (i = lane & 31, g = lane >> 5) element e holding W[32 T + i][16 ks + 8 (e >> 2) + 4 g + (e & 3)] -- the k order in which the
+ * accumulators of one layer are the operand registers of the next; pairs: + the same 16 fragments of w - h16(w)], padded to whole
+ * 32-KB slots.  `w` must hold the fp32 weights (device order).  Replaces the per-layer Linear calls of mlp:87-102 at net:202-206. */
+size_t ciaosr_head_chain_bytes(const ciaosr_head_weights_t* w, int pairs);
+int ciaosr_pack_head_chain_bf16(const ciaosr_head_weights_t* w, int pairs, void* out, void* stream);
+int ciaosr_pack_head_chain_f16(const ciaosr_head_weights_t* w, int pairs, void* out, void* stream);
 
 /* Grid-centre coordinates and cells of an Ht x Wt target: coord[q] = (seq_y[i], seq_x[j]) with
  * seq[i] = fp32(-1 + 1/n) + fp32(2/n) * fp32(i), cell[q] = (2/Ht, 2/Wt), q = i*Wt + j

@@ -481,6 +481,72 @@ def test_half_head_wide_and_narrow_workgroups_agree(dev, C, hw, target):
         assert e < 1e-4 * max(scale, 1.0), (route, e)
 
 
+@pytest.mark.parametrize('C,hw,target', [(64, (21, 30), (59, 83)), (64, (48, 48), (192, 192)), (180, (12, 16), (40, 53))])
+def test_chained_16bit_head_kernel_vs_the_128_row_kernels(dev, C, hw, target):
+    """Round 5: the default 16-bit kv kernel is the weights-stationary, register-chained one (csrc/head_chain_h16.hip; tags
+    head_kv_chain_{f16 | pairs_f16 | pairs_bf16 | bf16}); head_route bit HEAD_NO_CHAIN keeps the 128-row kernels (head_fused_h16.hip).
+    Same rounding points except the layer-0 tail term (hi + lo pairs through the MFMA instead of fp32 FMAs) and the fp32 summation orders
+    of the logit and of z: the two agree far inside the 16-bit modes' own distance to fp32.  Ragged sizes (the target grid does not
+    divide into 16 x 4 blocks, Q not a multiple of 64), C = 180 (57 output units: an odd count, the padded tile), every weight form.
+    The traversal hint must not change a bit: queries given as a make_coord grid (hinted, walked in 16 x 4 blocks) and as the same
+    coordinates in a tensor of their own (index order) give the same output wherever both run the chained kernel."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd._lib import HEAD_NO_CHAIN
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(C, (256,) * 4, seeded_head(C, 3, head_gain=2.0), dev, eval_bsize=30000)
+    feat = randn((1, C) + hw, 11).to(dev)
+    ht, wt = target
+    own = (make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev))
+    hc, hl = hip_ops.make_coord_cell(ht, wt, dev)
+    hinted = (hc.unsqueeze(0), hl.unsqueeze(0))
+    assert torch.equal(hinted[0], own[0]) and hip_ops.grid_width_of(hinted[0][0]) == wt and hip_ops.grid_width_of(own[0][0]) == 0
+    x = (randn((1, 3) + hw, 12) * 0.3).to(dev)
+    fp32 = g._predict([feat], own[0], own[1], 30000, x, hip_ops.Options('fp32')).cpu()
+    scale = fp32.abs().max().item()
+    for prec, kw, tag in (('f16', {}, 'head_kv_chain_f16'), ('f16-pairs', {}, 'head_kv_chain_pairs_f16'), ('bf16', {}, 'head_kv_chain_pairs_bf16'),
+                          ('bf16', dict(bf16_single=1), 'head_kv_chain_bf16')):
+        old = g._predict([feat], own[0], own[1], 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_CHAIN, **kw)).cpu()
+        with hip_ops.profile():
+            new = g._predict([feat], hinted[0], hinted[1], 30000, x, hip_ops.Options(prec, **kw)).cpu()
+        prof = hip_ops.profile.results()
+        assert tag in prof and prof[tag]['launches'] == 1, (tag, sorted(prof))
+        with hip_ops.profile():
+            unhinted = g._predict([feat], own[0], own[1], 30000, x, hip_ops.Options(prec, **kw)).cpu()
+        d, e_new, e_old = (new - old).abs().max().item(), (new - fp32).abs().max().item(), (old - fp32).abs().max().item()
+        print(f'C={C} {target} {prec} {kw}: chained vs 128-row {d:.2e}; vs fp32: chained {e_new:.2e}, 128-row {e_old:.2e} (scale {scale:.2f})')
+        assert torch.isfinite(new).all()
+        assert d < (2e-2 if prec == 'bf16' else 2e-3) * scale, (prec, d)
+        assert e_new < 1.5 * e_old + 1e-4 * scale, (prec, e_new, e_old)
+        # index-order traversal: either the chained kernel again (bitwise the hinted result: rows do not depend on their row tile) or --
+        # where 8 consecutive queries of a row leave a row tile's 4 x 4 key-pixel window -- the flagged fallback = the 128-row result
+        assert torch.equal(unhinted, new) or torch.equal(unhinted, old), (prec, (unhinted - new).abs().max().item())
+
+
+def test_chained_16bit_head_falls_back_when_a_row_tile_leaves_its_window(dev):
+    """Queries in RANDOM order (a shuffled target grid: no traversal hint, eight consecutive queries scattered over the map) put the key
+    pixels of a row tile outside its 4 x 4 gather window: the chained kernel raises the launch's flag and the 128-row kernel, launched
+    behind it and gated on that flag, redoes the launch -- bitwise the HEAD_NO_CHAIN result, and finite.  (The same happens for target
+    grids coarser than the LR map; those are too small to have a logit table and never reach the chained kernel.)"""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd._lib import HEAD_NO_CHAIN
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 3, head_gain=2.0), dev, eval_bsize=30000)
+    feat = randn((1, 64, 24, 32), 11).to(dev)
+    perm = torch.randperm(96 * 128, generator=torch.Generator().manual_seed(4))
+    coord = make_coord((96, 128))[perm].unsqueeze(0).to(dev)
+    cell = make_cell((96, 128))[perm].unsqueeze(0).to(dev)
+    x = (randn((1, 3, 24, 32), 12) * 0.3).to(dev)
+    for prec in ('f16', 'bf16'):
+        old = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_CHAIN))
+        with hip_ops.profile():
+            new = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec))
+        prof = hip_ops.profile.results()
+        chain = [k for k in prof if k.startswith('head_kv_chain')]
+        fused = [k for k in prof if k.startswith('head_kv_fused')]
+        assert chain and fused and prof[fused[0]]['total_ms'] > 0.2 * prof[chain[0]]['total_ms'], (sorted(prof), 'the fallback did not do the work')
+        assert torch.isfinite(new).all() and torch.equal(new, old), (prec, (new - old).abs().max().item())
+
+
 def test_fused_and_staged_head_paths_agree(dev):
     """The fused kernels (head_kv_fused / head_decode_fused) against the staged per-layer path on the
     same inputs (both through ciaosr_head_forward_f32), including a ragged last workgroup."""
@@ -842,6 +908,53 @@ def test_e2e_restorer_vs_golden(dev, tag, kind, scale):
     assert d_psnr <= 0.01, d_psnr
 
 
+@pytest.mark.parametrize('size', [48, 64])
+def test_condition_stress_trained_like_trunk_vs_reference(dev, size):
+    """The fp32 default route is not an fmaf chain any more (Winograd F(4x4, 3x3) dense layers with transform constants up to 8 and
+    1/24, the logit table as Winograd convolutions of product maps), and every other fixture has Gaussian weights on a smooth image.
+    This one has the statistics a TRAINED RDN lives in -- per-output-channel log-normal weight scales, 1 % of the weights x20, bias
+    offsets, an input with a DC offset and a step edge, trunk features of std ~10 and magnitude ~100 (tools/make_golden.py gen_stress,
+    produced by the unmodified reference's CiaoSR.forward_test) -- and is run with the Winograd routes FORCED on these small maps
+    (dense_min_tiles = 1): RGB within the north-star 1e-3 of the reference on every trunk route, trunk features against the fp64
+    evaluation reported per route and bounded relative to the feature scale."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.init_utils import seeded_init_, trained_like_
+    fx = load_golden(f'stress_rdn_x4_{size}')
+    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
+    seeded_init_(model, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=float(fx['head_gain']))
+    assert trained_like_(model, seed=int(fx['weight_seed']), sigma=float(fx['sigma'])) == str(fx['sha'])
+    model = model.to(dev)
+    lq = _t(fx['lq']).to(dev)
+    ref, f64, f32ref = _t(fx['out']), _t(fx['feat64']), _t(fx['feat'])
+    fscale = f64.abs().max().item()
+    assert fscale > 50 and f64.std().item() > 5                       # the regime the fixture exists for
+    routes = {'wino4 (default on big maps)': dict(dense_min_tiles=1, scatter_small_max=-1),
+              'wino2': dict(dense_min_tiles=1, scatter_small_max=-1, dense_direct=2),
+              'direct': dict(dense_min_tiles=1, scatter_small_max=-1, dense_direct=1),
+              'small-map default (scatter form)': {}}
+    print(f'stress {size}x{size}: feature scale {fscale:.1f}; reference fp32 trunk vs fp64 {(f32ref - f64).abs().max().item():.2e}')
+    for name, kw in routes.items():
+        opt = hip_ops.Options('fp32', **kw)
+        with hip_ops.profile():
+            feat = model.generator.gen_feature(model.normalize(lq), opt)[0].cpu()
+        prof = hip_ops.profile.results()
+        want = {'wino4 (default on big maps)': 'enc_dense_wino4', 'wino2': 'enc_dense_wino', 'direct': 'enc_dense_gather',
+                'small-map default (scatter form)': 'enc_dense_scatter'}[name]
+        assert want in prof, (name, sorted(prof))
+        ferr = (feat - f64).abs().max().item()
+        out = model.restore(lq, options=opt).cpu()
+        err = (out - ref).abs().max().item()
+        print(f'  {name:34s} trunk max|d| vs fp64 {ferr:.2e} ({ferr / fscale:.1e} of scale)   RGB max|d| vs reference {err:.2e}')
+        assert ferr < 2e-5 * fscale, (name, ferr)
+        assert err < NORTH_STAR_TOL, (name, err)
+    # the logit table's Winograd form against its GEMM form on the same features
+    from ciaosr_amd._lib import HEAD_TABLE_GEMM
+    a = model.restore(lq, options=hip_ops.Options('fp32')).cpu()
+    b = model.restore(lq, options=hip_ops.Options('fp32', head_route=HEAD_TABLE_GEMM)).cpu()
+    print(f'  logit table: Winograd vs GEMM form, RGB max|d| {(a - b).abs().max().item():.2e}')
+    assert (b - ref).abs().max().item() < NORTH_STAR_TOL
+
+
 @pytest.mark.parametrize('precision', ['fp32', 'bf16', 'f16', 'f16-pairs'])
 def test_whole_path_never_reads_scratch_it_did_not_write(dev, precision):
     """RDN x4 on a ragged 45x51 LR image (nothing divides the tile sizes of any kernel): second run with every scratch buffer of
@@ -956,6 +1069,9 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         sfx = '_f16' if precision.startswith('f16') else '_bf16'
         for tag in ('enc_dense', 'csa_attn_v', 'csa_scores', 'head_kv_fused', 'head_logit_table'):
             assert tag + sfx in prof, (tag + sfx, sorted(prof))
+        # the kv kernel that did the work: the chained one (its gated fallback 'head_kv_fused' + sfx is launched behind it and returns at once)
+        chain = {'bf16': 'head_kv_chain_pairs_bf16', 'bf16-single': 'head_kv_chain_bf16', 'f16': 'head_kv_chain_f16', 'f16-pairs': 'head_kv_chain_pairs_f16'}[precision]
+        assert chain in prof and prof[chain]['total_ms'] > 20 * prof['head_kv_fused' + sfx]['total_ms'], (chain, prof.get(chain), prof['head_kv_fused' + sfx])
     assert out.shape == (1, 3, 768, 768)
     errs = _tile192_checks(out, fx, None)
     psnr_build = psnr_tensors(out, gt, crop_border=4)
@@ -1200,11 +1316,18 @@ def test_swinir_e2e_vs_golden(dev, precision):
     ht, wt = [int(v) for v in fx['target']]
     coord, cell = make_coord((ht, wt)).unsqueeze(0).to(dev), make_cell((ht, wt)).unsqueeze(0).to(dev)
     model.test_cfg['precision'] = precision
+    if precision == 'bf16':
+        # not offered on the SwinIR head (it misses the gate): refused, unless the caller opts in to the f16 substitution
+        from ciaosr_amd._lib import CiaoSRHipError
+        with pytest.raises(CiaoSRHipError, match='allow_f16_substitute'):
+            model(lq=_t(fx['lq']).to(dev), gt=None, test_mode=True, coord=coord, cell=cell)
+        model.test_cfg['allow_f16_substitute'] = True
+        assert model.generator.effective_options('bf16').precision == 'f16'
     with hip_ops.profile():
         out = model(lq=_t(fx['lq']).to(dev), gt=None, test_mode=True, coord=coord, cell=cell)['output']
-    # precision='bf16' on the SwinIR head runs the f16 kernels (LocalImplicitSRSWINIR.effective_options)
-    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_f16', 'f16': 'head_kv_fused_f16'}[precision] in hip_ops.profile.results()
-    assert 'head_kv_fused_bf16' not in hip_ops.profile.results()
+    # precision='bf16' + allow_f16_substitute on the SwinIR head runs the f16 kernels (LocalImplicitSRSWINIR.effective_options)
+    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_chain_f16', 'f16': 'head_kv_chain_f16'}[precision] in hip_ops.profile.results()
+    assert not any(k.endswith('_bf16') and k.startswith('head_kv') for k in hip_ops.profile.results())
     ref = _t(fx['out'])
     err = (out - ref).abs().max().item()
     _, gt = synthetic_pair(24, 24, 3.3)
@@ -1245,15 +1368,20 @@ def test_swinir_c5_at_its_own_size_vs_reference(dev, precision):
         assert ferr < 2e-4 * max(want.abs().max().item(), 1.0), ferr
     model.test_cfg['precision'] = precision
     import warnings
+    from ciaosr_amd._lib import CiaoSRHipError
     from ciaosr_amd.implicit_net import LocalImplicitSRSWINIR
     LocalImplicitSRSWINIR._warned_bf16 = False
+    if precision == 'bf16':         # refused as named; runs (as f16, with one warning) only on the caller's explicit opt-in
+        with pytest.raises(CiaoSRHipError, match='not offered on the SwinIR-CiaoSR head'):
+            model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+        model.test_cfg['allow_f16_substitute'] = True
     with hip_ops.profile(), warnings.catch_warnings(record=True) as caught:
         warnings.simplefilter('always')
         out = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)['output']
     prof = hip_ops.profile.results()
     assert 'swin_window_attention' in prof
-    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_fused_f16', 'f16': 'head_kv_fused_f16', 'f16x3': 'head_kv_fused_f16x3'}[precision] in prof
-    assert 'head_kv_fused_bf16' not in prof
+    assert {'fp32': 'head_kv_fused', 'bf16': 'head_kv_chain_f16', 'f16': 'head_kv_chain_f16', 'f16x3': 'head_kv_fused_f16x3'}[precision] in prof
+    assert not any(k.startswith('head_kv') and k.endswith('_bf16') for k in prof)
     assert (precision == 'bf16') == any('does not meet the 0.01 dB PSNR gate' in str(c.message) for c in caught)
     ref = _t(fx['out'])
     err = (out - ref).abs().max().item()

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 from tools import ref_stubs                                   # noqa: E402
-from ciaosr_amd.init_utils import seeded_init_, synthetic_pair  # noqa: E402
+from ciaosr_amd.init_utils import seeded_init_, synthetic_pair, trained_like_  # noqa: E402
 from ciaosr_amd.coords import make_coord, make_cell           # noqa: E402
 
 OUT = os.path.join(REPO, 'tests', 'golden')
@@ -311,6 +311,50 @@ def gen_e2e(ref):
              gain=np.array(gain), scale=np.array(scale))
 
 
+def stress_input(h, w, scale):
+    """LR input with a DC offset and a step edge (the right half 0.45 darker): what a Winograd tile straddling an edge sees."""
+    lq, gt = synthetic_pair(h, w, scale)
+    lq = (0.35 * lq + 0.5).clamp(0, 1)
+    lq[..., :, w // 2:] = (lq[..., :, w // 2:] - 0.45).clamp(0, 1)
+    return lq
+
+
+STRESS = dict(gain=2.3, head_gain=1.0, sigma=1.0)      # trunk features: std ~10, max ~110, per-channel std 0.1 .. 26 (printed below)
+
+
+def gen_stress(ref):
+    """Condition-stress vectors for the fp32 default route (Winograd F(4x4, 3x3) dense layers, Winograd logit table): RDN-CiaoSR x4 at LR
+    48x48 and 64x64 through the REFERENCE's CiaoSR.forward_test with TRAINED-LIKE trunk statistics (init_utils.trained_like_: log-normal
+    per-output-channel scales, 1 % of the weights x20, bias offsets; trunk gain 2.3 -> feature magnitudes O(10 .. 100)) on an input with a
+    DC offset and a step edge.  Stores the output, the reference-side trunk features (fp32) and the same trunk evaluated in fp64."""
+    mean = (0.4488, 0.4371, 0.4040)
+    for size in (48, 64):
+        q, k, v = mlp_cfg((256,) * 4)
+        gen = dict(type=ref.LocalImplicitSRRDN,
+                   encoder=dict(type='RDN', in_channels=3, out_channels=3, mid_channels=64, num_blocks=16,
+                                upscale_factor=4, num_layers=8, channel_growth=64),
+                   imnet_q=q, imnet_k=k, imnet_v=v, feat_unfold=True, eval_bsize=30000)
+        model = ref.CiaoSR(generator=gen, pixel_loss=dict(type='L1Loss', loss_weight=1.0, reduction='mean'),
+                           rgb_mean=mean, rgb_std=(1., 1., 1.), test_cfg=ref.ConfigDict(scale=4, tile=192, tile_overlap=32)).eval()
+        seeded_init_(model, seed=0, gain=STRESS['gain'], head_gain=STRESS['head_gain'])
+        sha = trained_like_(model, seed=0, sigma=STRESS['sigma'])
+        lq = stress_input(size, size, 4)
+        coord, cell, (ht, wt) = coords_for(size, size, 4)
+        x = lq - torch.tensor(mean).view(1, 3, 1, 1)
+        with torch.no_grad():
+            feat = model.generator.gen_feature(x)[0]
+            res = model(lq=lq, gt=None, test_mode=True, coord=coord, cell=cell)
+            feat64 = model.generator.double().gen_feature(x.double())[0]
+            model.generator.float()
+        out = res['output']
+        cs = feat.std(dim=(0, 2, 3))
+        print(f'  stress_rdn_x4_{size}: feature std {feat.std():.2f} max {feat.abs().max():.1f} per-channel std {cs.min():.2f} .. {cs.max():.2f}; '
+              f'fp32 vs fp64 trunk {(feat.double() - feat64).abs().max():.2e}; out range [{out.min():.3f},{out.max():.3f}] std {out.std():.3f} '
+              f'frac clamped {(out.eq(0) | out.eq(1)).float().mean():.3f}')
+        save(f'stress_rdn_x4_{size}', lq=lq, out=out, feat=feat, feat64=feat64.float(), sha=np.array(sha), weight_seed=np.array(0),
+             gain=np.array(STRESS['gain']), head_gain=np.array(STRESS['head_gain']), sigma=np.array(STRESS['sigma']), scale=np.array(4))
+
+
 def gen_tiling(ref):
     """clip_test index lists + E/W blending: LR 100x132, tile 48, overlap 16, x2, small EDSR."""
     q, k, v = mlp_cfg((64, 64))
@@ -409,7 +453,7 @@ def gen_swinir48(ref):
 
 ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, tiny_act=gen_tiny_head_act, csattn_scales=gen_csattn_scales, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
-           head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir, swinir48=gen_swinir48)
+           head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir, swinir48=gen_swinir48, stress=gen_stress)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
