@@ -312,6 +312,11 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
             t0 = time.perf_counter()
             feat = orc.encoder_features(x, params)
             t_enc = time.perf_counter() - t0
+            if best is not None and t_enc > 2.0 * best[2]:
+                # a thread count at which the trunk alone is over twice as slow is not going to be the faster one: the rest of its sample
+                # (minutes at 256 threads on a 2 x 64-core host: the port's small ops drown in synchronisation) is not run
+                tried[str(n_thr)] = f'not completed: RDN trunk {t_enc:.1f} s against {best[2]:.1f} s at {best[1]} threads'
+                continue
             t0 = time.perf_counter()
             orc.query_rgb(feat, coord, cell, params)                           # one chunk as the reference runs it
             t_chunk = time.perf_counter() - t0
@@ -471,7 +476,9 @@ def main():
                          'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product); f16x3: the fp32-tolerance '
                          'fast mode -- head weights AND activations as half pairs (three MFMAs per product), fp32 trunk and tables')
     ap.add_argument('--tile-batch', type=int, default=0, help='developer: test_cfg.tile_batch (0 = the default: 7 with the fp32 trunk, else 8)')
-    ap.add_argument('--encoder-ahead', action='store_true', help='test_cfg.encoder_ahead: trunk of the next tile batch on a side stream under the heads of the current one (bitwise the same image; per-kernel timings then overlap)')
+    ap.add_argument('--encoder-ahead', action='store_true', help='(default since round 5; kept for old command lines)')
+    ap.add_argument('--no-encoder-ahead', action='store_true', help='test_cfg.encoder_ahead = False: every kernel of the step on ONE stream (the product default runs the trunk '
+                    'of the next tile batch on a side stream under the heads of the current one: bitwise the same image, ~1 %% faster)')
     ap.add_argument('--bf16-single', action='store_true',
                     help='with --precision bf16: weights as ONE bf16 (one MFMA per product; fails the 0.01 dB PSNR gate) instead of the default hi + lo pairs')
     ap.add_argument('--rank0-share', default='1.0',
@@ -534,7 +541,7 @@ def main():
 
     scale = 4
     lr_h, lr_w, n_tiles_img, wl_desc = WORKLOADS[args.workload]
-    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32, **({'tile_batch': args.tile_batch} if args.tile_batch else {}), **({'encoder_ahead': True} if args.encoder_ahead else {})))
+    model = rdn_ciaosr(dict(scale=scale, tile=192, tile_overlap=32, **({'tile_batch': args.tile_batch} if args.tile_batch else {}), ))
     seeded_init_(model, seed=0, gain=1.0)             # default-init scale for timing
     model = model.to(dev)
     lq, _ = synthetic_pair(lr_h, lr_w, scale)         # identical on every rank (CPU-generated)
@@ -617,12 +624,25 @@ def main():
     # warm-up; the last warm-up step is fully profiled (per-kernel HIP events) to find the dominant kernel.  The weights are packed
     # first (Restorer.prepare: once per model, what the first call would do), so that the profiled step lists a steady-state step's
     # kernels and not the 6900 one-time pack_fragments launches of the Winograd weight sets
+    # Per-kernel event timings need the kernels one after the other on one stream: the product default `test_cfg.encoder_ahead` (the next tile
+    # batch's trunk on a side stream under the current batch's heads; bitwise the same image) is switched off for the two profiled passes
+    # -- the fully profiled warm-up step here and the dominant kernel's pass behind the timed region -- and ON (unless --no-encoder-ahead)
+    # for the timed region itself.
+    t_prep = time.perf_counter()
     model.prepare(opt)
+    torch.cuda.synchronize(dev)
+    prepare_s = time.perf_counter() - t_prep
+    ahead = not args.no_encoder_ahead
+    model.test_cfg['encoder_ahead'] = ahead
     for _ in range(max(args.warmup - 1, 0)):
         step()
+    model.test_cfg['encoder_ahead'] = False
     with hip_ops.profile():
         step()
         torch.cuda.synchronize(dev)
+    model.test_cfg['encoder_ahead'] = ahead
+    if args.warmup > 0:
+        step()                                      # the side stream's scratch and events exist before the timed region
     prof_all = hip_ops.profile.results()
     dominant = max(prof_all, key=lambda k: prof_all[k]['total_ms']) if prof_all else None
     step_ms_est = sum(v['total_ms'] for v in prof_all.values()) or 1.0
@@ -631,7 +651,8 @@ def main():
     # the GPU timeline, so it is bracketed live when its launches add < 0.3 % to the step (C3: ~1000 launches of 2.4 ms),
     # otherwise (C2: 128 dense-block launches of ~10 us) its duration is measured in a separate pass right after.
     lib = _lib.load()
-    live = bool(dominant) and prof_all[dominant]['launches'] * 0.004 < 0.003 * step_ms_est
+    two_streams = world == 1 and ahead and n_tiles_img > model.tile_batch(opt)     # the timed region overlaps two streams: no live event timing
+    live = bool(dominant) and prof_all[dominant]['launches'] * 0.004 < 0.003 * step_ms_est and not two_streams
     lib.ciaosr_prof_filter(dominant.encode() if dominant else None)
     lib.ciaosr_prof_reset()
     lib.ciaosr_prof_enable(1 if live else 0)
@@ -652,13 +673,15 @@ def main():
         need_pass = int(flag.item())
     if need_pass:
         live = False
-        prof_steps = min(args.steps, 10)
+        prof_steps = min(args.steps, 3 if two_streams else 10)
+        model.test_cfg['encoder_ahead'] = False
         lib.ciaosr_prof_reset()
         lib.ciaosr_prof_enable(1)
         for _ in range(prof_steps):
             step()
         sync()
         lib.ciaosr_prof_enable(0)
+        model.test_cfg['encoder_ahead'] = ahead
     prof_dom = hip_ops.profile.results()
     lib.ciaosr_prof_filter(None)
 
@@ -688,7 +711,9 @@ def main():
             roof = roofline_object(dominant, step_ms, launches_per_step, Q, HW, n_tiles, args.precision, args.bf16_single)
             if roof:
                 roof.update(kernel=dominant, timing='HIP events on the launch stream inside the timed region' if live else
-                            f'HIP events in a separate pass of {prof_steps} steps (too many short launches per step to bracket live)',
+                            (f'HIP events in a separate pass of {prof_steps} steps with test_cfg.encoder_ahead = False (the timed region overlaps the next '
+                             f'tile batch\'s trunk with the heads on a second stream: events there would time two kernels at once)' if two_streams else
+                             f'HIP events in a separate pass of {prof_steps} steps (too many short launches per step to bracket live)'),
                             avg_launch_ms=round(avg_ms, 5),
                             launches=prof_dom[dominant]['launches'],
                             share_of_step=round(prof_all[dominant]['total_ms'] /
@@ -755,6 +780,8 @@ def main():
                        'lr': [lr_h, lr_w], 'scale': scale, 'tiles': n_tiles_img, 'queries_per_step': out_pixels,
                        'parallelism': (f'query-shard x{world}' if args.workload == 'c2q' else f'tile-shard x{world}')},
             'roofline': roof,
+            'prepare_s': round(prepare_s, 3),        # model.prepare(): one-time weight packing (not in the timed region)
+            'encoder_ahead': bool(two_streams),
             'kernels_ms_per_step': {k: round(v['total_ms'], 4) for k, v in sorted(
                 prof_all.items(), key=lambda kv: -kv[1]['total_ms'])},
         }
@@ -794,9 +821,12 @@ def main():
             # (2) the other precision / the other single-tile config, for the record (not the headline); every 16-bit figure carries
             # the roofline object of ITS dominant kernel (one profiled pass of the same input)
             def mode_roofline(inp, o, precision, n_t):
+                keep = model.test_cfg.get('encoder_ahead', True)
+                model.test_cfg['encoder_ahead'] = False               # one stream: event timings of single kernels
                 with hip_ops.profile():
                     model.restore(inp, options=o)
                     torch.cuda.synchronize(dev)
+                model.test_cfg['encoder_ahead'] = keep
                 pr = hip_ops.profile.results()
                 if not pr:
                     return None
@@ -830,13 +860,14 @@ def main():
                         extras[f'c3_{nm}_mode_roofline'] = mode_roofline(lq, o, prec, n_tiles_img)
                     # opt-in test_cfg.encoder_ahead: the trunk of tile batch k + 1 on a side stream under the heads of batch k (bitwise the
                     # same image).  Not the headline: per-kernel event timings overlap while two streams share the chip.
-                    model.test_cfg['encoder_ahead'] = True
+                    # the one-stream form of the step (test_cfg.encoder_ahead = False), for the record
+                    model.test_cfg['encoder_ahead'] = False
                     for nm, o in (('fp32', hip_ops.DEFAULT_OPTIONS), ('f16', oh)):
                         model.restore(lq, options=o)
                         t_ = time_steps(lambda: model.restore(lq, options=o), 1, dev)
-                        extras[f'c3_{nm}_encoder_ahead_ms'] = round(t_, 1)
-                        extras[f'c3_{nm}_encoder_ahead_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
-                    model.test_cfg['encoder_ahead'] = False
+                        extras[f'c3_{nm}_one_stream_ms'] = round(t_, 1)
+                        extras[f'c3_{nm}_one_stream_mpix_s'] = round(out_pixels / 1e6 / (t_ * 1e-3), 2)
+                    model.test_cfg['encoder_ahead'] = ahead
                 # (3) the other BASELINE configs, every round: C1 (EDSR-CiaoSR x2, LR 48x48 -> 96x96) and C5 (SwinIR-CiaoSR x3.3, LR 48x48 ->
                 # 158x158; its "bf16" = the precision the generator really runs, see `effective_precision`), each with the roofline object of its
                 # dominant known kernel and of the fused head's kv kernel at C = 180

@@ -164,7 +164,7 @@ class CiaoSR(BasicRestorer):
                 hasattr(getattr(self.generator, '_encoder_hip', None), 'forward_hwc_batch')):
             # `test_cfg.tile_batch` (an extension; default 7 or 8, see tile_batch()) consecutive tiles share the encoder's dense-layer launches; every tile
             # is bitwise the one-at-a-time result and the blend order is the reference's
-            if self.test_cfg.get('encoder_ahead', False) and getattr(self.generator, '_head', None) is not None:
+            if self.test_cfg.get('encoder_ahead', True) and len(origins) > n_batch and getattr(self.generator, '_head', None) is not None:
                 return self._clip_test_encoder_ahead(img_lq, tile, origins, n_batch, sf, E, Wt, options)
             for i0 in range(0, len(origins), n_batch):
                 group = origins[i0:i0 + n_batch]
@@ -211,9 +211,10 @@ class CiaoSR(BasicRestorer):
         return torch.stack([hip_ops.tile_finalize(E[bi], Wt[bi]) for bi in range(b)])
 
     def _clip_test_encoder_ahead(self, img_lq, tile, origins, n_batch, sf, E, Wt, options):
-        """`test_cfg.encoder_ahead = True` (an extension, off by default for the same reason as `tile_streams`: per-kernel event
-        timings are meaningless while two streams share the chip): the RDN trunk of tile batch k + 1 runs on a side stream UNDER the
-        heads of batch k (cs_attn + fused head kernels, the caller's stream).  The trunk's 130 strictly dependent launches per batch
+        """`test_cfg.encoder_ahead` (an extension; ON by default since round 5 for images of more than one tile batch -- a product default is
+        not chosen for the profiler's convenience: bench.py times its step with it and takes its per-kernel event timings in a separate
+        pass with `encoder_ahead = False`, where no second stream shares the chip): the RDN trunk of tile batch k + 1 runs on a side stream
+        UNDER the heads of batch k (cs_attn + fused head kernels, the caller's stream).  The trunk's 130 strictly dependent launches per batch
         and the heads' long MFMA kernels fill each other's ramp / drain / memory phases.  Same kernels on the same data in the same
         per-tile order: the image is bitwise the default path's."""
         gen = self.generator
