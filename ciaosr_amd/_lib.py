@@ -117,6 +117,9 @@ SIGNATURES = {
     'ciaosr_pack_fragments_bf16': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_bf16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
     'ciaosr_pack_fragments_f16_lo': (_I, [_P, _I, _I, _I, _P, _P]),
+    'ciaosr_pack_fragments_bf16_pair': (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    'ciaosr_pack_fragments_f16_pair': (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    'ciaosr_pack_conv3x3_f32': (_I, [_P, _S, _S, _S, _S, _I, _I, _P, _P, _P, _P]),
     'ciaosr_head_chain_bytes': (_S, [C.POINTER(HeadWeightsT), _I]),
     'ciaosr_pack_head_chain_bf16': (_I, [C.POINTER(HeadWeightsT), _I, _P, _P]),
     'ciaosr_pack_head_chain_f16': (_I, [C.POINTER(HeadWeightsT), _I, _P, _P]),

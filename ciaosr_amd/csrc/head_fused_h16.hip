@@ -51,8 +51,9 @@ __device__ __forceinline__ void hstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned by
 // ---- fragment packing: W [N][ld] fp32 (K valid columns) -> P[nt][ks][lane][8 bf16]; lane (i = lane&31,
 // g = lane>>5) holds W[32nt + i][16ks + 8g .. 16ks + 8g + 7]; zero padded.
 // residual != 0: the element packed is w - bf16(w) (the low half of the hi + lo pair) instead of w
+// P_lo != null: the residual form goes there as well (one launch packs the hi + lo pair)
 __global__ void pack_fragments_h16_kernel(const float* __restrict__ W, int ld, int N, int K, uint4* __restrict__ P,
-                                           int n_tiles, int nks, int residual) {
+                                           int n_tiles, int nks, int residual, uint4* __restrict__ P_lo = nullptr) {
     const long total = (long)n_tiles * nks * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx & 63);
@@ -66,6 +67,11 @@ __global__ void pack_fragments_h16_kernel(const float* __restrict__ W, int ld, i
             if (residual) v[e] -= h16_lo<kF16>(to_h16<kF16>(v[e]));
         }
         P[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        if (P_lo) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] -= h16_lo<kF16>(to_h16<kF16>(v[e]));
+            P_lo[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+        }
     }
 }
 
@@ -642,13 +648,13 @@ __global__ __launch_bounds__(256, 2) void head_decode_fused_h16_kernel(FusedQP p
 }
 
 // ---- host side ----------------------------------------------------------------------------------
-int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual) {
+int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual, void* P_lo) {
     const int n_tiles = (N + 31) / 32, nks = (K + 15) / 16;
     const long total = (long)n_tiles * nks * 64;
     int grid = (int)((total + 255) / 256);
     ProfScope prof("pack_fragments" CIAOSR_H16_SUFFIX, s);
     hipLaunchKernelGGL(pack_fragments_h16_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, s, W, ld, N, K,
-                       reinterpret_cast<uint4*>(P), n_tiles, nks, residual);
+                       reinterpret_cast<uint4*>(P), n_tiles, nks, residual, reinterpret_cast<uint4*>(P_lo));
     return launch_status("pack_fragments" CIAOSR_H16_SUFFIX);
 }
 
@@ -699,12 +705,17 @@ extern "C" size_t ciaosr_fragment_f16_bytes(int N, int K) { return (size_t)((N +
 
 extern "C" int ciaosr_pack_fragments_f16(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0);
+    return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0, nullptr);
 }
 
 extern "C" int ciaosr_pack_fragments_f16_lo(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 1);
+    return f16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 1, nullptr);
+}
+
+extern "C" int ciaosr_pack_fragments_f16_pair(const float* W, int ld, int N, int K, void* out_hi, void* out_lo, void* stream) {
+    CIAOSR_CHECK_ARG(W && out_hi && out_lo && N > 0 && K > 0 && ld >= K);
+    return f16::pack_fragments_h16(W, ld, N, K, out_hi, (hipStream_t)stream, 0, out_lo);
 }
 #else
 #ifdef CIAOSR_PROBE
@@ -717,11 +728,16 @@ extern "C" size_t ciaosr_fragment_bf16_bytes(int N, int K) { return (size_t)((N 
 
 extern "C" int ciaosr_pack_fragments_bf16(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return b16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0);
+    return b16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 0, nullptr);
 }
 
 extern "C" int ciaosr_pack_fragments_bf16_lo(const float* W, int ld, int N, int K, void* out, void* stream) {
     CIAOSR_CHECK_ARG(W && out && N > 0 && K > 0 && ld >= K);
-    return b16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 1);
+    return b16::pack_fragments_h16(W, ld, N, K, out, (hipStream_t)stream, 1, nullptr);
+}
+
+extern "C" int ciaosr_pack_fragments_bf16_pair(const float* W, int ld, int N, int K, void* out_hi, void* out_lo, void* stream) {
+    CIAOSR_CHECK_ARG(W && out_hi && out_lo && N > 0 && K > 0 && ld >= K);
+    return b16::pack_fragments_h16(W, ld, N, K, out_hi, (hipStream_t)stream, 0, out_lo);
 }
 #endif

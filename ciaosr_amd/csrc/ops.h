@@ -184,7 +184,7 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
     int pack_head_chain(const ciaosr_head_weights_t* w, int pairs, void* out, hipStream_t s);                                         \
     int head_kv_chain_h16(const FusedKVP& kp, const ciaosr_head_weights_t* w, const void* blob, int pairs, int grid_w, int* flag,     \
                           hipStream_t s);                                                                                             \
-    int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual);                               \
+    int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual, void* P_lo);                   \
     int dense_h16_tiles(int H, int W);                                                                                                \
     int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);                       \
     int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,                     \

@@ -48,49 +48,30 @@ def _pack_conv(conv, keep, pad_cin_to=None, frag16=False, frag=False, widen=None
     st.frag = None
     st.frag_wino = None
     st.frag_wino4 = None
-    if frag16 and kh == 3 and co == 64 and ci % 64 == 0:
-        # Winograd F(4x4, 3x3) form (dense_wino4_f32.hip): U = G g G^T with the 6x3 G of F(4, 3), in fp64, rounded once; position
-        # p = 6 i + j as its own [co][ci] matrix in MFMA fragment order, the 36 arrays back to back
-        G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                           [0, 0, 1]], dtype=torch.float64, device=w.device)
-        g4 = w.view(co, 3, 3, ci).double()
-        U4 = torch.einsum('ia,oabc,jb->ijoc', G4, g4, G4).float().contiguous()           # [6][6][co][ci]
-        nfl4 = _lib.load().ciaosr_fragment_floats(co, ci)
-        fw4 = torch.empty(36 * nfl4, dtype=torch.float32, device=w.device)
-        for pos in range(36):
-            up = U4[pos // 6, pos % 6]
-            _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(up), ci, co, ci, C.c_void_p(fw4.data_ptr() + 4 * pos * nfl4), hip_ops.stream_ptr())
-        keep += [fw4]
-        st.frag_wino4 = fw4.data_ptr()
-    if frag16 and kh == 3 and co == 64 and ci % 64 == 0:
-        # Winograd F(2x2, 3x3) form of the weights for the fp32 big-map kernel (dense_wino_f32.hip): U = G g G^T per (co, ci), in
-        # fp64, rounded once; position p = 4 i + j as its own [co][ci] matrix in MFMA fragment order, the 16 arrays back to back
-        Gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
-        g = w.view(co, 3, 3, ci).double()                                   # [co][a][b][ci]
-        U = torch.einsum('ia,oabc,jb->ijoc', Gm, g, Gm).float().contiguous()     # [4][4][co][ci]
-        nfl = _lib.load().ciaosr_fragment_floats(co, ci)
-        fw = torch.empty(16 * nfl, dtype=torch.float32, device=w.device)
-        for pos in range(16):
-            up = U[pos // 4, pos % 4]
-            _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(up), ci, co, ci, C.c_void_p(fw.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
-        keep += [fw]                    # (U is read by the pack launches on this stream: stream-ordered reuse makes dropping it safe)
-        st.frag_wino = fw.data_ptr()
     if frag16:
-        # bf16 MFMA fragments of the [cout][k*k*cin] matrix for the bf16 trunk mode (dense_h16.hip)
+        # every fp32 fragment form of the dense layer in ONE launch (csrc/pack_ops.hip): the direct [cout][9 cin] matrix for the halo-resident
+        # kernel of big maps (dense_f32.hip) and, for the 64 -> 64-per-group layers, the Winograd F(2x2, 3x3) / F(4x4, 3x3) forms
+        # U = G g G^T (dense_wino_f32.hip / dense_wino4_f32.hip; transform in fp64 on the device, rounded once).  The 16-bit fragments of
+        # the bf16 / f16 trunk modes are packed when such a mode is first used (PackedEncoder.struct).
+        lib = _lib.load()
         n_, k_ = w.shape
-        f16 = torch.empty(_lib.load().ciaosr_fragment_bf16_bytes(n_, k_), dtype=torch.uint8, device=w.device)
-        _lib.call('ciaosr_pack_fragments_bf16', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f16), hip_ops.stream_ptr())
-        keep.append(f16)
-        st.frag16 = f16.data_ptr()
-        lo16 = torch.empty_like(f16)                # low half of the hi + lo weight pair
-        _lib.call('ciaosr_pack_fragments_bf16_lo', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(lo16), hip_ops.stream_ptr())
-        keep.append(lo16)
-        st.frag16_lo = lo16.data_ptr()
-        # exact-fp32 MFMA fragments for the halo-resident fp32 kernel of big maps (dense_f32.hip)
-        f32 = torch.empty(_lib.load().ciaosr_fragment_floats(n_, k_), dtype=torch.float32, device=w.device)
-        _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f32), hip_ops.stream_ptr())
+        f32 = torch.empty(lib.ciaosr_fragment_floats(n_, k_), dtype=torch.float32, device=w.device)
+        wino = kh == 3 and co == 64 and ci % 64 == 0
+        fw = fw4 = None
+        if wino:
+            nfl = lib.ciaosr_fragment_floats(co, ci)
+            fw = torch.empty(16 * nfl, dtype=torch.float32, device=w.device)
+            fw4 = torch.empty(36 * nfl, dtype=torch.float32, device=w.device)
+        if kh == 3:
+            _lib.call('ciaosr_pack_conv3x3_f32', hip_ops.ptr(w), 9 * ci, 3 * ci, ci, 1, co, ci, hip_ops.ptr(f32), hip_ops.ptr(fw), hip_ops.ptr(fw4),
+                      hip_ops.stream_ptr())
+        else:
+            _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(w), w.stride(0), n_, k_, hip_ops.ptr(f32), hip_ops.stream_ptr())
         keep.append(f32)
         st.frag = f32.data_ptr()
+        if wino:
+            keep += [fw, fw4]
+            st.frag_wino, st.frag_wino4 = fw.data_ptr(), fw4.data_ptr()
     elif frag:
         # exact-fp32 MFMA fragments only: the one-launch small-map 3x3 kernel (conv_small_f32.hip)
         n_, k_ = w.shape
@@ -109,8 +90,7 @@ class PackedEncoder:
         self._key = None
         self._st = None
         self._keep = None
-        self._st_f16 = None       # RDN: copy of the struct whose dense-layer frag16 are IEEE half (packed on first use)
-        self._keep_f16 = None
+        self._st_half = {}        # RDN: per 16-bit element type, the copy of the struct whose dense layers carry its fragment pairs
 
     def _params(self):
         n = self.net
@@ -118,35 +98,35 @@ class PackedEncoder:
         return [p for m in mods for p in m.parameters()]
 
     def struct(self, half=None):
-        """The trunk's weight struct.  half='f16' (RDN): the copy whose dense layers carry IEEE-half fragments (the _f16 entry)."""
+        """The trunk's weight struct.  half='bf16' | 'f16' (RDN): the copy whose dense layers carry the 16-bit hi + lo fragment pairs of that
+        element type, packed when the mode is first used (one launch pair per layer); None: the fp32 forms only."""
         key = tuple((p.data_ptr(), p._version) for p in self._params())
         if self._st is None or key != self._key:
             self._build(key)
-            self._st_f16 = None
-        if half != 'f16' or self.kind != 'rdn':
+            self._st_half = {}
+        if half not in ('bf16', 'f16') or self.kind != 'rdn':
             return self._st
-        if self._st_f16 is None:
+        if half not in self._st_half:
             base = self._st
             st = _lib.RdnWeightsT()
             C.memmove(C.byref(st), C.byref(base), C.sizeof(st))
             nd = base.num_blocks * base.num_layers
             dense = (_lib.ConvT * nd)()
             keep = [dense]
+            lib = _lib.load()
             for i in range(nd):
                 C.memmove(C.byref(dense[i]), C.byref(base.dense[i]), C.sizeof(_lib.ConvT))
                 c = dense[i]
                 n_, k_ = c.cout, c.ksize * c.ksize * c.cin
-                f = torch.empty(_lib.load().ciaosr_fragment_f16_bytes(n_, k_), dtype=torch.uint8, device=self._keep[0].device)
-                _lib.call('ciaosr_pack_fragments_f16', c.weight, k_, n_, k_, hip_ops.ptr(f), hip_ops.stream_ptr())
-                keep.append(f)
+                f = torch.empty(getattr(lib, f'ciaosr_fragment_{half}_bytes')(n_, k_), dtype=torch.uint8, device=self._keep[0].device)
+                lo = torch.empty_like(f)                     # h16(w - h16(w)): the lo half of the weight pair (bf16 default, Options(f16_pairs=1))
+                _lib.call(f'ciaosr_pack_fragments_{half}_pair', c.weight, k_, n_, k_, hip_ops.ptr(f), hip_ops.ptr(lo), hip_ops.stream_ptr())
+                keep += [f, lo]
                 c.frag16 = f.data_ptr()
-                lo = torch.empty_like(f)                     # half(w - half(w)): read only with Options(f16_pairs=1)
-                _lib.call('ciaosr_pack_fragments_f16_lo', c.weight, k_, n_, k_, hip_ops.ptr(lo), hip_ops.stream_ptr())
-                keep.append(lo)
                 c.frag16_lo = lo.data_ptr()
             st.dense = dense
-            self._st_f16, self._keep_f16 = st, keep
-        return self._st_f16
+            self._st_half[half] = (st, keep)
+        return self._st_half[half][0]
 
     def width(self):
         """(c, c'): the trunk's channel width and the width the kernels run it at (next multiple of 32, zero-padded weights)."""
@@ -182,20 +162,22 @@ class PackedEncoder:
                 # slices of every later layer -> one N = 64*(nl-s), K = 576 convolution per group
                 ptrs = (C.c_void_p * (nb * nl))()
                 fptrs = (C.c_void_p * (nb * nl))()
+                lib = _lib.load()
                 for b in range(nb):
                     convs = [_widen(n.rdbs[b].layers[l].conv.weight.detach().float(), n.rdbs[b].layers[l].conv.bias.detach().float(), wd)[0]
                              for l in range(nl)]                                                 # [64][64(l+1)][3][3]
+                    # the nl stacked matrices of the block, row-stacked into one [64 (nl + ... + 1)][576] matrix: ONE fragment-pack launch per
+                    # block (fragments are per 32-row tile, every group's row count is a multiple of 64: group s's fragments are a slice)
+                    sl = [convs[l][:, 64 * s_:64 * s_ + 64].permute(0, 2, 3, 1).reshape(64, 576) for s_ in range(nl) for l in range(s_, nl)]
+                    wblk = torch.cat(sl, 0).contiguous()
+                    fblk = torch.empty(lib.ciaosr_fragment_floats(wblk.shape[0], 576), dtype=torch.float32, device=wblk.device)
+                    _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(wblk), 576, wblk.shape[0], 576, hip_ops.ptr(fblk), hip_ops.stream_ptr())
+                    keep += [wblk, fblk]
+                    row = 0
                     for s_ in range(nl):
-                        sl = [convs[l][:, 64 * s_:64 * s_ + 64].permute(0, 2, 3, 1).reshape(64, 576) for l in range(s_, nl)]
-                        wst = torch.cat(sl, 0).contiguous()
-                        keep.append(wst)
-                        ptrs[b * nl + s_] = wst.data_ptr()
-                        # MFMA fragment order for the small-map scatter kernel (dense_scatter_f32.hip)
-                        fr = torch.empty(_lib.load().ciaosr_fragment_floats(wst.shape[0], 576), dtype=torch.float32, device=wst.device)
-                        _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(wst), 576, wst.shape[0], 576, hip_ops.ptr(fr),
-                                  hip_ops.stream_ptr())
-                        keep.append(fr)
-                        fptrs[b * nl + s_] = fr.data_ptr()
+                        ptrs[b * nl + s_] = wblk.data_ptr() + 4 * row * 576
+                        fptrs[b * nl + s_] = fblk.data_ptr() + 4 * lib.ciaosr_fragment_floats(row, 576) if row else fblk.data_ptr()
+                        row += 64 * (nl - s_)
                 bias = torch.stack([torch.stack([_widen(n.rdbs[b].layers[l].conv.weight.detach().float(),
                                                         n.rdbs[b].layers[l].conv.bias.detach().float(), wd)[1] for l in range(nl)])
                                     for b in range(nb)]).contiguous()

@@ -28,8 +28,7 @@ class PackedHead:
         self._key = None
         self._st = None
         self._keep = None
-        self._st_f16 = None       # copy of the struct whose frag16 hold IEEE-half fragments (packed on first use)
-        self._keep_f16 = None
+        self._st_half = {}        # per 16-bit element type: (copy of the struct with that type's fragment pairs + chain stream, kept tensors)
         self._grid_opts = {}      # (Options, grid width) -> Options carrying the traversal hint
 
     def _version_key(self):
@@ -74,49 +73,37 @@ class PackedHead:
                           hip_ops.stream_ptr())
                 keep.append(frag)
                 st.frag[i] = frag.data_ptr()
-                f16 = torch.empty(_lib.load().ciaosr_fragment_bf16_bytes(n, k), dtype=torch.uint8, device=w.device)
-                _lib.call('ciaosr_pack_fragments_bf16', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(f16),
-                          hip_ops.stream_ptr())
-                keep.append(f16)
-                st.frag16[i] = f16.data_ptr()
-                lo16 = torch.empty_like(f16)            # bf16(w - bf16(w)): low half of the hi + lo weight pair
-                _lib.call('ciaosr_pack_fragments_bf16_lo', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(lo16),
-                          hip_ops.stream_ptr())
-                keep.append(lo16)
-                st.frag16_lo[i] = lo16.data_ptr()
         st.in_dim = lin[0].weight.shape[1]
         return st, keep, srcs
 
     def struct(self, half=None):
-        """The ciaosr_head_weights_t of the net.  half='f16': the copy whose 16-bit fragments are IEEE half (the _f16
-        entry); else the struct with bf16 hi + lo fragments (the _f32 / _bf16 entries)."""
+        """The ciaosr_head_weights_t of the net.  half=None: fp32 fragments only (the _f32 entry).  half='bf16' | 'f16': the copy that also
+        carries the 16-bit hi + lo fragment pairs of that element type and the weight stream of the chained kv kernel -- packed when the
+        mode is first used."""
         key = self._version_key()
         if self._st is None or self._key != key:
             self._build()
-            self._st_f16 = None
-        if half != 'f16':
-            if half == 'bf16' and not self._st.chain16_pairs:
-                self._keep += self._pack_chain(self._st, 'bf16')
+            self._st_half = {}
+        if half not in ('bf16', 'f16'):
             return self._st
-        if self._st_f16 is None:
+        if half not in self._st_half:
             st = _lib.HeadWeightsT()
             C.memmove(C.byref(st), C.byref(self._st), C.sizeof(st))
             keep = []
+            lib = _lib.load()
             for name in ('k', 'v', 'q'):
                 m = getattr(st, name)
                 for i, w in self._srcs[name]:
                     n, k = w.shape
-                    f = torch.empty(_lib.load().ciaosr_fragment_f16_bytes(n, k), dtype=torch.uint8, device=w.device)
-                    _lib.call('ciaosr_pack_fragments_f16', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(f), hip_ops.stream_ptr())
-                    keep.append(f)
+                    f = torch.empty(getattr(lib, f'ciaosr_fragment_{half}_bytes')(n, k), dtype=torch.uint8, device=w.device)
+                    lo = torch.empty_like(f)                 # h16(w - h16(w)): the lo half of the weight pair
+                    _lib.call(f'ciaosr_pack_fragments_{half}_pair', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(f), hip_ops.ptr(lo), hip_ops.stream_ptr())
+                    keep += [f, lo]
                     m.frag16[i] = f.data_ptr()
-                    lo = torch.empty_like(f)                 # half(w - half(w)): read only with Options(f16_pairs=1)
-                    _lib.call('ciaosr_pack_fragments_f16_lo', hip_ops.ptr(w), w.stride(0), n, k, hip_ops.ptr(lo), hip_ops.stream_ptr())
-                    keep.append(lo)
                     m.frag16_lo[i] = lo.data_ptr()
-            keep += self._pack_chain(st, 'f16')
-            self._st_f16, self._keep_f16 = st, keep
-        return self._st_f16
+            keep += self._pack_chain(st, half)
+            self._st_half[half] = (st, keep)
+        return self._st_half[half][0]
 
     @staticmethod
     def _pack_chain(st, half):
@@ -167,24 +154,16 @@ class PackedHead:
         if unfold and Cc == 64 and tuple(w5.shape) == (576, 256):
             # the logit table as nine 3x3 convolutions (head.hip): g[n][c][a][b] = W5[(3a+b) C + c][n] in Winograd F(2x2, 3x3) form,
             # U = G g G^T in fp64, rounded once; position p = 4 i + j as its own [256][64] matrix in MFMA fragment order
-            Gm = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=dev)
-            Uw = torch.einsum('ia,abcn,jb->ijnc', Gm, w5.view(3, 3, 64, 256).double(), Gm).float().contiguous()   # [4][4][256][64]
+            # (both forms in one launch, transform in fp64 on the device: csrc/pack_ops.hip; element (n, a, b, c) of the convolution weight is
+            # w5[(3 a + b) 64 + c][n])
             nfl = _lib.load().ciaosr_fragment_floats(256, 64)
             fw = torch.empty(16 * nfl, dtype=torch.float32, device=dev)
-            for pos in range(16):
-                _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(Uw[pos // 4, pos % 4]), 64, 256, 64,
-                          C.c_void_p(fw.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
-            kk = kk + [fw]
-            st.k_out_wino = fw.data_ptr()
-            # ... and in F(4x4, 3x3) form (dense_wino4_f32.hip's table kernel): 36 positions
-            G4 = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
-                               [0, 0, 1]], dtype=torch.float64, device=dev)
-            Uw4 = torch.einsum('ia,abcn,jb->ijnc', G4, w5.view(3, 3, 64, 256).double(), G4).float().contiguous()   # [6][6][256][64]
             fw4 = torch.empty(36 * nfl, dtype=torch.float32, device=dev)
-            for pos in range(36):
-                _lib.call('ciaosr_pack_fragments_f32', hip_ops.ptr(Uw4[pos // 6, pos % 6]), 64, 256, 64,
-                          C.c_void_p(fw4.data_ptr() + 4 * pos * nfl), hip_ops.stream_ptr())
-            kk = kk + [fw4]
+            ld5 = w5.stride(0)
+            _lib.call('ciaosr_pack_conv3x3_f32', hip_ops.ptr(w5), 1, 3 * 64 * ld5, 64 * ld5, ld5, 256, 64, None, hip_ops.ptr(fw), hip_ops.ptr(fw4),
+                      hip_ops.stream_ptr())
+            kk = kk + [fw, fw4]
+            st.k_out_wino = fw.data_ptr()
             st.k_out_wino4 = fw4.data_ptr()
         st.v, kv, sv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
         st.q, kq, sq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))

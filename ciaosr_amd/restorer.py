@@ -366,7 +366,7 @@ class CiaoSR(BasicRestorer):
         keep = (scratch, dict(hip_ops._coord_cache),
                 [getattr(m, '_packed', None) for m in self.modules()],
                 [(getattr(o, '_st', None), getattr(o, '_keep', None), getattr(o, '_mask_keep', None),
-                  getattr(o, '_st_f16', None), getattr(o, '_keep_f16', None))
+                  dict(getattr(o, '_st_half', None) or {}))
                  for m in self.modules() for o in (getattr(m, '_head', None), getattr(m, '_encoder_hip', None)) if o is not None])
 
         def run(new_lq=None):

@@ -223,6 +223,18 @@ size_t ciaosr_fragment_f16_bytes(int N, int K);
 int ciaosr_pack_fragments_f16(const float* W, int ld, int N, int K, void* out, void* stream);
 /* Rounding residual w - half(w) of the same matrix in the same fragment order: the lo half of the pair of opt->f16_pairs. */
 int ciaosr_pack_fragments_f16_lo(const float* W, int ld, int N, int K, void* out, void* stream);
+/* hi and lo of a matrix in ONE launch (model-load path): out_hi = ciaosr_pack_fragments_{bf16,f16}, out_lo = ..._lo */
+int ciaosr_pack_fragments_bf16_pair(const float* W, int ld, int N, int K, void* out_hi, void* out_lo, void* stream);
+int ciaosr_pack_fragments_f16_pair(const float* W, int ld, int N, int K, void* out_hi, void* out_lo, void* stream);
+
+/* Every fp32 fragment form of ONE 3x3 convolution weight in one launch (model-load path).  Element (o, a, b, c) -- output channel, kernel
+ * row, kernel column, input channel -- is read at w[o * stride_o + a * stride_a + b * stride_b + c * stride_c]; N output, K input channels
+ * (K a multiple of 4).  Outputs (each optional, NULL = skip): frag_direct = ciaosr_pack_fragments_f32 of the [N][(3 a + b) K + c]
+ * matrix; frag_wino2 = the 16 matrices U[p] = (G g G^T)[p], p = 4 i + j, of Winograd F(2x2, 3x3), each [N][K] in
+ * ciaosr_pack_fragments_f32 order, back to back (ciaosr_conv_t.frag_wino, ciaosr_head_weights_t.k_out_wino); frag_wino4 = the 36
+ * matrices of F(4x4, 3x3), p = 6 i + j (frag_wino4 / k_out_wino4).  The transform is evaluated in fp64 and rounded once. */
+int ciaosr_pack_conv3x3_f32(const float* w, size_t stride_o, size_t stride_a, size_t stride_b, size_t stride_c, int N, int K,
+                            float* frag_direct, float* frag_wino2, float* frag_wino4, void* stream);
 
 typedef struct ciaosr_head_weights {
     int channels;         /* C  (encoder width)                                   net:57-60 */
