@@ -53,7 +53,8 @@ __device__ unsigned long long g_cprobe[256 * 16];
 #endif
 
 #ifndef CIAOSR_CHAIN_ABL      // developer ablations (timing only; results are wrong): 1 no value-row loads, 2 no Z stores, 4 no v-out epilogue
-#define CIAOSR_CHAIN_ABL 0    // arithmetic, 8 no DMA pieces in v-out, 16 no prefetch touches, 32 no table / logit-table loads
+#define CIAOSR_CHAIN_ABL 0    // arithmetic, 8 no DMA pieces in v-out, 32 no table / logit-table loads, 64 no hidden-layer epilogues, 128 no
+                              // barriers, 256 no DMA pieces in the hidden layers, 512 constant biases
 #endif
 constexpr int kAbl = CIAOSR_CHAIN_ABL;
 #ifndef CIAOSR_CHAIN_WAVES
@@ -61,11 +62,12 @@ constexpr int kAbl = CIAOSR_CHAIN_ABL;
 #endif
 constexpr int CNW = CIAOSR_CHAIN_WAVES;   // waves per workgroup: 4 (one per SIMD, two row tiles each) or 8 (two per SIMD, one row tile each)
 constexpr int CM = 8 / CNW;               // row tiles per wave
-constexpr int CPW = 32 / CNW;             // 1-KB DMA pieces of a slot a wave issues
+constexpr int CPW = 16 / CNW;             // 1-KB DMA pieces of a slot a wave issues
 constexpr int CROWS = 32 * CM * CNW;      // rows per workgroup pass (256)
 constexpr int CQ = CROWS / 4;             // queries per pass (64)
-constexpr int CSLOT = 32 * 1024;          // ring slot
-constexpr int CRING = 3;                  // slots of the weight ring: one being read, two in flight
+constexpr int CSLOT = 16 * 1024;          // ring slot = 16 fragments: one tile, or the hi / the lo half of a pair tile
+constexpr int CRING = 4;                  // slots of the weight ring: one being read, two in flight, one being requested
+constexpr int CNSTAGE = 4;                // gather stages per row tile
 constexpr int CWIN = 16;                  // key pixels of a row tile's gather window (4 x 4 LR pixels)
 constexpr int CSTAGE = CWIN * 128;        // one staged line set: a 128-B line of each window pixel's row (2 KB)
 constexpr int CTILE = 16 * 1024;          // one 32-column tile of a 256-deep layer: 16 fragments of 1 KB
@@ -125,7 +127,7 @@ __global__ void pack_tail_kernel(const float* __restrict__ W1, int ld, int fan, 
 
 struct ChainP {
     FusedKVP kv;                    // coord, cell, q0, nq, chunk, H, W, U, ldu, u_bytes, k.table, v.table, bias_*, softmax_scale, Z, ldz, G
-    const unsigned char* blob;      // [tail_k 8 KB][tail_v 8 KB][stream: n_slots x 32 KB]
+    const unsigned char* blob;      // [tail_k 8 KB][tail_v 8 KB][stream: n_slots x 16 KB]
     unsigned blob_bytes;
     int n_slots;                    // slots of one pass
     int n_vout;                     // 32-column tiles of imnet_v's output layer
@@ -139,6 +141,7 @@ struct RowState {
     unsigned koff;                  // byte offset of the key pixel's row in the layer-0 tables (kpix * 1024)
     unsigned uoff;                  // byte offset of its U row
     unsigned goff;                  // byte offset of the logit-table row, kOobC = none
+    int grow;                       // its row index, 0x7FFFFFFF = none
     unsigned zoff;                  // byte offset of the query's Z row, kOobC = query out of range
     u32x4 q4;                       // B operand of the tail MFMA: (rel_y, rel_x, scale_y, scale_x) as hi (elements 0-3) + lo (4-7)
     float attn;
@@ -146,58 +149,58 @@ struct RowState {
 
 template <bool PAIRS>
 struct Geo {
-    static constexpr int TILE_BYTES = CTILE * (PAIRS ? 2 : 1);
-    static constexpr int TILES_PER_SLOT = CSLOT / TILE_BYTES;       // 2 / 1
-    static constexpr int PIECES_PER_TILE = CPW / TILES_PER_SLOT;    // DMA pieces a wave issues per tile
-    static constexpr int STEPS = PAIRS ? 32 : 16;                   // k-steps (fragments) per tile
+    static constexpr int SLOTS_PER_TILE = PAIRS ? 2 : 1;
+    static constexpr int PIECES_PER_TILE = CPW * SLOTS_PER_TILE;    // DMA pieces a wave issues per tile
+    static constexpr int STEPS = 16 * SLOTS_PER_TILE;               // k-steps (fragments) per tile
 };
 
-// ---- the stream: ring of three 32-KB slots, DMA two slots ahead -----------------------------------------------------------------------
+// ---- the stream: ring of four 16-KB slots, DMA three slots ahead ----------------------------------------------------------------------
 struct Stream {
     i32x4 desc;
     unsigned lds0;                  // LDS byte address of the ring
-    unsigned voff;                  // this lane's offset inside a slot: (8 w) KB + lane * 16
+    unsigned voff;                  // this lane's offset inside a slot: (CPW w) KB + lane * 16
     unsigned src0;                  // byte offset of the stream inside the blob
     int n_slots;                    // per pass
     int total;                      // slots this workgroup consumes in the launch
     int cur;                        // next slot to consume
-    int ridx;                       // its ring buffer (cur % 3)
+    int ridx;                       // its ring buffer (cur % 4)
     // prefetch target of the slot being consumed; pf_voff = voff, or an out-of-range offset past the launch's last slot (the DMA then
-    // writes zeros into a buffer nobody reads again: every slot issues its 8 pieces, the wait counts below never change)
+    // writes zeros into a buffer nobody reads again: every slot issues its pieces, the wait counts below never change)
     unsigned pf_dst, pf_src, pf_voff;
 
     __device__ __forceinline__ void dma(unsigned lds_dst, unsigned soff, unsigned vo) const {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" :: "v"(vo), "s"(lds_dst), "s"(desc), "s"(soff) : "memory");
     }
-    __device__ __forceinline__ void issue_whole(int slot) const {       // prologue (slot < CRING): all of this wave's pieces of a slot at once
+    __device__ __forceinline__ void issue_whole(int slot) const {       // prologue (slot < CRING - 1): all of this wave's pieces of a slot at once
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * CSLOT + (voff & ~1023u));
         const unsigned src = __builtin_amdgcn_readfirstlane(src0 + (unsigned)(slot % n_slots) * CSLOT);
 #pragma unroll
         for (int i = 0; i < CPW; ++i) dma(dst + i * 1024u, src + i * 1024u, voff);
     }
-    // in front of slot `cur`: its pieces have landed -- counted wait: this wave issued the CPW pieces of slot cur + 1 behind them, so
-    // "at most CPW vector-memory operations outstanding" covers them whatever else (gather DMAs, stores) is younger still; every wave is
-    // past slot cur - 1 (barrier), whose buffer then receives slot cur + 2 piece by piece
+    // in front of slot `cur`: its pieces have landed -- counted wait: this wave issued the pieces of slots cur + 1 and cur + 2 behind them,
+    // so "at most 2 CPW vector-memory operations outstanding" covers them whatever else (gather DMAs, stores) is younger still; every wave
+    // is past slot cur - 1 (barrier), whose buffer then receives slot cur + 3 piece by piece
     // EXTRA: further vector-memory operations this wave is KNOWN to have issued behind slot cur's pieces (the v-out units' value-row
     // fetches and Z stores): they may stay in flight too
     template <int EXTRA = 0>
     __device__ __forceinline__ lds_cptr begin_slot(lds_cptr ring) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(CPW + EXTRA) : "memory");
-        __builtin_amdgcn_s_barrier();
-        const int nxt = cur + 2;
-        const int nidx = ridx == 0 ? 2 : ridx - 1;                    // (cur + 2) % 3 = the buffer slot cur - 1 used
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"((CRING - 2) * CPW + EXTRA) : "memory");
+        if (!(kAbl & 128)) __builtin_amdgcn_s_barrier();
+        const int nxt = cur + CRING - 1;
+        const int nidx = (ridx + CRING - 1) & (CRING - 1);            // the buffer slot cur - 1 used
         pf_voff = nxt < total ? voff : kOobC;
         pf_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)nidx * CSLOT + (voff & ~1023u));
         pf_src = __builtin_amdgcn_readfirstlane(src0 + (unsigned)(nxt % n_slots) * CSLOT);
         lds_cptr s = ring + ridx * CSLOT;
         ++cur;
-        ridx = ridx == 2 ? 0 : ridx + 1;
+        ridx = (ridx + 1) & (CRING - 1);
         return s;
     }
     __device__ __forceinline__ void piece(int i) const {
         dma(pf_dst + (unsigned)i * 1024u, pf_src + (unsigned)i * 1024u, pf_voff);
     }
 };
+static_assert(CRING == 4, "ring index arithmetic");
 
 // ---- epilogue pieces ----------------------------------------------------------------------------------------------------------------
 // relu + convert accumulator registers 4 qd .. 4 qd + 3 of tile T of row tile mi into their two packed registers of `out`
@@ -216,6 +219,7 @@ __device__ __forceinline__ void finish_tile(int T, const f32x16 (&c)[CM], u32x4 
 
 __device__ __forceinline__ f32x16 bias_frag(const LDS3 float* bias, int T, int lh) {
     f32x16 b;
+    if (kAbl & 512) { for (int i = 0; i < 16; ++i) b[i] = 0.25f; return b; }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 v = *(const LDS3 f32x4*)(bias + 32 * T + 8 * g + 4 * lh);
@@ -240,6 +244,17 @@ struct LogitAcc {
     float sum[CM];
     int lh;
     bool on;                        // false: the functions below are no-ops (v chain)
+    // the staged logit-table window (kernel body): instruction i of its eight
+    i32x4 g_desc;
+    unsigned g_vo;                  // byte offset of the window's row 0, kOobC = no window (the instructions still issue, out of range)
+    unsigned g_row_bytes, g_lds, g_lane;
+    __device__ __forceinline__ void window_dma(int i) const {
+        // row g_row0 + i whole (64 lanes x 16 B), lane position l receiving source chunk l ^ 2 i; the row offset sits in the range-checked
+        // VGPR offset: rows past the table's end read zeros
+        const unsigned vo = g_vo == kOobC ? kOobC : g_vo + (unsigned)i * g_row_bytes + ((g_lane ^ (unsigned)(2 * i)) << 4);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(g_lds + (unsigned)i * 1024u);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(vo), "s"(dst), "s"(g_desc) : "memory");
+    }
     __device__ __forceinline__ void request(int T) {
         if (!on) return;
 #pragma unroll
@@ -268,27 +283,38 @@ struct LogitAcc {
 // tb: LDS address of the tile's fragments (+ lane * 16).  PT >= 0: `prev` is the accumulator of tile PT of the layer whose outputs go
 // to `pout` (finished here, behind k-steps 2 ..).  Returns this tile's accumulators.
 // LT >= 0: this is tile LT of the k chain's third hidden layer (see LogitAcc): request its G columns, multiply in tile LT - 1's.
-template <bool PAIRS, int PT, int P0, int LT = -1>
-__device__ __forceinline__ void tile_mma(lds_cptr tb, const u32x4 (&in)[CM][16], const f32x16& c0, f32x16 (&acc)[CM], const f32x16 (&prev)[CM],
-                                         u32x4 (&pout)[CM][16], const Stream& st, LogitAcc* lg = nullptr) {
+// GI: the first tile of the k chain issues its weight pieces early (k-steps 1 ..) and the eight logit-table window DMAs behind them (k-steps
+// 3 .. 10): younger than the pieces of the three slots that follow (their waits carry XS = 8), a good four tiles old when the slot
+// after those wants them landed
+template <bool PAIRS, int PT, int LT = -1, int XS0 = 0, int XS1 = 0, bool GI = false>
+__device__ __forceinline__ void tile_mma(lds_cptr ring, int lane, const u32x4 (&in)[CM][16], const f32x16& c0, f32x16 (&acc)[CM], const f32x16 (&prev)[CM],
+                                         u32x4 (&pout)[CM][16], Stream& st, LogitAcc* lg = nullptr) {
     constexpr int STEPS = Geo<PAIRS>::STEPS;
     u32x4 a[3];
-    a[0] = *(const LDS3 u32x4*)(tb);
-    a[1] = *(const LDS3 u32x4*)(tb + 1024);
+    lds_cptr tb = ring;
 #pragma unroll
     for (int f = 0; f < STEPS; ++f) {
         const int ks = f & 15;
-        if (f + 2 < STEPS) a[(f + 2) % 3] = *(const LDS3 u32x4*)(tb + (f + 2) * 1024);
+        if (ks == 0) {                                  // a slot = 16 fragments
+            tb = (f == 0 ? st.template begin_slot<XS0>(ring) : st.template begin_slot<XS1>(ring)) + lane * 16;      // XS: see Layers::tile
+            asm volatile("" : "+v"(tb));
+            a[f % 3] = *(const LDS3 u32x4*)(tb);
+            a[(f + 1) % 3] = *(const LDS3 u32x4*)(tb + 1024);
+        }
+        if (ks + 2 < 16) a[(f + 2) % 3] = *(const LDS3 u32x4*)(tb + (ks + 2) * 1024);
 #pragma unroll
         for (int mi = 0; mi < CM; ++mi) acc[mi] = mfma(a[f % 3], in[mi][ks], f == 0 ? c0 : acc[mi]);
-        if (PT >= 0 && f >= 2 && f < 2 + 4 * CM) {
+        if (!(kAbl & 64) && PT >= 0 && f >= 2 && f < 2 + 4 * CM) {
             const int piece = f - 2;
             finish_quad(PT, prev[piece >> 2], pout[piece >> 2], piece & 3);
         }
         if (LT >= 0 && f == 1) lg->request(LT);
         if (LT >= 1 && f == 2 + 4 * CM) lg->add(LT - 1, pout);
-        if (f >= 11 && f < 11 + Geo<PAIRS>::PIECES_PER_TILE * (PAIRS ? 2 : 1) && (!PAIRS || ((f - 11) & 1) == 0))
-            st.piece(P0 + (PAIRS ? (f - 11) / 2 : f - 11));          // this wave's share of the slot three ahead, one behind a k-step
+        constexpr int P1 = 11;
+        if (GI && f < 16) {
+            if (ks >= 1 && ks < 1 + CPW) st.piece(ks - 1);
+            if (ks >= 3 && ks < 11) lg->window_dma(ks - 3);
+        } else if (!(kAbl & 256) && ks >= P1 && ks < P1 + CPW) st.piece(ks - P1);   // this wave's share of the slot three ahead, one behind a k-step
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -298,37 +324,37 @@ __device__ __forceinline__ void tile_mma(lds_cptr tb, const u32x4 (&in)[CM][16],
 template <bool PAIRS>
 struct Layers {
     using G = Geo<PAIRS>;
-    template <int L, int T>
-    static __device__ __forceinline__ void tile(lds_cptr ring, Stream& st, lds_cptr& slot, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
+    // GX: the eight logit-table DMAs of the pass were issued right in front of this chain's first slot, behind the pieces of its first
+    // three slots: those slots' counted waits let them stay in flight (the fourth slot's wait then covers them)
+    template <int L, int T, bool GX = false>
+    static __device__ __forceinline__ void tile(lds_cptr ring, Stream& st, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
                                                 f32x16 (&acc)[2][CM], int lane, LogitAcc* lg) {
         constexpr int t_lin = 8 * L + T;                                   // tile index inside the chain's hidden stream
-        constexpr int in_slot = t_lin % G::TILES_PER_SLOT;
-        if (in_slot == 0) slot = st.begin_slot(ring);
-        lds_cptr tb = slot + in_slot * G::TILE_BYTES + lane * 16;
-        asm volatile("" : "+v"(tb));
         const f32x16 c0 = bias_frag(bias + 256 * L, T, lane >> 5);
         constexpr int cur = t_lin & 1;
         constexpr int PT = (T + 7) & 7;                                    // previous tile (of the previous layer when T == 0)
-        constexpr int P0 = in_slot * G::PIECES_PER_TILE;
         // outputs of the previous tile: layer L - 1's output array when T == 0 (= this layer's input), else this layer's output array
+        constexpr int first_slot = t_lin * G::SLOTS_PER_TILE;
+        constexpr int XS0 = (GX && first_slot >= 1 && first_slot <= 3) ? 8 : 0, XS1 = (GX && first_slot + 1 <= 3) ? 8 : 0;
+        constexpr bool GI = GX && t_lin == 0;
         if constexpr (L == 2) {             // in = a0, out = a1; the k chain accumulates its logit here (lg->on)
-            if constexpr (T == 0) tile_mma<PAIRS, PT, P0, 0>(tb, a0, c0, acc[cur], acc[cur ^ 1], a0, st, lg);
-            else tile_mma<PAIRS, PT, P0, T>(tb, a0, c0, acc[cur], acc[cur ^ 1], a1, st, lg);
+            if constexpr (T == 0) tile_mma<PAIRS, PT, 0>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a0, st, lg);
+            else tile_mma<PAIRS, PT, T>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a1, st, lg);
         } else if constexpr ((L & 1) == 0) {       // in = a0, out = a1
-            if constexpr (T == 0) tile_mma<PAIRS, PT, P0>(tb, a0, c0, acc[cur], acc[cur ^ 1], a0, st);
-            else tile_mma<PAIRS, PT, P0>(tb, a0, c0, acc[cur], acc[cur ^ 1], a1, st);
+            if constexpr (T == 0) tile_mma<PAIRS, PT, -1, XS0, XS1, GI>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a0, st, lg);
+            else tile_mma<PAIRS, PT, -1, XS0, XS1>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a1, st);
         } else {                            // in = a1, out = a0
-            if constexpr (T == 0) tile_mma<PAIRS, PT, P0>(tb, a1, c0, acc[cur], acc[cur ^ 1], a1, st);
-            else tile_mma<PAIRS, PT, P0>(tb, a1, c0, acc[cur], acc[cur ^ 1], a0, st);
+            if constexpr (T == 0) tile_mma<PAIRS, PT>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a1, st);
+            else tile_mma<PAIRS, PT>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a0, st);
         }
     }
-    template <int L>
-    static __device__ __forceinline__ void layer(lds_cptr ring, Stream& st, lds_cptr& slot, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
+    template <int L, bool GX = false>
+    static __device__ __forceinline__ void layer(lds_cptr ring, Stream& st, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
                                                  f32x16 (&acc)[2][CM], int lane, LogitAcc* lg) {
-        tile<L, 0>(ring, st, slot, a0, a1, bias, acc, lane, lg); tile<L, 1>(ring, st, slot, a0, a1, bias, acc, lane, lg);
-        tile<L, 2>(ring, st, slot, a0, a1, bias, acc, lane, lg); tile<L, 3>(ring, st, slot, a0, a1, bias, acc, lane, lg);
-        tile<L, 4>(ring, st, slot, a0, a1, bias, acc, lane, lg); tile<L, 5>(ring, st, slot, a0, a1, bias, acc, lane, lg);
-        tile<L, 6>(ring, st, slot, a0, a1, bias, acc, lane, lg); tile<L, 7>(ring, st, slot, a0, a1, bias, acc, lane, lg);
+        tile<L, 0, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 1, GX>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 2, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 3, GX>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 4>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 5>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 6>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 7>(ring, st, a0, a1, bias, acc, lane, lg);
     }
 };
 
@@ -349,20 +375,21 @@ struct Window {
 };
 
 struct Stager {
-    unsigned lds_stage;             // LDS byte address of this wave's stages: [CM][2][CSTAGE]
+    unsigned lds_stage;             // LDS byte address of this wave's stages: [CM][CNSTAGE][CSTAGE]
     // the 128-B line `line` of all 16 window rows of row tile mi into stage `buf` (two instructions; `off` = Window::t_off / u_off)
     __device__ __forceinline__ void fetch(const i32x4& d, const unsigned (&off)[2], unsigned line, int mi, int buf) const {
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_stage + (unsigned)(mi * 2 + buf) * CSTAGE);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_stage + (unsigned)(mi * CNSTAGE + buf) * CSTAGE);
+        // the line offset rides in the scalar offset (no per-line VGPR: hipcc kept all sixteen per-line offsets of the table rows alive from
+        // the k chain's layer 0 to the v chain's); an out-of-range window pixel stays out of range (the check is on the VGPR offset)
+        const unsigned so = __builtin_amdgcn_readfirstlane(line * 128u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned vo = off[i] == kOobC ? kOobC : off[i] + line * 128u;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(vo), "s"(dst + i * 1024u), "s"(d) : "memory");
-        }
+        for (int i = 0; i < 2; ++i)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" :: "v"(off[i]), "s"(dst + i * 1024u), "s"(d), "s"(so) : "memory");
     }
 };
 // this lane's 16 B of source chunk `chunk` (0..7) of its pixel's line in stage (mi, buf)
 __device__ __forceinline__ f32x4 stage_read(const LDS3 unsigned char* stages, const Window& wn, int mi, int buf, int chunk) {
-    return *(const LDS3 f32x4*)(stages + (mi * 2 + buf) * CSTAGE + wn.slot * 128u + (((unsigned)chunk ^ (wn.slot & 7u)) << 4));
+    return *(const LDS3 f32x4*)(stages + (mi * CNSTAGE + buf) * CSTAGE + wn.slot * 128u + (((unsigned)chunk ^ (wn.slot & 7u)) << 4));
 }
 
 // layer 0 from the hoisted table: acc = T[key pixel][32 T ..] + W1[:, tail] . q4 (one K = 16 MFMA per row tile), relu, convert -> act0.
@@ -371,27 +398,35 @@ __device__ __forceinline__ f32x4 stage_read(const LDS3 unsigned char* stages, co
 __device__ __forceinline__ void build_rows(const LDS3 unsigned char* tail, const i32x4& d_t, const Stager& sg, const LDS3 unsigned char* stages,
                                            const Window (&wn)[CM], const RowState (&rs)[CM], u32x4 (&a0)[CM][16], f32x16 (&acc)[2][CM], int lane) {
     const int lh = lane >> 5;
-    // line T of the window rows = columns 32 T .. 32 T + 31 of the table rows = tile T; two stages per row tile: tile T + 1 is fetched while
-    // tile T is read.  Wait counts: 2 CM instructions per tile; tile T's have landed once at most the 2 CM of tile T + 1 are outstanding.
-    // (Fetching two tiles ahead -- tiles 0, 1 before the preceding phase, tile T + 2 into tile T's stage behind its reads -- measured 1 k cycles
-    // faster per chain and NOT bitwise reproducible from run to run; not understood, not kept.)
+    // line T of the window rows = columns 32 T .. 32 T + 31 of the table rows = tile T; CNSTAGE stages per row tile: tiles T + 1 .. T + D are in
+    // flight while tile T is read (tile T + D goes into the stage tile T - 1 was read from).  Wait counts: 2 CM instructions per tile; tile
+    // T's have landed once at most those of the tiles behind it are outstanding.
+    constexpr int D = CNSTAGE - 1;
 #pragma unroll
-    for (int mi = 0; mi < CM; ++mi) sg.fetch(d_t, wn[mi].t_off, 0, mi, 0);
+    for (int T = 0; T < D; ++T)
+#pragma unroll
+        for (int mi = 0; mi < CM; ++mi) sg.fetch(d_t, wn[mi].t_off, T, mi, T % CNSTAGE);
 #pragma unroll
     for (int T = 0; T < 8; ++T) {
-        if (T + 1 < 8) {
+        if (T + D < 8) {
 #pragma unroll
-            for (int mi = 0; mi < CM; ++mi) sg.fetch(d_t, wn[mi].t_off, T + 1, mi, (T + 1) & 1);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * CM) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int mi = 0; mi < CM; ++mi) sg.fetch(d_t, wn[mi].t_off, T + D, mi, (T + D) % CNSTAGE);
+        }
+        {
+            constexpr int kBehind[8] = {D, D, D, D, D < 3 ? D : 3, D < 2 ? D : 2, D < 1 ? D : 1, 0};
+            switch (kBehind[T]) {
+                case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * CM) : "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(%0)" :: "i"(4 * CM) : "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(%0)" :: "i"(6 * CM) : "memory"); break;
+            }
         }
         f32x16 tr[CM];
 #pragma unroll
         for (int mi = 0; mi < CM; ++mi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 v = stage_read(stages, wn[mi], mi, T & 1, 2 * g + lh);
+                const f32x4 v = stage_read(stages, wn[mi], mi, T % CNSTAGE, 2 * g + lh);
                 tr[mi][4 * g] = v.x; tr[mi][4 * g + 1] = v.y; tr[mi][4 * g + 2] = v.z; tr[mi][4 * g + 3] = v.w;
             }
         const u32x4 a = *(const LDS3 u32x4*)(tail + T * 1024 + lane * 16);
@@ -438,64 +473,91 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
     st.cur = 0;
     st.ridx = 0;
     st.pf_dst = 0; st.pf_src = 0; st.pf_voff = kOobC;
-    // gather stages of this wave: [CM][2][2 KB] behind the bias table
-    const LDS3 unsigned char* stages = (const LDS3 unsigned char*)(lbias + 1536 + 32 * (p.n_vout + 1)) + (size_t)w * (CM * 2 * CSTAGE);
+    // gather stages of this wave: [CM][CNSTAGE][2 KB] behind the bias table
+    const LDS3 unsigned char* stages = (const LDS3 unsigned char*)(lbias + 1536 + 32 * (p.n_vout + 1)) + (size_t)w * (CM * CNSTAGE * CSTAGE);
     Stager sg;
     sg.lds_stage = __builtin_amdgcn_readfirstlane((unsigned)(size_t)stages);
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 2; ++s) st.issue_whole(s);          // (a launch has at least one pass = at least 25 slots)
+    for (int s = 0; s < CRING - 1; ++s) st.issue_whole(s);   // (a launch has at least one pass = at least 50 slots)
 
     const unsigned t_bytes = (unsigned)((size_t)kv.H * kv.W * 1024);
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kv.G), 0, kv.g_bytes, 0x00020000);
     auto desc_of = [](const void* ptr, unsigned bytes) { return i32x4{(int)(unsigned)(size_t)ptr, (int)(((size_t)ptr >> 32) & 0xFFFFu), (int)bytes, 0x00020000}; };
     const i32x4 d_tk = desc_of(kv.k.table, t_bytes), d_tv = desc_of(kv.v.table, t_bytes), d_u = desc_of(kv.U, kv.u_bytes);
     const i32x4 d_z = desc_of(kv.Z, (unsigned)((size_t)kv.nq * kv.ldz * 2));
+    const i32x4 d_g = desc_of(kv.G, kv.g_bytes);
     const bool grid = p.grid_w > 0;
     const int grid_h = grid ? kv.nq / p.grid_w : 0;
     const int nbx = grid ? (p.grid_w + 15) >> 4 : 1;
+
+    // the queries of a pass: where row tile mi's lane sits (ql = index inside the launch, ok = inside it) and its coordinates / cells.
+    // (Issuing the loads of pass n + 1 in front of pass n's v-out loop only moved their wait: hipcc waits for its own loads with vmcnt(0).)
+    struct QIn { int ql; bool ok; float cy, cx, c0y, c0x, cqy, cqx; };
+    auto load_queries = [&](int pass, QIn (&qi)[CM]) {
+#pragma unroll
+        for (int mi = 0; mi < CM; ++mi) {
+            const int ql8 = li >> 2;
+            QIn q;
+            if (grid) {
+                const int bx = pass % nbx, by = pass / nbx;
+                const int g8 = w * CM + mi;           // row tile of the pass: a 4 x 2 block of queries, the eight of them 4 wide and 2 high
+                const int x = 16 * bx + 4 * (g8 & 3) + (ql8 & 3), y = 4 * by + 2 * (g8 >> 2) + (ql8 >> 2);
+                q.ok = x < p.grid_w && y < grid_h;
+                q.ql = y * p.grid_w + x;
+            } else {
+                q.ql = (pass * 8 + w * CM + mi) * 8 + ql8;
+                q.ok = q.ql < kv.nq;
+            }
+            q.ok = q.ok && pass < p.n_pass;
+            q.cy = q.cx = q.c0y = q.c0x = q.cqy = q.cqx = 0.f;
+            if (q.ok) {
+                const long qq = kv.q0 + q.ql;
+                const long c0 = kv.chunk > 0 ? (qq / kv.chunk) * kv.chunk : 0;
+                q.cy = kv.coord[2 * qq]; q.cx = kv.coord[2 * qq + 1];
+                q.c0y = kv.cell[2 * c0]; q.c0x = kv.cell[2 * c0 + 1];
+                q.cqy = kv.cell[2 * qq]; q.cqx = kv.cell[2 * qq + 1];
+            }
+            qi[mi] = q;
+        }
+    };
+    QIn qin[CM];
 
     int pass_i = 0;
 #pragma unroll 1
     for (int pass = blockIdx.x; pass < p.n_pass; pass += gridDim.x, ++pass_i) {
         CPROBE(0);
+        load_queries(pass, qin);
         // ---- index math: row m = 4 q + j of row tile mi --------------------------------------------------------------------------
         RowState rs[CM];
         Window wn[CM];
         int bad = 0;
+        int g_row0 = 0;
+        bool g_wide = false;
 #pragma unroll
         for (int mi = 0; mi < CM; ++mi) {
-            const int ql8 = li >> 2, j = li & 3;
+            const int j = li & 3;
             int ky = 0x7FFF, kx = 0x7FFF;
-            int ql;
-            bool ok;
-            if (grid) {
-                const int bx = pass % nbx, by = pass / nbx;
-                const int g8 = w * CM + mi;           // row tile of the pass: a 4 x 2 block of queries, the eight of them 4 wide and 2 high
-                const int x = 16 * bx + 4 * (g8 & 3) + (ql8 & 3), y = 4 * by + 2 * (g8 >> 2) + (ql8 >> 2);
-                ok = x < p.grid_w && y < grid_h;
-                ql = y * p.grid_w + x;
-            } else {
-                ql = (pass * 8 + w * CM + mi) * 8 + ql8;
-                ok = ql < kv.nq;
-            }
+            const int ql = qin[mi].ql;
+            const bool ok = qin[mi].ok;
             RowState r;
-            r.koff = 0; r.uoff = 0; r.goff = kOobC; r.zoff = kOobC; r.attn = 0.f;
+            r.koff = 0; r.uoff = 0; r.goff = kOobC; r.grow = 0x7FFFFFFF; r.zoff = kOobC; r.attn = 0.f;
             float t4[4] = {0.f, 0.f, 0.f, 0.f};
             if (ok) {
-                const long q = kv.q0 + ql;
-                const float cy = kv.coord[2 * q], cx = kv.coord[2 * q + 1];
-                const long c0 = kv.chunk > 0 ? (q / kv.chunk) * kv.chunk : 0;
-                const KeySample s = key_sample(cy, cx, kv.cell[2 * c0], kv.cell[2 * c0 + 1], kv.H, kv.W, j, 2);
+                const float cy = qin[mi].cy, cx = qin[mi].cx;
+                const KeySample s = key_sample(cy, cx, qin[mi].c0y, qin[mi].c0x, kv.H, kv.W, j, 2);
                 const int kpix = s.ky * kv.W + s.kx;
                 ky = s.ky; kx = s.kx;
                 t4[0] = s.rel_y; t4[1] = s.rel_x;
-                t4[2] = mul_rn(kv.cell[2 * q], (float)kv.H);
-                t4[3] = mul_rn(kv.cell[2 * q + 1], (float)kv.W);
+                t4[2] = mul_rn(qin[mi].cqy, (float)kv.H);
+                t4[3] = mul_rn(qin[mi].cqx, (float)kv.W);
                 const int iy = nearest_index(cy, kv.H), ix = nearest_index(cx, kv.W);
                 if (iy >= 0 && iy < kv.H && ix >= 0 && ix < kv.W) {
                     const int oy = s.ky - iy, ox = s.kx - ix;
-                    if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) r.goff = (unsigned)((iy * kv.W + ix) * 9 + (oy + 1) * 3 + (ox + 1)) * (unsigned)kv.ldg * 4u;
+                    if (oy >= -1 && oy <= 1 && ox >= -1 && ox <= 1) {
+                        r.grow = (iy * kv.W + ix) * 9 + (oy + 1) * 3 + (ox + 1);
+                        r.goff = (unsigned)r.grow * (unsigned)kv.ldg * 4u;
+                    }
                     else bad = 1;
                 }
                 r.koff = (unsigned)kpix * 1024u;
@@ -505,9 +567,13 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
             r.q4 = q4_operand(t4[0], t4[1], t4[2], t4[3]);
             rs[mi] = r;
             // gather window of the row tile: origin = the smallest key row / column of its 32 rows (rows of out-of-range queries stand aside)
-            int y0 = ky, x0 = kx;
+            int y0 = ky, x0 = kx, g0 = r.grow;
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) { y0 = min(y0, __shfl_xor(y0, d, 64)); x0 = min(x0, __shfl_xor(x0, d, 64)); }
+            for (int d = 1; d < 32; d <<= 1) { y0 = min(y0, __shfl_xor(y0, d, 64)); x0 = min(x0, __shfl_xor(x0, d, 64)); g0 = min(g0, __shfl_xor(g0, d, 64)); }
+            // logit-table rows of the row tile: a window of 8 consecutive rows from the smallest one (at an integer scale the 32 rows of a
+            // 4 x 2 block of queries share the query pixel and use 6 of its 9 rows); wider spreads take the four-round path
+            g_row0 = __builtin_amdgcn_readfirstlane(g0);
+            g_wide = __builtin_amdgcn_ballot_w64(r.grow != 0x7FFFFFFF && r.grow - g0 >= 8) != 0;
             Window wv;
             const int dy = ky - y0, dx = kx - x0;
             wv.slot = 0;
@@ -530,7 +596,6 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
 
         u32x4 act0[CM][16], act1[CM][16];
         f32x16 acc[2][CM];
-        lds_cptr slot = ring;
 
         // ================= phi_k =================================================================================================
         CPROBE(1);
@@ -538,36 +603,94 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
         CPROBE(2);
         LogitAcc lg;
         lg.rs_g = rs_g; lg.lh = lh; lg.on = kFusedLogit;
+        {
+            // the logit-table window goes into the (now idle) gather stages under the first hidden tile, see tile_mma GI.  A wide row tile
+            // issues the same eight instructions out of range (zeros): the counted waits do not depend on the path
+            const bool fast = !g_wide && g_row0 != 0x7FFFFFFF && !(kAbl & 32);
+            lg.g_desc = d_g;
+            lg.g_vo = fast ? (unsigned)g_row0 * (unsigned)kv.ldg * 4u : kOobC;
+            lg.g_lane = (unsigned)lane;
+            lg.g_row_bytes = (unsigned)kv.ldg * 4u;
+            lg.g_lds = sg.lds_stage;
+        }
 #pragma unroll
         for (int mi = 0; mi < CM; ++mi) { lg.goff[mi] = rs[mi].goff; lg.sum[mi] = 0.f; }
-        Layers<PAIRS>::template layer<0>(ring, st, slot, act0, act1, lbias, acc, lane, &lg);
-        Layers<PAIRS>::template layer<1>(ring, st, slot, act0, act1, lbias, acc, lane, &lg);
-        Layers<PAIRS>::template layer<2>(ring, st, slot, act0, act1, lbias, acc, lane, &lg);
+        Layers<PAIRS>::template layer<0, !kFusedLogit>(ring, st, act0, act1, lbias, acc, lane, &lg);
+        Layers<PAIRS>::template layer<1>(ring, st, act0, act1, lbias, acc, lane, &lg);
+        Layers<PAIRS>::template layer<2>(ring, st, act0, act1, lbias, acc, lane, &lg);
         finish_tile(7, acc[1], act1);            // layer 2 (third hidden layer) writes act1; its tile 7 sits in acc[(16 + 7) & 1] = acc[1]
         CPROBE(3);
         lg.add(7, act1);
-        if (!kFusedLogit) {                  // the logit as a phase of its own: 32 gathers of the lane's half row, 16 in flight at a time
+        float g_const = 0.f;
+        if (!kFusedLogit) {
+            // The logit as a phase of its own: h3 . G[row] with the 32 logit-table rows of the row tile staged through this wave's gather
+            // stages (8 KB) by LDS-DMA, 256 B of every row per round (k-steps 4 r .. 4 r + 3), four rounds.  hipcc's form of the direct
+            // gather (32 x 16 B per lane) kept two loads in flight: 9.8 k cycles.  Instruction i of a round fetches rows 4 i .. 4 i + 3
+            // (16 lanes a row; lane position p receives source chunk p ^ (row & 15): the readers of a ds_read_b128 lane group then fall
+            // on 16 different bank quads).
+            static_assert(CM == 1 && CNSTAGE * CSTAGE == 8192, "8 KB of stages per wave");
+            float asum = 0.f;
+            if (!g_wide && g_row0 != 0x7FFFFFFF && !(kAbl & 32)) {
+                // the window's rows landed under the hidden layers (the fourth slot's counted wait covered them): row slot sm, chunk c =
+                // 4 s + 2 hi4 + lh of k-step s at position c ^ 2 sm
+                const unsigned gb = rs[0].goff;
+                g_const = gb != kOobC ? kv.G[(size_t)(gb >> 2) + 256] : 0.f;
+                const unsigned sm = gb != kOobC ? (unsigned)(rs[0].grow - g_row0) : 0u;
+                const LDS3 unsigned char* rq[8];
 #pragma unroll
-            for (int mi = 0; mi < CM; ++mi) {
-                const unsigned gb = rs[mi].goff;
-                float a = 0.f;
+                for (int x = 0; x < 8; ++x) rq[x] = stages + sm * 1024u + (unsigned)lh * 16u + ((((unsigned)x) ^ sm) << 5);
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    f32x4 gv[16];
+                for (int half = 0; half < 4; ++half) {
+                    f32x4 gv[8];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int s = 8 * half + (i >> 1), hi4 = i & 1;
-                        gv[i] = (kAbl & 32) ? f32x4{0.1f, 0.2f, 0.3f, 0.4f} : cload4(rs_g, gb == kOobC ? kOobC : gb + (unsigned)(16 * s + 8 * hi4 + 4 * lh) * 4u);
+                    for (int i = 0; i < 8; ++i) {
+                        const int s4 = 4 * half + (i >> 1), hi4 = i & 1;
+                        gv[i] = *(const LDS3 f32x4*)(rq[hi4 | ((s4 & 3) << 1)] + (s4 >> 2) * 256);
                     }
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int s = 8 * half + (i >> 1), hi4 = i & 1;
-                        const unsigned x0 = hi4 ? act1[mi][s].z : act1[mi][s].x, x1 = hi4 ? act1[mi][s].w : act1[mi][s].y;
-                        a += h16_lo<kF16>(x0) * gv[i].x + h16_hi<kF16>(x0) * gv[i].y + h16_lo<kF16>(x1) * gv[i].z + h16_hi<kF16>(x1) * gv[i].w;
+                    for (int i = 0; i < 8; ++i) {
+                        const int s4 = 4 * half + (i >> 1), hi4 = i & 1;
+                        const unsigned x0 = hi4 ? act1[0][s4].z : act1[0][s4].x, x1 = hi4 ? act1[0][s4].w : act1[0][s4].y;
+                        asum += h16_lo<kF16>(x0) * gv[i].x + h16_hi<kF16>(x0) * gv[i].y + h16_lo<kF16>(x1) * gv[i].z + h16_hi<kF16>(x1) * gv[i].w;
                     }
                 }
-                lg.sum[mi] = a;
+                if (gb == kOobC) asum = 0.f;
+            } else {
+                // four rounds through the stages: 256 B of every row per round (k-steps 4 r .. 4 r + 3); instruction i of a round fetches
+                // rows 4 i .. 4 i + 3, 16 lanes a row, lane position p receiving source chunk p ^ (row & 15)
+                const unsigned gb = rs[0].goff;
+                g_const = (gb != kOobC && !(kAbl & 32)) ? kv.G[(size_t)(gb >> 2) + 256] : 0.f;
+                int lo = lane;                      // opaque copy: the per-lane addresses below are loop invariants hipcc would otherwise hoist out
+                asm volatile("" : "+v"(lo));        // of the pass loop and keep in 24 registers for the whole kernel
+                const int lio = lo & 31, lho = lo >> 5;
+                const LDS3 unsigned char* rd0 = stages + lio * 256;
+#pragma unroll 1
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int rr = 4 * i + (lo >> 4);
+                        const unsigned g = (unsigned)__shfl((int)gb, rr, 64);
+                        const unsigned vo = ((kAbl & 32) || g == kOobC) ? kOobC : g + ((unsigned)((lo & 15) ^ (rr & 15)) << 4) + (unsigned)r * 256u;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(sg.lds_stage + (unsigned)i * 1024u);
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, 0 offen lds" :: "v"(vo), "s"(dst), "s"(d_g) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (r == 0) asm volatile("" :: "v"(g_const));          // requested in front of round 0, here: hipcc must not sink the load to its use
+                    f32x4 gv[8];
+#pragma unroll
+                    for (int c2 = 0; c2 < 8; ++c2) gv[c2] = *(const LDS3 f32x4*)(rd0 + ((((unsigned)(2 * c2 + lho)) ^ (unsigned)(lio & 15)) << 4));
+                    u32x4 hr[4];                // act1[0][4 r .. 4 r + 3] (r is a run-time index: the loop is rolled to keep the path small)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) hr[q] = r == 0 ? act1[0][q] : (r == 1 ? act1[0][4 + q] : (r == 2 ? act1[0][8 + q] : act1[0][12 + q]));
+#pragma unroll
+                    for (int c2 = 0; c2 < 8; ++c2) {
+                        const int q = c2 >> 1, hi4 = c2 & 1;
+                        const unsigned x0 = hi4 ? hr[q].z : hr[q].x, x1 = hi4 ? hr[q].w : hr[q].y;
+                        asum += h16_lo<kF16>(x0) * gv[c2].x + h16_hi<kF16>(x0) * gv[c2].y + h16_lo<kF16>(x1) * gv[c2].z + h16_hi<kF16>(x1) * gv[c2].w;
+                    }
+                }
             }
+            lg.sum[0] = asum;
         }
         // ---- logit (accumulated under layer 2, LogitAcc) + the table's constant term, 4-way softmax over the quad --------------------
 #pragma unroll
@@ -575,7 +698,8 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
             const unsigned gb = rs[mi].goff;
             float a = lg.sum[mi];
             a += __shfl_xor(a, 32, 64);
-            if (gb != kOobC) a += kv.G[(size_t)(gb >> 2) + 256];
+            if (kFusedLogit) { if (gb != kOobC) a += kv.G[(size_t)(gb >> 2) + 256]; }
+            else a += g_const;                       // (0 from the out-of-range load of a row without a table entry)
             const float lg = a / kv.softmax_scale;
             float m = fmaxf(lg, quad_xor1(lg));
             m = fmaxf(m, quad_xor2(m));
@@ -590,9 +714,9 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
         build_rows(tails + CTAIL, d_tv, sg, stages, wn, rs, act0, acc, lane);
         CPROBE(5);
         lg.on = false;
-        Layers<PAIRS>::template layer<0>(ring, st, slot, act0, act1, lbias + 768, acc, lane, &lg);
-        Layers<PAIRS>::template layer<1>(ring, st, slot, act0, act1, lbias + 768, acc, lane, &lg);
-        Layers<PAIRS>::template layer<2>(ring, st, slot, act0, act1, lbias + 768, acc, lane, &lg);
+        Layers<PAIRS>::template layer<0>(ring, st, act0, act1, lbias + 768, acc, lane, &lg);
+        Layers<PAIRS>::template layer<1>(ring, st, act0, act1, lbias + 768, acc, lane, &lg);
+        Layers<PAIRS>::template layer<2>(ring, st, act0, act1, lbias + 768, acc, lane, &lg);
         finish_tile(7, acc[1], act1);
         CPROBE(6);
         // ---- output layer fused with z = sum_j a_j value_j . (W h_j + b): one 32-column unit per tile of the stream ------------------
@@ -604,11 +728,11 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
             auto fetch_vv = [&](int u) {
                 if (kAbl & 1) return;
 #pragma unroll
-                for (int mi = 0; mi < CM; ++mi) sg.fetch(d_u, wn[mi].u_off, (unsigned)u, mi, u & 1);
+                for (int mi = 0; mi < CM; ++mi) sg.fetch(d_u, wn[mi].u_off, (unsigned)u, mi, u & (CNSTAGE - 1));
             };
             auto read_vv = [&](int u, int mi, int g) -> f32x4 {
                 if (kAbl & 1) return f32x4{1.f, 1.f, 1.f, 1.f};
-                return stage_read(stages, wn[mi], mi, u & 1, 2 * g + lh);
+                return stage_read(stages + (u & (CNSTAGE - 1)) * CSTAGE, wn[mi], mi, 0, 2 * g + lh);
             };
             // epilogue of a unit in 8 + 2 pieces, each behind one k-step of the NEXT unit: piece (mi, g) reduces accumulator registers 4 g ..
             // 4 g + 3 of row tile mi over the quad (the four key samples of a query) and keeps them in the lane whose sample index is g
@@ -657,70 +781,121 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
                 const unsigned long long zd = (unsigned long long)zb.x | ((unsigned long long)zb.y << 32);
                 if (!(kAbl & 2)) asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen" :: "v"(zd), "v"(zo), "s"(d_z) : "memory");
             };
-            // Vector-memory operations of a unit, in issue order: [k-step 4 CM + 1] 2 CM fetch instructions, then CM Z stores (one per k-step),
-            // then PPT weight pieces.  Behind the fetch of unit u's line (issued in unit u - 1) and in front of its first read (unit u + 1,
-            // k-step 0) this wave has issued KW of them; unit 1 reads the line fetched in front of the loop: K1.
-            constexpr int KW = 2 * (PPT + CM) + 2 * CM, K1 = PPT + CM + 2 * CM;
-            auto epilogue = [&](int u, const f32x16 (&c)[CM]) {       // whole, for the last unit
-                asm volatile("s_waitcnt vmcnt(%0)" :: "i"(KW) : "memory");
+            static_assert(CM == 1, "the pipelined v-out epilogue is written for one row tile per wave");
+            // Vector-memory operations of a unit, in issue order: [k-step 0] the Z store of unit u - 2, [k-step 5] the two fetch instructions
+            // of line u + VD, [k-steps 11, 12 of each slot] PPT weight pieces: OPU of them.  Line L is first read behind the last k-step of
+            // unit L (value rows of accumulator registers 0-3 of the epilogue that runs under unit L + 1): behind its fetch this wave has
+            // issued KW operations by then; lines 0 .. VD - 1 are fetched in front of the loop.
+            constexpr int VD = 2, OPU = 3 + PPT;
+            constexpr int KW = PPT + VD * OPU;
+            auto wait_line = [&](int line) {        // uniform
+                if (line >= VD) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(KW) : "memory");
+                else if (line == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (VD - 1) + OPU) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * OPU) : "memory");
+            };
+            static_assert(VD == 2 && VD + 2 <= CNSTAGE, "a line's stage is free again two units after its reads");
+            auto epilogue = [&](int u, const f32x16 (&c)[CM]) {       // whole, for the last unit (its line has been waited for)
 #pragma unroll
-                for (int mi = 0; mi < CM; ++mi) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) epi_piece(mi, g, c[mi], read_vv(u, mi, g));
-                    epi_store(u, mi);
+                for (int g = 0; g < 4; ++g) epi_piece(0, g, c[0], read_vv(u, 0, g));
+            };
+            // The epilogue of unit u - 1 under unit u, one accumulator register r = 4 g + i at a time in three stages a k-step apart, so that the
+            // VALU work is spread evenly (about 5 instructions behind every MFMA; the first cut's 16-20-instruction blocks behind four of
+            // the sixteen MFMAs ran in series with the MFMAs of BOTH waves of the SIMD) and every DPP source is a k-step old:
+            //   A(r): t_r = (attn . value_r) . acc_r      B(r): t_r += quad-neighbour 1      C(r): t_r += quad-neighbour 2, kept by sample g's lane
+            float tt[16];
+            auto stage_a = [&](int r, const f32x16& c, const f32x4& val) {
+                if (kAbl & 4) { tt[r] = c[r] + val[r & 3]; return; }
+                asm volatile("v_mul_f32 %0, %1, %2\n\tv_mul_f32 %0, %0, %3" : "=&v"(tt[r]) : "v"(rs[0].attn), "v"(val[r & 3]), "v"(c[r]));
+            };
+            auto stage_b = [&](int r) {
+                if (kAbl & 4) return;
+                asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(tt[r]));
+            };
+            auto stage_c = [&](int r) {
+                const int g = r >> 2, i = r & 3;
+                if (kAbl & 4) { if (g == 0) zk[0][i] = tt[r]; return; }
+                if (g == 0) {
+                    asm volatile("v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(zk[0][i]) : "v"(tt[r]));
+                } else {
+                    const unsigned long long lanes_g = 0x1111111111111111ull << g;        // lanes whose key-sample index is g
+                    asm volatile("v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\tv_cndmask_b32 %0, %0, %1, %2"
+                                 : "+v"(zk[0][i]), "+v"(tt[r]) : "s"(lanes_g));
                 }
             };
-            fetch_vv(0);
+#pragma unroll
+            for (int l = 0; l < VD; ++l) fetch_vv(l);
             const LDS3 float* bo = lbias + 1536;
-            // two units per iteration: static accumulator / value-row buffers; the stream pads an odd unit count with a zero tile
+            f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f}, vb = va;       // value rows of register groups g = 0, 2 / g = 1, 3
+            // two units per iteration: static accumulator buffers; the stream pads an odd unit count with a zero tile
             const int n_u2 = (p.n_vout + 1) >> 1;
 #pragma unroll 1
             for (int u2 = 0; u2 < n_u2; ++u2) {
 #pragma unroll
                 for (int par = 0; par < 2; ++par) {
                     const int u = 2 * u2 + par;
-                    const int in_slot = G::TILES_PER_SLOT == 2 ? par : 0;
-                    if (in_slot == 0) {
-                        // behind slot cur's pieces: the pieces of slot cur + 1 and, from the v-out's second slot on, the fetches and stores of the
-                        // units that ran meanwhile (TILES_PER_SLOT of them)
-                        if (u2 == 0 && par == 0) slot = st.begin_slot(ring);
-                        else slot = st.template begin_slot<G::TILES_PER_SLOT * 3 * CM>(ring);
-                    }
-                    lds_cptr tb = slot + in_slot * G::TILE_BYTES + lane * 16;
-                    asm volatile("" : "+v"(tb));
                     const f32x16 c0 = bias_frag(bo, u, lh);
                     constexpr int STEPS = G::STEPS;
                     u32x4 a[3];
-                    f32x4 vcur = f32x4{0.f, 0.f, 0.f, 0.f}, vnext = vcur;
-                    a[0] = *(const LDS3 u32x4*)(tb);
-                    a[1] = *(const LDS3 u32x4*)(tb + 1024);
+                    lds_cptr tb = ring;
+                    const f32x16& cprev = acc[par ^ 1][0];
 #pragma unroll
                     for (int f = 0; f < STEPS; ++f) {
                         const int ks = f & 15;
-                        if (f + 2 < STEPS) a[(f + 2) % 3] = *(const LDS3 u32x4*)(tb + (f + 2) * 1024);
-#pragma unroll
-                        for (int mi = 0; mi < CM; ++mi) acc[par][mi] = mfma(a[f % 3], act1[mi][ks], f == 0 ? c0 : acc[par][mi]);
-                        // the previous unit's epilogue, a piece per k-step under this unit's MFMAs (unit 0 "finishes" unit -1: stores nothing).
-                        // Its value rows were fetched a unit and a half ago: behind that fetch this wave issued PPT weight pieces and the
-                        // 2 CM instructions of the next fetch at least, so "at most that many outstanding" says they have landed
-                        if (f == 0) {
-                            if (u2 == 0 && par == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(K1) : "memory");
-                            else if (u2 > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(KW) : "memory");
+                        if (ks == 0) {
+                            // behind slot cur's pieces (issued three slots ago): the pieces of slots cur + 1, cur + 2, the stores and fetches (3 a
+                            // unit, k-steps 0 and 5 of its first slot) of the v-out units among the last two slots, the 2 VD fetches in front of
+                            // the loop while the pieces date from the hidden layers
+                            constexpr int PRE = 2 * VD;
+                            lds_cptr sl;
+                            if (!PAIRS) {
+                                if (u == 0) sl = st.template begin_slot<PRE>(ring);
+                                else if (u == 1) sl = st.template begin_slot<PRE + 3>(ring);
+                                else if (u == 2) sl = st.template begin_slot<PRE + 6>(ring);
+                                else sl = st.template begin_slot<6>(ring);
+                            } else if (f == 0) {
+                                if (u == 0) sl = st.template begin_slot<PRE>(ring);
+                                else if (u == 1) sl = st.template begin_slot<PRE + 3>(ring);
+                                else sl = st.template begin_slot<3>(ring);
+                            } else {
+                                if (u == 0) sl = st.template begin_slot<PRE + 3>(ring);
+                                else sl = st.template begin_slot<3>(ring);
+                            }
+                            tb = sl + lane * 16;
+                            asm volatile("" : "+v"(tb));
+                            a[f % 3] = *(const LDS3 u32x4*)(tb);
+                            a[(f + 1) % 3] = *(const LDS3 u32x4*)(tb + 1024);
                         }
-                        if (f < 4 * CM) vnext = read_vv(par ^ 1, f >> 2, f & 3);                 // stage parity of unit u - 1 = par ^ 1
-                        if (f >= 1 && f < 1 + 4 * CM) epi_piece((f - 1) >> 2, (f - 1) & 3, acc[par ^ 1][(f - 1) >> 2], vcur);
-                        vcur = vnext;
-                        if (f == 1 + 4 * CM) fetch_vv(u + 1);                              // ... whose stage then takes unit u + 1's line
-                        if (f >= 1 + 4 * CM && f < 1 + 5 * CM) epi_store(u - 1, f - 1 - 4 * CM);
-                        if (!(kAbl & 8) && f >= 11 && f < 11 + G::PIECES_PER_TILE * (PAIRS ? 2 : 1) && (!PAIRS || ((f - 11) & 1) == 0))
-                            st.piece(in_slot * G::PIECES_PER_TILE + (PAIRS ? (f - 11) / 2 : f - 11));
+                        if (ks + 2 < 16) a[(f + 2) % 3] = *(const LDS3 u32x4*)(tb + (ks + 2) * 1024);
+                        acc[par][0] = mfma(a[f % 3], act1[0][ks], f == 0 ? c0 : acc[par][0]);
+                        if (f == 0) epi_store(u - 2, 0);                                   // formed under unit u - 1
+                        if (f == 2) vb = read_vv(u - 1, 0, 1);
+                        if (f == 6) va = read_vv(u - 1, 0, 2);
+                        if (f == 10) vb = read_vv(u - 1, 0, 3);
+                        if (f < 16) {
+                            // registers whose stage A sits at k-step x: x for x < 12, (12, 13) at 12, (14, 15) at 13
+                            auto first = [](int x) { return x < 0 ? 0 : (x < 12 ? x : (x == 12 ? 12 : 14)); };
+                            auto count = [](int x) { return x < 0 || x > 13 ? 0 : (x < 12 ? 1 : 2); };
+                            if (count(f - 2) >= 1) stage_c(first(f - 2));
+                            if (count(f - 2) == 2) stage_c(first(f - 2) + 1);
+                            if (count(f - 1) >= 1) stage_b(first(f - 1));
+                            if (count(f - 1) == 2) stage_b(first(f - 1) + 1);
+                            if (count(f) >= 1) stage_a(first(f), cprev, ((first(f) >> 2) & 1) ? vb : va);
+                            if (count(f) == 2) stage_a(first(f) + 1, cprev, (((first(f) + 1) >> 2) & 1) ? vb : va);
+                        }
+                        if (f == 5) fetch_vv(u + VD);
+                        if (!(kAbl & 8) && ks >= 11 && ks < 11 + CPW) st.piece(ks - 11);
+                        if (f == STEPS - 1) { wait_line(u); va = read_vv(u, 0, 0); }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            // the last real unit (the pad tile of an odd count computed zeros + bias 0: nothing to store for it)
-            const int last = p.n_vout - 1;
-            if (last & 1) epilogue(last, acc[1]);
+            // drain: Z of the last-but-one unit run; an even unit count leaves the last unit's epilogue to do (an odd count's pad unit ran it)
+            const int u_end = 2 * n_u2;
+            epi_store(u_end - 2, 0);
+            if (!(p.n_vout & 1)) {
+                epilogue(u_end - 1, acc[1]);
+                epi_store(u_end - 1, 0);
+            }
         }
         CPROBE(7);
     }
@@ -732,9 +907,8 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
 static int chain_tiles(const ciaosr_head_weights_t* w, int pairs) {
     const int n_vout = (w->v.width[w->v.n_layers - 1] + 31) / 32;
-    int tiles = 24 + 24 + n_vout;
-    const int per_slot = pairs ? 1 : 2;
-    return (tiles + per_slot - 1) / per_slot * per_slot;
+    (void)pairs;
+    return 24 + 24 + ((n_vout + 1) & ~1);           // the v-out loop runs two units per iteration: an odd count is padded with a zero tile
 }
 
 bool head_chain_ok(const ciaosr_head_weights_t* w) {
@@ -742,7 +916,7 @@ bool head_chain_ok(const ciaosr_head_weights_t* w) {
     for (int i = 0; i < 4; ++i)
         if (w->k.width[i] != 256 || w->v.width[i] != 256) return false;
     const int n_vout = (w->v.width[4] + 31) / 32;
-    const size_t lds = (size_t)chain::CRING * chain::CSLOT + 2 * chain::CTAIL + (size_t)(1536 + 32 * (n_vout + 1)) * 4 + (size_t)chain::CNW * chain::CM * 2 * chain::CSTAGE;
+    const size_t lds = (size_t)chain::CRING * chain::CSLOT + 2 * chain::CTAIL + (size_t)(1536 + 32 * (n_vout + 1)) * 4 + (size_t)chain::CNW * chain::CM * chain::CNSTAGE * chain::CSTAGE;
     return lds <= 160 * 1024;
 }
 
@@ -781,14 +955,13 @@ int head_kv_chain_h16(const FusedKVP& kp, const ciaosr_head_weights_t* w, const 
     p.kv = kp;
     p.blob = reinterpret_cast<const unsigned char*>(blob);
     p.blob_bytes = (unsigned)head_chain_bytes(w, pairs);
-    const int per_slot = pairs ? 1 : 2;
-    p.n_slots = chain_tiles(w, pairs) / per_slot;
+    p.n_slots = chain_tiles(w, pairs) * (pairs ? 2 : 1);
     p.n_vout = (w->v.width[4] + 31) / 32;
     p.grid_w = (grid_w > 0 && kp.nq % grid_w == 0 && kp.q0 % grid_w == 0) ? grid_w : 0;
     if (p.grid_w) p.n_pass = ((p.grid_w + 15) / 16) * ((kp.nq / p.grid_w + 3) / 4);
     else p.n_pass = (kp.nq + CQ - 1) / CQ;
     p.flag = flag;
-    const size_t lds = (size_t)CRING * CSLOT + 2 * CTAIL + (size_t)(1536 + 32 * (p.n_vout + 1)) * 4 + (size_t)CNW * CM * 2 * CSTAGE;
+    const size_t lds = (size_t)CRING * CSLOT + 2 * CTAIL + (size_t)(1536 + 32 * (p.n_vout + 1)) * 4 + (size_t)CNW * CM * CNSTAGE * CSTAGE;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int grid = p.n_pass < cus ? p.n_pass : cus;
