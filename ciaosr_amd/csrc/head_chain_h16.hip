@@ -283,10 +283,10 @@ struct LogitAcc {
 // tb: LDS address of the tile's fragments (+ lane * 16).  PT >= 0: `prev` is the accumulator of tile PT of the layer whose outputs go
 // to `pout` (finished here, behind k-steps 2 ..).  Returns this tile's accumulators.
 // LT >= 0: this is tile LT of the k chain's third hidden layer (see LogitAcc): request its G columns, multiply in tile LT - 1's.
-// GI: the first tile of the k chain issues its weight pieces early (k-steps 1 ..) and the eight logit-table window DMAs behind them (k-steps
-// 3 .. 10): younger than the pieces of the three slots that follow (their waits carry XS = 8), a good four tiles old when the slot
-// after those wants them landed
-template <bool PAIRS, int PT, int LT = -1, int XS0 = 0, int XS1 = 0, bool GI = false>
+// GI >= 0: tile GI (0..7) of the k chain's first hidden layer issues its weight pieces early (k-steps 1 ..) and window_dma(GI), one of the eight
+// logit-table window DMAs, behind them (k-step 3): one 1-KB request per wave and tile instead of a chip-wide 16-MB burst in front of
+// the chain (every workgroup starts its passes together; the burst took 7-8 k cycles to land and stalled the chain for 3 k of them)
+template <bool PAIRS, int PT, int LT = -1, int XS0 = 0, int XS1 = 0, int GI = -1>
 __device__ __forceinline__ void tile_mma(lds_cptr ring, int lane, const u32x4 (&in)[CM][16], const f32x16& c0, f32x16 (&acc)[CM], const f32x16 (&prev)[CM],
                                          u32x4 (&pout)[CM][16], Stream& st, LogitAcc* lg = nullptr) {
     constexpr int STEPS = Geo<PAIRS>::STEPS;
@@ -311,9 +311,9 @@ __device__ __forceinline__ void tile_mma(lds_cptr ring, int lane, const u32x4 (&
         if (LT >= 0 && f == 1) lg->request(LT);
         if (LT >= 1 && f == 2 + 4 * CM) lg->add(LT - 1, pout);
         constexpr int P1 = 11;
-        if (GI && f < 16) {
+        if (GI >= 0 && f < 16) {
             if (ks >= 1 && ks < 1 + CPW) st.piece(ks - 1);
-            if (ks >= 3 && ks < 11) lg->window_dma(ks - 3);
+            if (ks == 1 + CPW) lg->window_dma(GI);
         } else if (!(kAbl & 256) && ks >= P1 && ks < P1 + CPW) st.piece(ks - P1);   // this wave's share of the slot three ahead, one behind a k-step
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -324,8 +324,14 @@ __device__ __forceinline__ void tile_mma(lds_cptr ring, int lane, const u32x4 (&
 template <bool PAIRS>
 struct Layers {
     using G = Geo<PAIRS>;
-    // GX: the eight logit-table DMAs of the pass were issued right in front of this chain's first slot, behind the pieces of its first
-    // three slots: those slots' counted waits let them stay in flight (the fourth slot's wait then covers them)
+    // GX (k chain): window DMA t is issued in the first slot of tile t < 8, behind that slot's (early) weight pieces.  Slot k waits for its
+    // pieces, issued in slot k - 3: the window DMAs of slots k - 3 .. k - 1 are younger and may stay in flight (extra(k) of them)
+    static constexpr int extra(int k) {
+        int n = 0;
+        for (int j = k - 3; j <= k - 1; ++j)
+            if (j >= 0 && j % G::SLOTS_PER_TILE == 0 && j / G::SLOTS_PER_TILE < 8) ++n;
+        return n;
+    }
     template <int L, int T, bool GX = false>
     static __device__ __forceinline__ void tile(lds_cptr ring, Stream& st, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
                                                 f32x16 (&acc)[2][CM], int lane, LogitAcc* lg) {
@@ -335,17 +341,17 @@ struct Layers {
         constexpr int PT = (T + 7) & 7;                                    // previous tile (of the previous layer when T == 0)
         // outputs of the previous tile: layer L - 1's output array when T == 0 (= this layer's input), else this layer's output array
         constexpr int first_slot = t_lin * G::SLOTS_PER_TILE;
-        constexpr int XS0 = (GX && first_slot >= 1 && first_slot <= 3) ? 8 : 0, XS1 = (GX && first_slot + 1 <= 3) ? 8 : 0;
-        constexpr bool GI = GX && t_lin == 0;
+        constexpr int XS0 = GX ? extra(first_slot) : 0, XS1 = GX ? extra(first_slot + 1) : 0;
+        constexpr int GI = (GX && t_lin < 8) ? t_lin : -1;
         if constexpr (L == 2) {             // in = a0, out = a1; the k chain accumulates its logit here (lg->on)
             if constexpr (T == 0) tile_mma<PAIRS, PT, 0>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a0, st, lg);
             else tile_mma<PAIRS, PT, T>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a1, st, lg);
         } else if constexpr ((L & 1) == 0) {       // in = a0, out = a1
             if constexpr (T == 0) tile_mma<PAIRS, PT, -1, XS0, XS1, GI>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a0, st, lg);
-            else tile_mma<PAIRS, PT, -1, XS0, XS1>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a1, st);
+            else tile_mma<PAIRS, PT, -1, XS0, XS1, GI>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a1, st, lg);
         } else {                            // in = a1, out = a0
-            if constexpr (T == 0) tile_mma<PAIRS, PT>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a1, st);
-            else tile_mma<PAIRS, PT>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a0, st);
+            if constexpr (T == 0) tile_mma<PAIRS, PT, -1, XS0, XS1>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a1, st);
+            else tile_mma<PAIRS, PT, -1, XS0, XS1>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a0, st);
         }
     }
     template <int L, bool GX = false>
@@ -353,8 +359,8 @@ struct Layers {
                                                  f32x16 (&acc)[2][CM], int lane, LogitAcc* lg) {
         tile<L, 0, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 1, GX>(ring, st, a0, a1, bias, acc, lane, lg);
         tile<L, 2, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 3, GX>(ring, st, a0, a1, bias, acc, lane, lg);
-        tile<L, 4>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 5>(ring, st, a0, a1, bias, acc, lane, lg);
-        tile<L, 6>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 7>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 4, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 5, GX>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 6, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 7, GX>(ring, st, a0, a1, bias, acc, lane, lg);
     }
 };
 
@@ -616,7 +622,7 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
 #pragma unroll
         for (int mi = 0; mi < CM; ++mi) { lg.goff[mi] = rs[mi].goff; lg.sum[mi] = 0.f; }
         Layers<PAIRS>::template layer<0, !kFusedLogit>(ring, st, act0, act1, lbias, acc, lane, &lg);
-        Layers<PAIRS>::template layer<1>(ring, st, act0, act1, lbias, acc, lane, &lg);
+        Layers<PAIRS>::template layer<1, !kFusedLogit>(ring, st, act0, act1, lbias, acc, lane, &lg);
         Layers<PAIRS>::template layer<2>(ring, st, act0, act1, lbias, acc, lane, &lg);
         finish_tile(7, acc[1], act1);            // layer 2 (third hidden layer) writes act1; its tile 7 sits in acc[(16 + 7) & 1] = acc[1]
         CPROBE(3);
