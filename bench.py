@@ -133,6 +133,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         tag = tag[:-4] + '_bf16'
     if tag in ('head_kv_chain_bf16', 'head_kv_chain_pairs_bf16'):   # the weights-stationary form of the 16-bit kv kernel (round 5): same work
         tag = 'head_kv_fused_bf16'
+    if tag in ('head_decode_chain_bf16', 'head_decode_chain_pairs_bf16'):   # ... and of imnet_q
+        tag = 'head_decode_fused_bf16'
     D, Dv, R = 9 * C, 10 * C, Q * J
     side = HW ** 0.5
     dense = sum(2.0 * HW * 9 * (C + C * l) * C for l in range(layers)) * blocks
@@ -183,9 +185,9 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
 
 
 def executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
-    if tag.startswith('head_kv_chain_pairs'):
+    if tag.startswith('head_kv_chain_pairs') or tag.startswith('head_decode_chain_pairs'):
         return 2.0
-    if tag.startswith('head_kv_chain'):
+    if tag.startswith('head_kv_chain') or tag.startswith('head_decode_chain'):
         return 1.0
     return _executed_ratio(tag, HW, C, precision, bf16_single)
 

@@ -49,7 +49,7 @@ class OptionsT(C.Structure):
                 ('dense_direct', C.c_int), ('csa_scores_gemm', C.c_int), ('csa_attn_tile128', C.c_int), ('query_grid_w', C.c_int), ('f16_pairs', C.c_int)]
 
 
-HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG, HEAD_TABLE_WINO2, HEAD_NO_CHAIN = 1, 2, 4, 8, 16, 32
+HEAD_STAGED, HEAD_NO_LOGIT_TABLE, HEAD_TABLE_GEMM, HEAD_WIDE_WG, HEAD_TABLE_WINO2, HEAD_NO_CHAIN, HEAD_NO_DECODE_CHAIN = 1, 2, 4, 8, 16, 32, 64
 
 
 class ConvT(C.Structure):

@@ -59,7 +59,7 @@ int launch_status(const char* what);
 // (a caller built against a later layout -- or passing garbage -- is refused instead of being half-understood).
 static inline bool options_ok(const ciaosr_options_t* o) {
     if (!o) return true;
-    return o->query_grid_w >= 0 && (o->csa_attn_tile128 == 0 || o->csa_attn_tile128 == 1) && (o->head_route & ~63) == 0 && (o->kv_rows == 0 || o->kv_rows == 32 || o->kv_rows == 64) &&
+    return o->query_grid_w >= 0 && (o->csa_attn_tile128 == 0 || o->csa_attn_tile128 == 1) && (o->head_route & ~127) == 0 && (o->kv_rows == 0 || o->kv_rows == 32 || o->kv_rows == 64) &&
            (o->decode_rows == 0 || o->decode_rows == 32 || o->decode_rows == 64) && (o->bf16_single == 0 || o->bf16_single == 1) &&
            (o->dense_direct >= 0 && o->dense_direct <= 2) && (o->csa_scores_gemm == 0 || o->csa_scores_gemm == 1) &&
            o->f16_pairs >= 0 && o->f16_pairs <= 3;

@@ -305,6 +305,12 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
             qp.b_last = mq.bias[mq.n_layers - 1];
             qp.rows_per_wg = opt ? opt->decode_rows : 0;
             qp.x_lr = x_lr_nchw; qp.coord = coord; qp.q0 = q0; qp.nq = nq; qp.H = H; qp.W = W; qp.rgb = rgb;
+            // imnet_q through the same weights-stationary form where the blob carries its stream (Dv a multiple of 128, 256-wide layers)
+            if (chained && !(route & CIAOSR_HEAD_NO_DECODE_CHAIN) && h16_ops(prec).head_decode_chain_ok(w)) {
+                const unsigned char* qblob = reinterpret_cast<const unsigned char*>(blob) + h16_ops(prec).head_kv_chain_bytes(w, lo ? 1 : 0);
+                RUN(h16_ops(prec).head_decode_chain(qp, w, qblob, lo ? 1 : 0, s));
+                continue;
+            }
             RUN(wide16 ? wide::head_decode_fused_wide(qp, wide_mode, s) : bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
             continue;
         }

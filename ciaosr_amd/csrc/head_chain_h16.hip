@@ -332,7 +332,9 @@ struct Layers {
             if (j >= 0 && j % G::SLOTS_PER_TILE == 0 && j / G::SLOTS_PER_TILE < 8) ++n;
         return n;
     }
-    template <int L, int T, bool GX = false>
+    // BX > 0: the caller issued BX vector-memory operations right in front of the chain's first slot (the decode kernel's fetch of the next
+    // pass's first Z line): younger than the pieces of the first three slots, whose waits let them stay in flight
+    template <int L, int T, bool GX = false, int BX = 0>
     static __device__ __forceinline__ void tile(lds_cptr ring, Stream& st, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
                                                 f32x16 (&acc)[2][CM], int lane, LogitAcc* lg) {
         constexpr int t_lin = 8 * L + T;                                   // tile index inside the chain's hidden stream
@@ -341,7 +343,7 @@ struct Layers {
         constexpr int PT = (T + 7) & 7;                                    // previous tile (of the previous layer when T == 0)
         // outputs of the previous tile: layer L - 1's output array when T == 0 (= this layer's input), else this layer's output array
         constexpr int first_slot = t_lin * G::SLOTS_PER_TILE;
-        constexpr int XS0 = GX ? extra(first_slot) : 0, XS1 = GX ? extra(first_slot + 1) : 0;
+        constexpr int XS0 = GX ? extra(first_slot) : (first_slot < 3 ? BX : 0), XS1 = GX ? extra(first_slot + 1) : (first_slot + 1 < 3 ? BX : 0);
         constexpr int GI = (GX && t_lin < 8) ? t_lin : -1;
         if constexpr (L == 2) {             // in = a0, out = a1; the k chain accumulates its logit here (lg->on)
             if constexpr (T == 0) tile_mma<PAIRS, PT, 0>(ring, lane, a0, c0, acc[cur], acc[cur ^ 1], a0, st, lg);
@@ -354,11 +356,11 @@ struct Layers {
             else tile_mma<PAIRS, PT, -1, XS0, XS1>(ring, lane, a1, c0, acc[cur], acc[cur ^ 1], a0, st);
         }
     }
-    template <int L, bool GX = false>
+    template <int L, bool GX = false, int BX = 0>
     static __device__ __forceinline__ void layer(lds_cptr ring, Stream& st, u32x4 (&a0)[CM][16], u32x4 (&a1)[CM][16], const LDS3 float* bias,
                                                  f32x16 (&acc)[2][CM], int lane, LogitAcc* lg) {
-        tile<L, 0, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 1, GX>(ring, st, a0, a1, bias, acc, lane, lg);
-        tile<L, 2, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 3, GX>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 0, GX, BX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 1, GX, BX>(ring, st, a0, a1, bias, acc, lane, lg);
+        tile<L, 2, GX, BX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 3, GX>(ring, st, a0, a1, bias, acc, lane, lg);
         tile<L, 4, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 5, GX>(ring, st, a0, a1, bias, acc, lane, lg);
         tile<L, 6, GX>(ring, st, a0, a1, bias, acc, lane, lg); tile<L, 7, GX>(ring, st, a0, a1, bias, acc, lane, lg);
     }
@@ -908,6 +910,210 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA of this workgroup may land after it has gone
 }
 
+
+// =================================================================================================================================
+// imnet_q in the same form: rgb = W5 relu(W4 relu(W3 relu(W2 relu(W1 z + b1) ..))) + b5 + bilinear(x_lr).  Rows are queries (256 a pass, 32 a
+// wave), the weight stream of a pass is the input layer (k-step major: the eight 32-column tiles of a k-step back to back, so that a Z
+// fragment is read once and feeds eight independent accumulators), the three hidden layers (Layers, as above) and the 3-row output layer
+// as ONE tile of hi + lo halves (the fp32 weights of the old kernels' VALU tail to 2^-22).  The Z rows of a wave are staged like the
+// value rows above: whole 128-B lines (4 k-steps) of its 32 rows by four LDS-DMA instructions into a 4-KB stage, two stages; the next
+// pass's first line is fetched under the hidden layers.  Reference: ciaosr_net.py:107-108, 221 (imnet_q + the bilinear residual).
+struct DecodeChainP {
+    FusedQP q;
+    const unsigned char* blob;      // [stream: n_slots x 16 KB]
+    unsigned blob_bytes;
+    int n_slots;                    // per pass
+    int nline;                      // 128-B lines of a Z row (Dv / 64), even
+    int n_pass;                     // passes of 256 queries
+};
+
+// input-layer fragments, k-step major: [ks][hi: 8 tiles | lo: 8 tiles (pairs)][lane][8 h16], lane (n, g) holding W[32 T + n][16 ks + 8 g + e]
+__global__ void pack_decode_in_kernel(const float* __restrict__ W, int ld, int nks, int pairs, uint4* __restrict__ out) {
+    const int per_ks = pairs ? 16 : 8;
+    const long total = (long)nks * per_ks * 64;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long f = idx >> 6;
+        const int ks = (int)(f / per_ks), r = (int)(f % per_ks), lo = r >> 3, T = r & 7;
+        const int n = 32 * T + (lane & 31), g = lane >> 5;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = W[(size_t)n * ld + 16 * ks + 8 * g + e];
+            if (lo) v[e] -= h16_lo<kF16>(to_h16<kF16>(v[e]));
+        }
+        out[idx] = make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+    }
+}
+
+// one slot (16 fragments) of the input layer: single weights = k-steps (2 n, 2 n + 1) x 8 tiles, pairs = one k-step's hi and lo x 8 tiles
+template <bool PAIRS, int EXTRA>
+__device__ __forceinline__ void decode_in_slot(lds_cptr ring, Stream& st, int lane, const u32x4& b0, const u32x4& b1, f32x16 (&acc8)[8]) {
+    lds_cptr tb = st.template begin_slot<EXTRA>(ring) + lane * 16;
+    asm volatile("" : "+v"(tb));
+    u32x4 a[3];
+    a[0] = *(const LDS3 u32x4*)(tb);
+    a[1] = *(const LDS3 u32x4*)(tb + 1024);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        if (f + 2 < 16) a[(f + 2) % 3] = *(const LDS3 u32x4*)(tb + (f + 2) * 1024);
+        acc8[f & 7] = mfma(a[f % 3], (PAIRS || f < 8) ? b0 : b1, acc8[f & 7]);
+        if (f >= 11 && f < 11 + CPW) st.piece(f - 11);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool PAIRS>
+__global__ __launch_bounds__(64 * CNW) void head_decode_chain_kernel(DecodeChainP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    static_assert(CM == 1 && CNW == 8, "eight waves, one 32-query row tile each");
+    lds_cptr ring = (lds_cptr)smem_raw;
+    LDS3 float* lbias = (LDS3 float*)((LDS3 unsigned char*)ring + CRING * CSLOT);       // [256] in, [3][256] hidden, [32] out
+    const FusedQP& q = p.q;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    for (int i = t; i < 256; i += 64 * CNW) {
+        lbias[i] = q.bias_in[i];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) lbias[256 * (l + 1) + i] = q.bias_hidden[l][i];
+    }
+    if (t < 32) lbias[1024 + t] = t < 3 ? q.b_last[t] : 0.f;
+    Stream st;
+    st.desc = i32x4{(int)(unsigned)(size_t)p.blob, (int)(((size_t)p.blob >> 32) & 0xFFFFu), (int)p.blob_bytes, 0x00020000};
+    st.lds0 = (unsigned)(size_t)(LDS3 unsigned char*)ring;
+    st.voff = (unsigned)(CPW * w) * 1024u + (unsigned)lane * 16u;
+    st.src0 = 0;
+    st.n_slots = p.n_slots;
+    const int my_passes = (p.n_pass - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    st.total = my_passes * p.n_slots;
+    st.cur = 0;
+    st.ridx = 0;
+    st.pf_dst = 0; st.pf_src = 0; st.pf_voff = kOobC;
+    // Z stages of this wave: [2][4 KB] behind the bias table
+    const LDS3 unsigned char* stages = (const LDS3 unsigned char*)(lbias + 1056) + (size_t)w * 8192;
+    const unsigned lds_stage = __builtin_amdgcn_readfirstlane((unsigned)(size_t)stages);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < CRING - 1; ++s) st.issue_whole(s);
+    const i32x4 d_z = i32x4{(int)(unsigned)(size_t)q.Z, (int)(((size_t)q.Z >> 32) & 0xFFFFu), (int)(unsigned)((size_t)q.nq * q.ldz * 2), 0x00020000};
+
+    // Z line L of the wave's 32 rows: instruction i fetches rows 8 i .. 8 i + 7 (8 lanes a row), lane position p of a row receiving source
+    // chunk p ^ ((row >> 1) & 7): the ds_read_b128 lane groups then fall on 16 different bank quads
+    auto z_offsets = [&](int pass, unsigned (&zo)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);
+            const long ql = (long)pass * 256 + w * 32 + r;
+            zo[i] = (pass < p.n_pass && ql < q.nq) ? (unsigned)(ql * q.ldz * 2) + ((unsigned)((lane & 7) ^ ((r >> 1) & 7)) << 4) : kOobC;
+        }
+    };
+    auto fetch_line = [&](const unsigned (&zo)[4], int L, int buf) {
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)L * 128u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_stage + (unsigned)buf * 4096u + (unsigned)i * 1024u);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" :: "v"(zo[i]), "s"(dst), "s"(d_z), "s"(so) : "memory");
+        }
+    };
+    // this lane's B fragment of k-step sl (0..3) of a staged line: chunk 2 sl + lh of row li
+    const LDS3 unsigned char* rd[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) rd[sl] = stages + li * 128 + ((((unsigned)(2 * sl + lh)) ^ (unsigned)((li >> 1) & 7)) << 4);
+
+    unsigned zo[4];
+    z_offsets(blockIdx.x, zo);
+    fetch_line(zo, 0, 0);
+    constexpr int NP = (PAIRS ? 3 : 1) * CPW;           // weight pieces a wave issues in a line step BEHIND its line fetch (which follows the first slot)
+
+    int pass_i = 0;
+#pragma unroll 1
+    for (int pass = blockIdx.x; pass < p.n_pass; pass += gridDim.x, ++pass_i) {
+        // ================= input layer: 8 accumulator tiles, Z streamed by lines ======================================================
+        f32x16 acc8[8];
+#pragma unroll
+        for (int T = 0; T < 8; ++T) acc8[T] = bias_frag(lbias, T, lh);
+#pragma unroll 1
+        for (int L2 = 0; L2 < p.nline; L2 += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int L = L2 + par;
+                // line L has landed: it was fetched behind the first slot of the previous line step (the first line of a pass: under the hidden
+                // layers of the pass before), and this wave has issued NP weight pieces since
+                if (L == 0 && pass_i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NP) : "memory");
+                u32x4 bz[4];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) bz[sl] = *(const LDS3 u32x4*)(rd[sl] + par * 4096);
+                // counted waits of the slots: behind slot k's pieces (issued in slot k - 3) this wave issued those of the next two slots and,
+                // except for a line step's first slot (covered by the wait above), at least the 4 instructions of one line fetch
+                if (!PAIRS) {
+                    // (the wait above is the stricter one for a line step's first slot)
+                    decode_in_slot<false, 0>(ring, st, lane, bz[0], bz[1], acc8);
+                    fetch_line(zo, L + 1, par ^ 1);           // past the row's end: out of range, zeros (the counts stay the same)
+                    decode_in_slot<false, 4>(ring, st, lane, bz[2], bz[3], acc8);
+                } else {
+                    decode_in_slot<true, 0>(ring, st, lane, bz[0], bz[0], acc8);
+                    fetch_line(zo, L + 1, par ^ 1);
+                    decode_in_slot<true, 4>(ring, st, lane, bz[1], bz[1], acc8);
+                    decode_in_slot<true, 4>(ring, st, lane, bz[2], bz[2], acc8);
+                    decode_in_slot<true, 4>(ring, st, lane, bz[3], bz[3], acc8);
+                }
+            }
+        }
+        // ================= hidden layers ================================================================================================
+        u32x4 act0[CM][16], act1[CM][16];
+        f32x16 acc[2][CM];
+#pragma unroll
+        for (int T = 0; T < 7; ++T)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) finish_quad(T, acc8[T], act0[0], qd);
+        acc[1][0] = acc8[7];                                    // (the first hidden tile finishes tile 7, as in the kv chains)
+        unsigned zn[4];
+        z_offsets(pass + (int)gridDim.x, zn);
+        fetch_line(zn, 0, 0);                                   // the next pass's first line: 4 operations in front of the hidden chain (BX)
+        LogitAcc lg;
+        lg.on = false;
+        Layers<PAIRS>::template layer<0, false, 4>(ring, st, act0, act1, lbias + 256, acc, lane, &lg);
+        Layers<PAIRS>::template layer<1>(ring, st, act0, act1, lbias + 256, acc, lane, &lg);
+        Layers<PAIRS>::template layer<2>(ring, st, act0, act1, lbias + 256, acc, lane, &lg);
+        finish_tile(7, acc[1], act1);
+        // ================= output layer: one tile, hi + lo halves of W5 ================================================================
+        const f32x16 c0 = bias_frag(lbias + 1024, 0, lh);
+        tile_mma<true, -1>(ring, lane, act1, c0, acc[0], acc[1], act0, st);
+        if (lh == 0) {
+            const long ql = (long)pass * 256 + w * 32 + li;
+            if (ql < q.nq) {
+                const long qq = q.q0 + ql;
+                float v[3] = {acc[0][0][0], acc[0][0][1], acc[0][0][2]};
+                if (q.x_lr) {
+                    const float cy = q.coord[2 * qq], cx = q.coord[2 * qq + 1];
+                    float fy = sub_rn(mul_rn(add_rn(cy, 1.0f), (float)q.H * 0.5f), 0.5f);
+                    float fx = sub_rn(mul_rn(add_rn(cx, 1.0f), (float)q.W * 0.5f), 0.5f);
+                    fy = fminf((float)(q.H - 1), fmaxf(fy, 0.f));
+                    fx = fminf((float)(q.W - 1), fmaxf(fx, 0.f));
+                    const float y0f = floorf(fy), x0f = floorf(fx);
+                    const int y0 = (int)y0f, x0 = (int)x0f;
+                    const float wy1 = fy - y0f, wy0 = (y0f + 1.f) - fy;
+                    const float wx1 = fx - x0f, wx0 = (x0f + 1.f) - fx;
+                    const int y1 = min(y0 + 1, q.H - 1), x1 = min(x0 + 1, q.W - 1);     // weights of clamped taps are 0
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float* img = q.x_lr + (size_t)c * q.H * q.W;
+                        v[c] += img[(size_t)y0 * q.W + x0] * (wx0 * wy0) + img[(size_t)y0 * q.W + x1] * (wx1 * wy0) +
+                                img[(size_t)y1 * q.W + x0] * (wx0 * wy1) + img[(size_t)y1 * q.W + x1] * (wx1 * wy1);
+                    }
+                }
+                q.rgb[qq * 3] = v[0];
+                q.rgb[qq * 3 + 1] = v[1];
+                q.rgb[qq * 3 + 2] = v[2];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zo[i] = zn[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no LDS-DMA of this workgroup may land after it has gone
+}
+
 }  // namespace chain
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
@@ -926,8 +1132,15 @@ bool head_chain_ok(const ciaosr_head_weights_t* w) {
     return lds <= 160 * 1024;
 }
 
-size_t head_chain_bytes(const ciaosr_head_weights_t* w, int pairs) {
+bool head_decode_chain_ok(const ciaosr_head_weights_t* w);
+size_t head_decode_chain_bytes(const ciaosr_head_weights_t* w, int pairs);
+int pack_head_decode_chain(const ciaosr_head_weights_t* w, int pairs, void* out, hipStream_t s);
+// bytes of the kv part of the blob (the imnet_q stream, if its shape allows one, follows it)
+size_t head_kv_chain_bytes(const ciaosr_head_weights_t* w, int pairs) {
     return 2 * (size_t)chain::CTAIL + (size_t)chain_tiles(w, pairs) * chain::CTILE * (pairs ? 2 : 1);
+}
+size_t head_chain_bytes(const ciaosr_head_weights_t* w, int pairs) {
+    return head_kv_chain_bytes(w, pairs) + head_decode_chain_bytes(w, pairs);
 }
 
 int pack_head_chain(const ciaosr_head_weights_t* w, int pairs, void* out, hipStream_t s) {
@@ -951,7 +1164,9 @@ int pack_head_chain(const ciaosr_head_weights_t* w, int pairs, void* out, hipStr
     const int n_vout = (w->v.width[4] + 31) / 32;
     hipLaunchKernelGGL(pack_chain_kernel, dim3(128), dim3(256), 0, s, w->v.weight[4], w->v.ld[4], w->v.width[4], n_vout, pairs,
                        reinterpret_cast<uint4*>(st + (size_t)tile * tile_bytes));
-    return launch_status("pack_head_chain" CIAOSR_H16_SUFFIX);
+    const int rc = launch_status("pack_head_chain" CIAOSR_H16_SUFFIX);
+    if (rc != CIAOSR_OK) return rc;
+    return pack_head_decode_chain(w, pairs, o + head_kv_chain_bytes(w, pairs), s);
 }
 
 // kp: the FusedKVP of the 128-row kernel (tables, G, Z, biases); blob: pack_head_chain's output
@@ -960,7 +1175,7 @@ int head_kv_chain_h16(const FusedKVP& kp, const ciaosr_head_weights_t* w, const 
     ChainP p;
     p.kv = kp;
     p.blob = reinterpret_cast<const unsigned char*>(blob);
-    p.blob_bytes = (unsigned)head_chain_bytes(w, pairs);
+    p.blob_bytes = (unsigned)head_kv_chain_bytes(w, pairs);
     p.n_slots = chain_tiles(w, pairs) * (pairs ? 2 : 1);
     p.n_vout = (w->v.width[4] + 31) / 32;
     p.grid_w = (grid_w > 0 && kp.nq % grid_w == 0 && kp.q0 % grid_w == 0) ? grid_w : 0;
@@ -980,6 +1195,66 @@ int head_kv_chain_h16(const FusedKVP& kp, const ciaosr_head_weights_t* w, const 
         hipLaunchKernelGGL(head_kv_chain_kernel<false>, dim3(grid), dim3(64 * CNW), lds, s, p);
     }
     return launch_status("head_kv_chain" CIAOSR_H16_SUFFIX);
+}
+
+// ---- imnet_q stream ---------------------------------------------------------------------------------------------------------------------
+bool head_decode_chain_ok(const ciaosr_head_weights_t* w) {
+    const ciaosr_mlp_t& m = w->q;
+    if (m.n_layers != 5 || m.width[4] != 3) return false;
+    for (int i = 0; i < 4; ++i)
+        if (m.width[i] != 256) return false;
+    const int Dv = (w->no_unfold ? 1 : 9) * w->channels + w->nonlocal_channels;
+    return Dv > 0 && Dv % 128 == 0;                 // whole 128-B Z lines, an even number of them
+}
+static int decode_slots(const ciaosr_head_weights_t* w, int pairs) {
+    const int Dv = (w->no_unfold ? 1 : 9) * w->channels + w->nonlocal_channels;
+    const int nks = Dv / 16;
+    return pairs ? nks + 48 + 2 : nks / 2 + 24 + 2;
+}
+size_t head_decode_chain_bytes(const ciaosr_head_weights_t* w, int pairs) {
+    return head_decode_chain_ok(w) ? (size_t)decode_slots(w, pairs) * chain::CSLOT : 0;
+}
+int pack_head_decode_chain(const ciaosr_head_weights_t* w, int pairs, void* out, hipStream_t s) {
+    using namespace chain;
+    if (!head_decode_chain_ok(w)) return CIAOSR_OK;
+    const ciaosr_mlp_t& m = w->q;
+    unsigned char* o = reinterpret_cast<unsigned char*>(out);
+    const int Dv = (w->no_unfold ? 1 : 9) * w->channels + w->nonlocal_channels;
+    const int nks = Dv / 16;
+    hipLaunchKernelGGL(pack_decode_in_kernel, dim3(256), dim3(256), 0, s, m.weight[0], m.ld[0], nks, pairs, reinterpret_cast<uint4*>(o));
+    o += (size_t)(pairs ? nks : nks / 2) * CSLOT;
+    const size_t tile_bytes = (size_t)CTILE * (pairs ? 2 : 1);
+    for (int l = 1; l <= 3; ++l) {
+        hipLaunchKernelGGL(pack_chain_kernel, dim3(64), dim3(256), 0, s, m.weight[l], m.ld[l], 256, 8, pairs, reinterpret_cast<uint4*>(o));
+        o += 8 * tile_bytes;
+    }
+    hipLaunchKernelGGL(pack_chain_kernel, dim3(8), dim3(256), 0, s, m.weight[4], m.ld[4], 3, 1, 1, reinterpret_cast<uint4*>(o));      // hi + lo always
+    return launch_status("pack_head_decode_chain" CIAOSR_H16_SUFFIX);
+}
+
+// qp: the FusedQP of the 128-row kernel; blob: pack_head_decode_chain's output
+int head_decode_chain_h16(const FusedQP& qp, const ciaosr_head_weights_t* w, const void* blob, int pairs, hipStream_t s) {
+    using namespace chain;
+    DecodeChainP p;
+    p.q = qp;
+    p.blob = reinterpret_cast<const unsigned char*>(blob);
+    p.blob_bytes = (unsigned)head_decode_chain_bytes(w, pairs);
+    p.n_slots = decode_slots(w, pairs);
+    p.nline = qp.Dv / 64;
+    p.n_pass = (qp.nq + 255) / 256;
+    const size_t lds = (size_t)CRING * CSLOT + 1056 * 4 + (size_t)CNW * 8192;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int grid = p.n_pass < cus ? p.n_pass : cus;
+    ProfScope prof(pairs ? "head_decode_chain_pairs" CIAOSR_H16_SUFFIX : "head_decode_chain" CIAOSR_H16_SUFFIX, s);
+    if (pairs) {
+        CIAOSR_BIG_LDS(head_decode_chain_kernel<true>, lds);
+        hipLaunchKernelGGL(head_decode_chain_kernel<true>, dim3(grid), dim3(64 * CNW), lds, s, p);
+    } else {
+        CIAOSR_BIG_LDS(head_decode_chain_kernel<false>, lds);
+        hipLaunchKernelGGL(head_decode_chain_kernel<false>, dim3(grid), dim3(64 * CNW), lds, s, p);
+    }
+    return launch_status("head_decode_chain" CIAOSR_H16_SUFFIX);
 }
 
 }  // namespace CIAOSR_H16_NS

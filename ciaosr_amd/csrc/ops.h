@@ -182,6 +182,9 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
     bool head_chain_ok(const ciaosr_head_weights_t* w);                                                                               \
     size_t head_chain_bytes(const ciaosr_head_weights_t* w, int pairs);                                                               \
     int pack_head_chain(const ciaosr_head_weights_t* w, int pairs, void* out, hipStream_t s);                                         \
+    bool head_decode_chain_ok(const ciaosr_head_weights_t* w);                                                                        \
+    size_t head_kv_chain_bytes(const ciaosr_head_weights_t* w, int pairs);                                                            \
+    int head_decode_chain_h16(const FusedQP& qp, const ciaosr_head_weights_t* w, const void* blob, int pairs, hipStream_t s);         \
     int head_kv_chain_h16(const FusedKVP& kp, const ciaosr_head_weights_t* w, const void* blob, int pairs, int grid_w, int* flag,     \
                           hipStream_t s);                                                                                             \
     int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual, void* P_lo);                   \
@@ -226,16 +229,21 @@ struct H16Ops {
     decltype(&b16::softmax_gemm_scratch_floats) softmax_gemm_scratch;
     decltype(&b16::head_chain_ok) head_chain_ok;
     decltype(&b16::head_kv_chain_h16) head_kv_chain;
+    decltype(&b16::head_decode_chain_ok) head_decode_chain_ok;
+    decltype(&b16::head_kv_chain_bytes) head_kv_chain_bytes;
+    decltype(&b16::head_decode_chain_h16) head_decode_chain;
 };
 inline const H16Ops& h16_ops(Prec prec) {
     static const H16Ops kB = {b16::gemm_h16_nt, b16::cast_rows_h16, b16::softmax_rows_h16, b16::head_kv_fused_h16,
                               b16::head_decode_fused_h16, b16::cast_group_h16, b16::dense_layer_h16, b16::conv1x1_h16,
                               b16::cast_many_h16, b16::rows_to_f32_h16, b16::softmax_gemm_h16_nt,
-                              b16::softmax_gemm_scratch_floats, b16::head_chain_ok, b16::head_kv_chain_h16};
+                              b16::softmax_gemm_scratch_floats, b16::head_chain_ok, b16::head_kv_chain_h16,
+                              b16::head_decode_chain_ok, b16::head_kv_chain_bytes, b16::head_decode_chain_h16};
     static const H16Ops kH = {f16::gemm_h16_nt, f16::cast_rows_h16, f16::softmax_rows_h16, f16::head_kv_fused_h16,
                               f16::head_decode_fused_h16, f16::cast_group_h16, f16::dense_layer_h16, f16::conv1x1_h16,
                               f16::cast_many_h16, f16::rows_to_f32_h16, f16::softmax_gemm_h16_nt,
-                              f16::softmax_gemm_scratch_floats, f16::head_chain_ok, f16::head_kv_chain_h16};
+                              f16::softmax_gemm_scratch_floats, f16::head_chain_ok, f16::head_kv_chain_h16,
+                              f16::head_decode_chain_ok, f16::head_kv_chain_bytes, f16::head_decode_chain_h16};
     return prec == kF16 ? kH : kB;
 }
 

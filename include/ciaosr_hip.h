@@ -75,6 +75,9 @@ int ciaosr_prof_names(char* buf /*host*/, int buflen); /* ';'-separated kernel n
                                        * (head_fused_h16.hip) even when ciaosr_head_weights_t.chain16 is given; default = the weights-stationary,
                                        * register-chained kernel (head_chain_h16.hip).  Same products, other fp32 summation order of the logit dot
                                        * product and of z; the tail term of layer 0 enters through the MFMA as hi + lo pairs */
+#define CIAOSR_HEAD_NO_DECODE_CHAIN 64 /* head_route bit 6: keep imnet_q on the 128-row kernel while phi_k / phi_v run chained (imnet_q follows the
+                                       * chained form where the blob carries its stream: Dv a multiple of 128, four 256-wide layers + the 3-row
+                                       * output layer, which then enters the MFMA as a hi + lo pair instead of an fp32 VALU tail) */
 typedef struct ciaosr_options {
     int head_route;         /* CIAOSR_HEAD_* bits; 0 = automatic */
     int csa_composed_min;   /* cs_attn: LR pixels (after padding) from which the composed fold+down tail applies;
@@ -263,7 +266,8 @@ typedef struct ciaosr_head_weights {
     /* optional (16-bit entries; hidden_list = [256] * 4 for imnet_k and imnet_v): the weight stream of the weights-stationary head kernel,
      * packed by ciaosr_pack_head_chain_bf16 / _f16 with pairs = 0 (chain16: one 16-bit weight per product) and pairs = 1 (chain16_pairs:
      * every tile followed by its rounding residuals; read by the _bf16 entry unless opt->bf16_single, by the _f16 entry with
-     * opt->f16_pairs = 1).  ciaosr_head_chain_bytes() each.  NULL = the kernels that read ciaosr_mlp_t.frag16 */
+     * opt->f16_pairs = 1).  ciaosr_head_chain_bytes() each (the stream of phi_k / phi_v, followed by imnet_q's where its shape allows one).
+     * NULL = the kernels that read ciaosr_mlp_t.frag16 */
     const void* chain16;
     const void* chain16_pairs;
 } ciaosr_head_weights_t;

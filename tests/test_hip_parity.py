@@ -438,7 +438,8 @@ def test_head_bf16_mode_full_width_vs_reference(dev, name, C, hw, precision):
     with hip_ops.profile():
         out = g.batched_predict([feat], coord, cell, options=precision).cpu()
     prof = hip_ops.profile.results()
-    assert f'head_kv_fused_{precision}' in prof and f'head_decode_fused_{precision}' in prof, sorted(prof)
+    # the chained kernels where a logit table exists (kv; imnet_q follows at C = 64), else the 128-row ones
+    assert f'head_kv_fused_{precision}' in prof and any(k.startswith('head_decode_') and k.endswith('_' + precision) for k in prof), sorted(prof)
     ref = _t(fx['out'])
     err = (out[0] - ref).abs()
     scale = ref.abs().max().item()
@@ -491,7 +492,7 @@ def test_chained_16bit_head_kernel_vs_the_128_row_kernels(dev, C, hw, target):
     The traversal hint must not change a bit: queries given as a make_coord grid (hinted, walked in 16 x 4 blocks) and as the same
     coordinates in a tensor of their own (index order) give the same output wherever both run the chained kernel."""
     from ciaosr_amd import hip_ops
-    from ciaosr_amd._lib import HEAD_NO_CHAIN
+    from ciaosr_amd._lib import HEAD_NO_CHAIN, HEAD_NO_DECODE_CHAIN
     from ciaosr_amd.coords import make_coord, make_cell
     g = _my_generator(C, (256,) * 4, seeded_head(C, 3, head_gain=2.0), dev, eval_bsize=30000)
     feat = randn((1, C) + hw, 11).to(dev)
@@ -506,12 +507,29 @@ def test_chained_16bit_head_kernel_vs_the_128_row_kernels(dev, C, hw, target):
     for prec, kw, tag in (('f16', {}, 'head_kv_chain_f16'), ('f16-pairs', {}, 'head_kv_chain_pairs_f16'), ('bf16', {}, 'head_kv_chain_pairs_bf16'),
                           ('bf16', dict(bf16_single=1), 'head_kv_chain_bf16')):
         old = g._predict([feat], own[0], own[1], 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_CHAIN, **kw)).cpu()
+        e_old = (old - fp32).abs().max().item()
+        # (imnet_q kept on the 128-row kernel here: the fallback comparison below is bitwise)
         with hip_ops.profile():
-            new = g._predict([feat], hinted[0], hinted[1], 30000, x, hip_ops.Options(prec, **kw)).cpu()
+            new = g._predict([feat], hinted[0], hinted[1], 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_DECODE_CHAIN, **kw)).cpu()
         prof = hip_ops.profile.results()
         assert tag in prof and prof[tag]['launches'] == 1, (tag, sorted(prof))
         with hip_ops.profile():
-            unhinted = g._predict([feat], own[0], own[1], 30000, x, hip_ops.Options(prec, **kw)).cpu()
+            unhinted = g._predict([feat], own[0], own[1], 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_DECODE_CHAIN, **kw)).cpu()
+        # imnet_q in the chained form too (the default where Dv is a multiple of 128: C = 64): same products, other fp32 summation orders, the
+        # 3-row output layer as a hi + lo pair on the MFMA instead of fp32 FMAs -- as close to the 128-row kernel as the kv kernels are to
+        # each other, and no further from fp32
+        with hip_ops.profile():
+            full = g._predict([feat], hinted[0], hinted[1], 30000, x, hip_ops.Options(prec, **kw)).cpu()
+        qtag = tag.replace('head_kv_chain', 'head_decode_chain')
+        if C == 64:
+            assert qtag in hip_ops.profile.results() and not any(k.startswith('head_decode_fused') for k in hip_ops.profile.results())
+            dq = (full - new).abs().max().item()
+            e_full = (full - fp32).abs().max().item()
+            print(f'    imnet_q chained vs 128-row on the same Z: {dq:.2e}; vs fp32 {e_full:.2e}')
+            assert dq < (2e-2 if prec == 'bf16' else 2e-3) * scale, (prec, dq)      # other summation orders flip 16-bit roundings of activations
+            assert e_full < 1.5 * e_old + 1e-4 * scale, (prec, e_full, e_old)
+        else:
+            assert qtag not in hip_ops.profile.results() and torch.equal(full, new)
         d, e_new, e_old = (new - old).abs().max().item(), (new - fp32).abs().max().item(), (old - fp32).abs().max().item()
         print(f'C={C} {target} {prec} {kw}: chained vs 128-row {d:.2e}; vs fp32: chained {e_new:.2e}, 128-row {e_old:.2e} (scale {scale:.2f})')
         assert torch.isfinite(new).all()
@@ -528,7 +546,7 @@ def test_chained_16bit_head_falls_back_when_a_row_tile_leaves_its_window(dev):
     behind it and gated on that flag, redoes the launch -- bitwise the HEAD_NO_CHAIN result, and finite.  (The same happens for target
     grids coarser than the LR map; those are too small to have a logit table and never reach the chained kernel.)"""
     from ciaosr_amd import hip_ops
-    from ciaosr_amd._lib import HEAD_NO_CHAIN
+    from ciaosr_amd._lib import HEAD_NO_CHAIN, HEAD_NO_DECODE_CHAIN
     from ciaosr_amd.coords import make_coord, make_cell
     g = _my_generator(64, (256,) * 4, seeded_head(64, 3, head_gain=2.0), dev, eval_bsize=30000)
     feat = randn((1, 64, 24, 32), 11).to(dev)
@@ -539,7 +557,7 @@ def test_chained_16bit_head_falls_back_when_a_row_tile_leaves_its_window(dev):
     for prec in ('f16', 'bf16'):
         old = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_CHAIN))
         with hip_ops.profile():
-            new = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec))
+            new = g._predict([feat], coord, cell, 30000, x, hip_ops.Options(prec, head_route=HEAD_NO_DECODE_CHAIN))
         prof = hip_ops.profile.results()
         chain = [k for k in prof if k.startswith('head_kv_chain')]
         fused = [k for k in prof if k.startswith('head_kv_fused')]
@@ -689,7 +707,8 @@ def test_e2e_test_cfg_precision_selects_the_16bit_kernels_vs_reference(dev, prec
         prof = hip_ops.profile.results()
     finally:
         model.test_cfg.pop('precision')
-    for tag in ('enc_dense', 'csa_attn_v', 'csa_scores', 'head_kv_fused', 'head_decode_fused'):
+    for tag in ('enc_dense', 'csa_attn_v', 'csa_scores', 'head_kv_chain' + ('_pairs' if precision == 'bf16' else ''),
+                'head_decode_chain' + ('_pairs' if precision == 'bf16' else '')):
         assert f'{tag}_{precision}' in prof, (tag, sorted(prof))
     assert model.options().precision == 'fp32'
     ref = _t(fx['out'])
@@ -1072,6 +1091,8 @@ def test_e2e_full_c3_tile_vs_reference(dev, precision):
         # the kv kernel that did the work: the chained one (its gated fallback 'head_kv_fused' + sfx is launched behind it and returns at once)
         chain = {'bf16': 'head_kv_chain_pairs_bf16', 'bf16-single': 'head_kv_chain_bf16', 'f16': 'head_kv_chain_f16', 'f16-pairs': 'head_kv_chain_pairs_f16'}[precision]
         assert chain in prof and prof[chain]['total_ms'] > 20 * prof['head_kv_fused' + sfx]['total_ms'], (chain, prof.get(chain), prof['head_kv_fused' + sfx])
+        # ... and imnet_q in the same form (C = 64: Dv = 640 is a whole number of Z line pairs)
+        assert chain.replace('head_kv_chain', 'head_decode_chain') in prof and 'head_decode_fused' + sfx not in prof, sorted(prof)
     assert out.shape == (1, 3, 768, 768)
     errs = _tile192_checks(out, fx, None)
     psnr_build = psnr_tensors(out, gt, crop_border=4)
@@ -1118,7 +1139,7 @@ def test_e2e_bf16_mode_psnr_delta_vs_gt_on_reference_golden(dev, tag, kind, scal
     """The north-star gate for the bf16 mode on the 48x48 reference vector: |PSNR(bf16 build, GT) - PSNR(reference, GT)|
     <= 0.01 dB, with the default routing at this size (bf16 head, fp32 trunk and cs_attn) AND with every bf16 kernel
     forced to engage (per-call options: halo-resident dense layers from 1 tile, composed cs_attn tail from 1 pixel)."""
-    from ciaosr_amd import hip_ops
+    from ciaosr_amd import _lib, hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     from ciaosr_amd.metrics import psnr_tensors
     fx = load_golden(tag)
@@ -1127,12 +1148,14 @@ def test_e2e_bf16_mode_psnr_delta_vs_gt_on_reference_golden(dev, tag, kind, scal
     model = model.to(dev)
     ref = _t(fx['out'])
     _, gt = synthetic_pair(48, 48, scale)
-    for opt, tags, gate in ((hip_ops.Options('bf16'), ('head_kv_fused_bf16', 'head_decode_fused_bf16'), 0.01),
+    for opt, tags, gate in ((hip_ops.Options('bf16'), ('head_kv_chain_pairs_bf16', 'head_decode_chain_pairs_bf16'), 0.01),
                             (hip_ops.Options('bf16', dense_min_tiles=1, csa_composed_min=1),
-                             ('enc_dense_bf16', 'csa_attn_v_bf16', 'head_kv_fused_bf16', 'head_decode_fused_bf16'), 0.01),
-                            (hip_ops.Options('f16'), ('head_kv_fused_f16', 'head_decode_fused_f16'), 0.01),
+                             ('enc_dense_bf16', 'csa_attn_v_bf16', 'head_kv_chain_pairs_bf16', 'head_decode_chain_pairs_bf16'), 0.01),
+                            (hip_ops.Options('bf16', head_route=_lib.HEAD_NO_CHAIN), ('head_kv_fused_bf16', 'head_decode_fused_bf16'), 0.01),
+                            (hip_ops.Options('f16'), ('head_kv_chain_f16', 'head_decode_chain_f16'), 0.01),
+                            (hip_ops.Options('f16', head_route=_lib.HEAD_NO_CHAIN), ('head_kv_fused_f16', 'head_decode_fused_f16'), 0.01),
                             (hip_ops.Options('f16', dense_min_tiles=1, csa_composed_min=1),
-                             ('enc_dense_f16', 'csa_attn_v_f16', 'head_kv_fused_f16', 'head_decode_fused_f16'), 0.01)):
+                             ('enc_dense_f16', 'csa_attn_v_f16', 'head_kv_chain_f16', 'head_decode_chain_f16'), 0.01)):
         with hip_ops.profile():
             out = model.restore(_t(fx['lq']).to(dev), options=opt).cpu()
         prof = hip_ops.profile.results()

@@ -43,12 +43,15 @@ def main():
                 model.restore(lq, hc, hl, options=old)
                 torch.cuda.synchronize()
             po = hip_ops.profile.results()
+            dec = ' '.join('%s %.3f' % (k, pr[k]['total_ms']) for k in pr if k.startswith('head_decode'))
             tag = [k for k in pr if k.startswith('head_kv_chain')]
             told = [k for k in po if k.startswith('head_kv_fused')]
             print(f'{h}x{w} x{scale} {prec:10s} chain-old {float((a - b).abs().max()):.3e}  hinted-unhinted {float((b - c).abs().max()):.3e}  '
                   f'rerun {"bitwise" if same else "DIFFERS"}  chain-fp32 {float((b - ref32).abs().max()):.3e}  old-fp32 {float((a - ref32).abs().max()):.3e}  '
                   f'{tag[0] if tag else "NO CHAIN KERNEL"} {pr[tag[0]]["total_ms"] if tag else 0:.3f} ms '
-                  f'(fallback {sum(pr[k]["total_ms"] for k in pr if k.startswith("head_kv_fused")):.3f})  old {sum(po[k]["total_ms"] for k in told):.3f} ms', flush=True)
+                  f'(fallback {sum(pr[k]["total_ms"] for k in pr if k.startswith("head_kv_fused")):.3f})  old {sum(po[k]["total_ms"] for k in told):.3f} ms  '
+                  f'decode {dec}  '
+                  f'old {sum(po[k]["total_ms"] for k in po if k.startswith("head_decode")):.3f} ms', flush=True)
 
 
 if __name__ == '__main__':

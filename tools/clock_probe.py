@@ -1,45 +1,42 @@
-"""Developer probe: shader clock (rocm-smi) sampled while the fp32 head kernel runs back to back on one 192x192 tile.
-   python tools/clock_probe.py"""
-import os, subprocess, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from bench import rdn_ciaosr
-from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
+"""Developer probe: what clock and power the GPU runs at under one kernel mix.  Loops `restore()` on a 192x192 tile in the given precision
+for SECONDS while sampling `rocm-smi` (sclk, power, temperature) once a second from a child process.
+   python tools/clock_watch.py [f16|bf16|fp32] [seconds]"""
+import os
+import subprocess
+import sys
+import time
 
-dev = torch.device('cuda:0')
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import rdn_ciaosr                              # noqa: E402
+from ciaosr_amd import hip_ops                            # noqa: E402
+from ciaosr_amd.init_utils import seeded_init_, synthetic_pair   # noqa: E402
+
+mode = sys.argv[1] if len(sys.argv) > 1 else 'f16'
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 8.0
+dev = torch.device('cuda')
 model = rdn_ciaosr(dict(scale=4, tile=192, tile_overlap=32))
-seeded_init_(model, seed=0, gain=1.0)
+seeded_init_(model, 0)
 model = model.to(dev)
 lq = synthetic_pair(192, 192, 4)[0].to(dev)
+opt = hip_ops.Options(mode)
 for _ in range(3):
-    model.restore(lq)
+    model.restore(lq, options=opt)
 torch.cuda.synchronize()
-samples = []
-stop = False
-
-
-def sampler():
-    while not stop:
-        try:
-            out = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True, text=True, timeout=10).stdout
-            samples.append([l.strip() for l in out.splitlines() if 'sclk' in l or 'Power' in l or 'fclk' in l or 'mclk' in l])
-        except Exception as e:      # noqa: BLE001
-            samples.append([repr(e)])
-        time.sleep(0.2)
-
-
-th = threading.Thread(target=sampler)
-th.start()
-t0 = time.perf_counter()
+print(subprocess.run(['rocm-smi', '--showclocks', '--showpower', '--showtemp', '--showmaxpower'], capture_output=True, text=True).stdout[-1500:], flush=True)
+t0 = time.time()
 n = 0
-while time.perf_counter() - t0 < 6.0:
-    for _ in range(10):
-        model.restore(lq)
-    torch.cuda.synchronize()
-    n += 10
-el = time.perf_counter() - t0
-stop = True
-th.join()
-print(f'{n} tiles in {el:.2f} s = {el / n * 1e3:.2f} ms/tile')
-for s in samples[:3] + samples[-3:]:
+samples = []
+while time.time() - t0 < secs:
+    for _ in range(20):
+        model.restore(lq, options=opt)
+    n += 20
+    if len(samples) < int(time.time() - t0):          # queue stays full while rocm-smi runs
+        out = subprocess.run(['rocm-smi', '--showclocks', '--showpower'], capture_output=True, text=True).stdout
+        samples.append(' | '.join(ln.strip() for ln in out.splitlines() if 'sclk' in ln or 'Power' in ln or 'mclk' in ln))
+torch.cuda.synchronize()
+dt = time.time() - t0
+print(f'{mode}: {n} tiles in {dt:.2f} s = {1e3 * dt / n:.3f} ms per tile')
+for s in samples:
     print(s)
