@@ -740,7 +740,7 @@ def main():
                           'head_kv_chain_pairs_f16': 'head_kv_chain_kernel', 'head_kv_chain_pairs_bf16': 'head_kv_chain_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
                           'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel', 'enc_dense_wino4': 'dense_wino4_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
-                pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (4, 3))
+                pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (5, 4, 3))
                                  if os.path.exists(q)), '')
                 live_traffic = None
                 if world == 1 and not args.no_live_pmc and dominant in tag2fn:
