@@ -723,7 +723,12 @@ def main():
                 # the other kernels of the step against their own rooflines (one fully profiled step); `frac` is priced on the
                 # reference's form of the contraction, `executed_frac` on the flops the kernel's MFMAs execute
                 others = {}
+                chained_kv = any(t.startswith('head_kv_chain') for t in prof_all)
                 for tag, pr in prof_all.items():
+                    if chained_kv and tag.startswith('head_kv_fused'):
+                        # the 128-row kernel launched behind the chained one, gated on its fallback flag: it returned at once (no work to price)
+                        roof['gated_fallback_ms_per_step'] = round(pr['total_ms'], 4)
+                        continue
                     ro = roofline_object(tag, pr['total_ms'], pr['launches'], Q, HW, n_tiles, args.precision, args.bf16_single)
                     if tag == dominant or not ro or pr['total_ms'] < 0.02:
                         continue
