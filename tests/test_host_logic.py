@@ -329,3 +329,36 @@ def test_built_library_has_no_crossed_packed_fp32_instruction():
     hits, n_pk, n_obj = isa_scan.scan(_lib.LIB_PATH)
     assert n_obj >= 20, n_obj                      # every translation unit was found in the fat binary
     assert not hits, hits[:5]
+
+
+def test_chained_head_blob_sizes_follow_the_documented_stream_layout():
+    """`ciaosr_head_chain_bytes` is host arithmetic (no GPU): the blob of the weights-stationary 16-bit head = two 8-KB tail blocks + the
+    phi_k / phi_v stream (24 + 24 hidden tiles + the output layer's 32-column units padded to an even count; 16 KB a tile, twice that as
+    hi + lo pairs), followed by imnet_q's stream (input layer k-step major, 24 hidden tiles, the 3-row output layer as a hi + lo tile)
+    where Dv is a multiple of 128.  C = 180 (Dv = 1800): 57 units -> 58 tiles and no imnet_q stream.  Shapes the kernels do not
+    cover give 0 (the caller then leaves `chain16` NULL and the 128-row kernels run)."""
+    from ciaosr_amd import _lib
+    lib = _lib.load()
+    dummy = ctypes.c_void_p(64)                                   # never dereferenced by the size function
+
+    def head(C, hidden=(256, 256, 256, 256), local_size=2):
+        w = _lib.HeadWeightsT()
+        w.channels, w.nonlocal_channels, w.nonlocal_max_scale, w.local_size, w.no_unfold = C, C, 4, local_size, 0
+        D, Dv = 9 * C, 10 * C
+        for m, fan, out in ((w.q, Dv, 3), (w.k, D + 4, D), (w.v, Dv + 4, Dv)):
+            m.n_layers, m.in_dim = len(hidden) + 1, fan
+            for i, wd in enumerate(tuple(hidden) + (out,)):
+                m.width[i], m.ld[i] = wd, 4 * ((([fan] + list(hidden))[i] + 3) // 4)
+                m.weight[i], m.bias[i] = dummy, dummy
+        return w
+
+    KB = 1024
+    w = head(64)
+    kv, q = 16 * KB + (48 + 20) * 16 * KB, (640 // 16 // 2 + 24 + 2) * 16 * KB
+    assert lib.ciaosr_head_chain_bytes(ctypes.byref(w), 0) == kv + q
+    kv2, q2 = 16 * KB + (48 + 20) * 32 * KB, (640 // 16 + 48 + 2) * 16 * KB
+    assert lib.ciaosr_head_chain_bytes(ctypes.byref(w), 1) == kv2 + q2
+    w = head(180)
+    assert lib.ciaosr_head_chain_bytes(ctypes.byref(w), 0) == 16 * KB + (48 + 58) * 16 * KB           # 57 units padded, no imnet_q stream
+    assert lib.ciaosr_head_chain_bytes(ctypes.byref(head(64, hidden=(256, 256, 128, 256))), 0) == 0
+    assert lib.ciaosr_head_chain_bytes(ctypes.byref(head(64, local_size=3)), 0) == 0
