@@ -218,6 +218,26 @@ def _executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     return 1.0
 
 
+_TAG2FN_16 = {'head_kv_chain': 'head_kv_chain_kernel', 'head_decode_chain': 'head_decode_chain_kernel', 'head_kv_fused': 'head_kv_fused',
+              'head_decode_fused': 'head_decode_fused', 'enc_dense': 'dense_h16'}
+
+
+def offline_traffic(tag, precision):
+    """(bytes per launch, source) of a 16-bit kernel from profiles/r5_c3tile_<precision>_pmc_hbm_traffic.json (tools/pmc_summary.py over two
+    rocprofv3 --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
+    prec = {'f16-pairs': 'f16_pairs', 'f16x3-fast': 'f16x3_fast'}.get(precision, precision)
+    path = os.path.join(REPO, 'profiles', f'r5_c3tile_{prec}_pmc_hbm_traffic.json')
+    fn = next((v for k, v in _TAG2FN_16.items() if tag.startswith(k)), None)
+    if not fn or not os.path.exists(path):
+        return None
+    hits = [v for k, v in json.load(open(path)).items() if fn in k]
+    if not hits:
+        return None
+    n_l = sum(h['launches'] for h in hits)
+    return (round(sum(h['hbm_bytes_per_launch'] * h['launches'] for h in hits) / max(n_l, 1)),
+            f'offline: rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE of the same kernel on one 192x192 tile, profiles/{os.path.basename(path)}')
+
+
 def roofline_object(tag, total_ms, launches, Q, HW, n_tiles, precision='fp32', bf16_single=False, C=64):
     """The `roofline` entry of one kernel tag from its HIP-event time: algorithmic work / time against the gfx950 peak, with the
     executed-work twin (`executed_frac` <= 1 is the matrix pipe's share; `frac` may exceed 1 for Winograd / box-sum kernels)."""
@@ -756,6 +776,8 @@ def main():
                     roof['traffic_source'] = (f'live: bytes per launch of {tag2fn[dominant]} from two rocprofv3 --pmc child passes (FETCH_SIZE x2 '
                                               f'gfx950 correction + WRITE_SIZE, KiB units) of this script on one {tile_lr}x{tile_lr} tile, '
                                               f'{live_traffic[1]} launches')
+                elif args.precision != 'fp32' and offline_traffic(dominant, args.precision):
+                    roof['traffic'], roof['traffic_source'] = offline_traffic(dominant, args.precision)
                 elif args.precision == 'fp32' and os.path.exists(pmc_path) and dominant in tag2fn:
                     hits = [v for k, v in json.load(open(pmc_path)).items() if tag2fn[dominant] in k]
                     if hits:
@@ -839,6 +861,10 @@ def main():
                     return None
                 dom = max(pr, key=lambda k_: pr[k_]['total_ms'])
                 ro = roofline_object(dom, pr[dom]['total_ms'], pr[dom]['launches'], Q, HW, n_t, precision)
+                if ro:      # HBM bytes per launch of that kernel: offline, from the round's committed --pmc passes of this precision at the C3 tile
+                    tr = offline_traffic(dom, precision)
+                    if tr:
+                        ro['traffic'], ro['traffic_source'] = tr
                 if ro:
                     ro.update(kernel=dom, avg_launch_ms=round(pr[dom]['avg_ms'], 5), launches=pr[dom]['launches'],
                               share_of_step=round(pr[dom]['total_ms'] / max(sum(v['total_ms'] for v in pr.values()), 1e-9), 3),
