@@ -5,18 +5,23 @@
 // Why.  The 128-row kernels stream every layer's weight fragments from L2 into registers per 128 rows and sit on the L2 -> CU
 // delivery limit (21 B/clk per CU, tools/ubench/l2_stream.hip): MFMA-busy 0.46.  Here the weights go through LDS and the
 // activations never leave the register file:
-//   * ONE persistent workgroup of 4 waves per CU, one wave per SIMD (512 registers each).  A wave owns CM = 2 row tiles of 32
-//     (query, key sample) rows for ALL 256 columns of a layer.
+//   * ONE persistent workgroup of 8 waves per CU, two per SIMD.  A wave owns ONE row tile of 32 (query, key sample) rows for ALL
+//     256 columns of a layer (CM = 1; the 4-wave / two-tiles-per-wave form measured 14 % slower: a lone wave per SIMD has nobody to
+//     cover its epilogue VALU and DMA issue).
 //   * Swapped MFMA operands (weights = A, activations = B).  The accumulator tile of output columns 32T .. 32T+31 of layer l is,
 //     after relu + cvt_pk, exactly two B-operand fragments (k-steps 2T, 2T+1) of layer l + 1 -- lane (m, g) holds columns
 //     16 s + 8 (e >> 2) + 4 g + (e & 3), and the weight fragments are packed with the same k permutation (pack_chain_kernel) -- so
 //     hidden activations are chained register to register: no LDS round trip, no barrier between layers.
 //   * The weight stream of a pass (3 + 3 hidden layers, the 9C+Cn-column output layer of imnet_v: 68 tiles of 16 KB at C = 64) is
-//     DMA'd (buffer_load ... lds, 1 KB per wave instruction, issued one at a time behind MFMAs) into a ring of four 32-KB slots, three
-//     slots ahead of its use; every wave brings a quarter of each slot and reads all of it: one 1-KB ds_read_b128 feeds CM MFMAs.
-//     128 KB per 256 rows and layer = 12-16 B/clk per CU at the full MFMA rate, inside the 21 the L2 delivers, and the same
-//     stream per row as the 256-row kernel -- but the operand latency is the LDS's, there are no activation stores, and the epilogue
-//     of a tile (relu, convert) runs in the shadow of the next tile's MFMAs.
+//     DMA'd (buffer_load ... lds, 1 KB per wave instruction, issued one at a time behind MFMAs) into a ring of four 16-KB slots, three
+//     slots ahead of its use; every wave brings an eighth of each slot and reads all of it.  One barrier per slot, in front of it a
+//     COUNTED s_waitcnt vmcnt: vmcnt retires in order, so "at most N outstanding" means "everything older than the youngest N has
+//     landed"; N = the vector-memory operations this wave is KNOWN to have issued behind the slot's pieces (every such operation of
+//     the kernels is an asm statement; hipcc's own loads only make a wait conservative).  Too small a count waits longer, too large
+//     a count reads a slot before it landed: each count below carries its derivation.
+//   * Gathers (table rows, value rows, logit-table rows, imnet_q's Z rows) are staged as WHOLE 128-B lines of small per-tile windows
+//     by LDS-DMA into per-wave stages (8 KB a wave), chunk-swizzled on the source side so that the ds_read_b128 lane groups are
+//     conflict-free: a 16-B-per-lane gather costs the CU's vector L1 a tag lookup per (lane pair, line) and bounded the first cut.
 //   * layer 0 of imnet_k / imnet_v comes from the hoisted tables (head.hip): the table row of the key pixel is loaded straight into
 //     the accumulator layout as the C operand of ONE K = 16 MFMA that adds W1[:, tail] . (rel_y, rel_x, scale_y, scale_x), both
 //     factors as hi + lo pairs (all four cross terms in the 16 k slots): the fp32 tail term of the old kernels to ~2^-17.
