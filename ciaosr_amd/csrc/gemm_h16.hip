@@ -298,6 +298,118 @@ __global__ __launch_bounds__(256, 2) void gemm_h16_kernel(Gemm16P p) {
     else store_tile<MT>(p, acc, m0, n0, wm, wn, li, lh);
 }
 
+// ---- the wide kernel: one 64 MT x 256 tile per workgroup of EIGHT waves, one workgroup per CU (round 5) --------------------------------------
+// The 256 x 128 / 192 x 128 kernel above is bound by the L2 -> CU operand stream on a big plain GEMM: attn.V of cs_attn at the C3 tile
+// (36864 x 1024 x 9216) moves 20 KB per k-tile and workgroup = 8.85 GB per launch, 0.69 ms at the 12.9 TB/s the L2 delivers chip-wide
+// (tools/ubench/l2_stream.hip) against 0.28 ms of MFMA issue: measured 0.79 ms.  A 192 x 256 tile moves 28 KB per k-tile for twice the
+// MFMAs: 6.2 GB per launch, and 192 x 4 = 768 workgroups are exactly three rounds of 256 CUs.  Eight waves in a 2 x 4 grid, each the
+// same MT x 2 MFMA tiles and the same k order per output element as above (bitwise the same result); stages of 28 slices of 1 KB + 4
+// padding slices (every wave issues FOUR slices per stage: uniform counted waits), four stages, three k-tiles in flight.
+constexpr int WN = 256;                                   // columns of the wide tile
+constexpr int WNS = 4;                                    // stages
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_h16_wide_kernel(Gemm16P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds16[];      // [WNS] x { A [GM_][GRS], B [WN][GRS], 4 KB of padding slices }
+    constexpr int GM_ = 64 * MT;
+    constexpr int GA_T = GM_ * GRS;
+    constexpr int NSL = (GM_ + WN) / 16;                   // real 16-row slices per stage (28 at MT = 3)
+    static_assert(NSL <= 32 && GM_ % 16 == 0, "four slices per wave");
+    constexpr int STG = 32 * 1024;                         // 32 slices
+    const int bid = blockIdx.x;
+    const int q8 = p.n_wg >> 3, r8 = p.n_wg & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int m0 = (lid / p.tiles_n) * GM_, n0 = (lid % p.tiles_n) * WN;
+
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = w >> 2, wn = w & 3, li = lane & 31, lh = lane >> 5;
+    const int rl = lane >> 2, pc = lane & 3;
+    // slice i = w + 8 s of a stage: rows 16 i .. 16 i + 15 of [A | B | padding]
+    unsigned off[4];
+    bool is_b[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int i = w + 8 * s, row = 16 * i + rl;
+        const int part = pc ^ ((row >> 2) & 3);
+        if (i < GM_ / 16) {
+            const int gm = m0 + row;
+            off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 2u + (unsigned)part * 16u : kOob16;
+            is_b[s] = false;
+        } else if (i < NSL) {
+            const int gn = n0 + row - GM_;
+            off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 2u + (unsigned)part * 16u : kOob16;
+            is_b[s] = true;
+        } else {
+            off[s] = kOob16;                               // padding slice: zeros into the stage's last 4 KB
+            is_b[s] = false;
+        }
+    }
+    const int nk = (p.K + GK - 1) / GK;
+    const i32x4 da = {(int)(unsigned)(size_t)p.A, (int)(((size_t)p.A >> 32) & 0xFFFFu), (int)p.a_bytes, 0x00020000};
+    const i32x4 db = {(int)(unsigned)(size_t)p.B, (int)(((size_t)p.B >> 32) & 0xFFFFu), (int)p.b_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds16;
+    auto dma = [&](const i32x4& desc, unsigned lds_dst, unsigned voff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(desc) : "memory");
+    };
+    auto issue = [&](int kt, int buf) {
+        const int k0 = kt * GK;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int i = w + 8 * s;
+            const int part = pc ^ (((16 * i + rl) >> 2) & 3);
+            const bool ok = off[s] != kOob16 && k0 + part * 8 < p.K;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * STG) + (unsigned)i * 1024u);
+            dma(is_b[s] ? db : da, dst, ok ? off[s] + (unsigned)k0 * 2u : kOob16);
+        }
+    };
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+#pragma unroll
+    for (int k = 0; k < WNS - 1; ++k)
+        if (k < nk) issue(k, k);
+    const int lswz = (li >> 2) & 3;
+    const int a_row = (32 * MT * wm + li) * GRS, b_row = GA_T + (64 * wn + li) * GRS;
+    int buf = 0;
+#pragma unroll 1
+    for (int k = 0; k < nk; ++k) {
+        // stage k has landed once at most the 4 slices each of the stages behind it that this wave has requested are outstanding
+        const int behind = nk - 1 - k < WNS - 2 ? nk - 1 - k : WNS - 2;
+        if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // every wave's slices of stage k are in LDS; everyone is done reading stage k - 1
+        if (k + WNS - 1 < nk) issue(k + WNS - 1, (buf + WNS - 1) & (WNS - 1));         // the buffer stage k - 1 used
+        const unsigned char* st = lds16 + buf * STG;
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            const int co = ((2 * ks + lh) ^ lswz) * 16;
+            uint4 fb[2], fa[MT];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) fb[nt] = *reinterpret_cast<const uint4*>(st + b_row + nt * 32 * GRS + co);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const uint4*>(st + a_row + mt * 32 * GRS + co);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt][nt] = mfma_h16<kF16>(fb[nt], fa[mt], acc[mt][nt]);
+        }
+        buf = (buf + 1) & (WNS - 1);
+    }
+    // store_tile's column arithmetic is 64 wn + ...: the four wave columns of the wide tile need nothing else
+    store_tile<MT>(p, acc, m0, n0, wm, wn, li, lh);
+}
+static_assert((WNS & (WNS - 1)) == 0, "stage index arithmetic");
+
 // fp32 rows -> bf16 rows (first `cols` columns, cols % 4 == 0); pad columns [cols, ld_dst) are zeroed
 __global__ void cast_rows_h16_kernel(const float* __restrict__ src, int ld_src, unsigned short* __restrict__ dst, int ld_dst,
                                       long rows, int cols) {
@@ -403,6 +515,17 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     p.tiles_n = ceil_div(N, GN);
     ProfScope prof(tag ? tag : "gemm" CIAOSR_H16_SUFFIX, s);
+    // big plain GEMMs (the operand stream from L2 bounds the narrow tile): 192 x 256 tiles, eight waves, where they fill the chip
+    const long wide_tiles = (long)ceil_div(M, 192) * ceil_div(N, WN);
+    static const bool narrow_only = getenv("CIAOSR_GEMM16_NARROW") != nullptr;          // developer A/B switch
+    if (N % WN == 0 && K >= 512 && wide_tiles >= 256 && !narrow_only) {
+        p.tiles_n = N / WN;
+        p.n_wg = (int)wide_tiles;
+        const size_t lds = (size_t)WNS * 32 * 1024;
+        CIAOSR_BIG_LDS((gemm_h16_wide_kernel<3>), lds);
+        hipLaunchKernelGGL((gemm_h16_wide_kernel<3>), dim3(p.n_wg), dim3(512), lds, s, p);
+        return launch_status("gemm_wide" CIAOSR_H16_SUFFIX);
+    }
     const int rc = launch_gemm16<0>(p, pick_mt(M, p.tiles_n), s);
     if (rc != CIAOSR_OK) return rc;
     return launch_status("gemm" CIAOSR_H16_SUFFIX);
