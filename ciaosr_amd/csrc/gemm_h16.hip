@@ -518,7 +518,8 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     // big plain GEMMs (the operand stream from L2 bounds the narrow tile): 192 x 256 tiles, eight waves, where they fill the chip
     const long wide_tiles = (long)ceil_div(M, 192) * ceil_div(N, WN);
     static const bool narrow_only = getenv("CIAOSR_GEMM16_NARROW") != nullptr;          // developer A/B switch
-    if (N % WN == 0 && K >= 512 && wide_tiles >= 256 && !narrow_only) {
+    // (deep K only: at K = 576 -- the logit table's slices -- one workgroup per CU hides its 18 k-tiles' prologue worse than two: 45 vs 39 us)
+    if (N % WN == 0 && K >= 2048 && wide_tiles >= 256 && !narrow_only) {
         p.tiles_n = N / WN;
         p.n_wg = (int)wide_tiles;
         const size_t lds = (size_t)WNS * 32 * 1024;
