@@ -634,6 +634,101 @@ __global__ __launch_bounds__(256, 2) void conv1x1_skinny_h16_kernel(Skinny16P p)
         }
 }
 
+// Round 5: the same kernel with the A tile fetched as WHOLE 128-B lines.  Above, a load instruction covers 32 rows x 32 B: the CU's vector
+// L1 looks up 32 lines per instruction and uses a quarter of each (the pattern that bounded the first cut of the chained head kernel,
+// DESIGN 4.3e).  Here instruction j of line L covers rows 8 j .. 8 j + 7 whole (8 lanes a row, 16 B each): a quarter of the tag lookups
+// for the same bytes, all K / 64 x 4 loads of the tile still in flight at once (registers), and the MFMA operand layout comes out of a
+// per-wave 4-KB LDS transpose per line (ds_write_b128 of whole rows, chunk-swizzled; ds_read_b128 as the decode kernel reads its Z
+// lines).  Eight waves per workgroup share ONE copy of the weights (138 KB of LDS, one workgroup per CU).  K a multiple of 64.
+__global__ __launch_bounds__(512) void conv1x1_lines_h16_kernel(Skinny16P p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wl[];      // [64][wpitch] weights, then [8 waves][2][4 KB] transpose buffers
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int rt = blockIdx.x * 8 + w;                                      // 32-row tile of this wave
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.A), 0, p.a_bytes, 0x00020000);
+    constexpr int NL = SK_KS / 4;                                           // 128-B lines of a row (9 at K = 576)
+    const int nl = p.nks >> 2;
+    i32x4 ld[NL][4];
+    {
+        const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+        for (int L = 0; L < NL; ++L)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = rt * 32 + 8 * j + rr;
+                const bool ok = r < p.M && L < nl;
+                ld[L][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_a, ok ? (int)((unsigned)r * (unsigned)p.lda * 2u + (unsigned)L * 128u + (unsigned)c * 16u) : (int)kOob16, 0, 0);
+            }
+    }
+    const int cpr = p.K >> 3;                                               // chunks per row
+    for (int c = t; c < SK_N * cpr; c += 512) {
+        const int r = c / cpr, k8 = c - r * cpr;
+        *reinterpret_cast<uint4*>(wl + r * p.wpitch + k8 * 16) = *reinterpret_cast<const uint4*>(p.W + (size_t)r * p.ldw + k8 * 8);
+    }
+    __syncthreads();
+    unsigned char* tb = wl + SK_N * p.wpitch + w * 8192;                    // this wave's two 4-KB line buffers: [32 rows][128 B], swizzled
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nt][e] = 0.f;
+    const unsigned char* wrow = wl + li * p.wpitch + lh * 16;
+    // writer: lane -> (row 8 j + lane / 8, chunk lane % 8) at position chunk ^ ((row >> 1) & 7); reader: lane (li, lh), k-step sl -> chunk 2 sl + lh
+    const int wr_r = lane >> 3, wr_c = lane & 7;
+#pragma unroll
+    for (int L = 0; L < NL; ++L) {
+        if (L < nl) {
+            unsigned char* buf = tb + (L & 1) * 4096;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 8 * j + wr_r;
+                *reinterpret_cast<i32x4*>(buf + r * 128 + ((wr_c ^ ((r >> 1) & 7)) << 4)) = ld[L][j];
+            }
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const i32x4 av = *reinterpret_cast<const i32x4*>(buf + li * 128 + (((2 * sl + lh) ^ ((li >> 1) & 7)) << 4));
+                const uint4 a = make_uint4((unsigned)av.x, (unsigned)av.y, (unsigned)av.z, (unsigned)av.w);
+                const int ks = 4 * L + sl;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint4 wf = *reinterpret_cast<const uint4*>(wrow + nt * 32 * p.wpitch + ks * 32);
+                    acc[nt] = mfma_h16<kF16>(wf, a, acc[nt]);
+                }
+            }
+        }
+    }
+    // Epilogue through the same 8 KB of LDS: the accumulators (lane = row, 4 columns per quad) are written as a [32][64] fp32 tile, chunk-
+    // swizzled, and read back row-major -- lane -> (row 4 j + lane / 16, columns 4 (lane % 16) ..) -- so that the residual loads and the
+    // stores cover whole 256-B rows (4 rows per instruction) instead of 32 B of 32 different rows.  Same sums in the same order.
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n4 = 8 * nt + 2 * q + lh;
+            *reinterpret_cast<float4*>(tb + li * 256 + ((n4 ^ (li & 15)) << 4)) =
+                make_float4(acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]);
+        }
+    const int er = lane >> 4, ec = lane & 15;
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + 4 * ec);
+    float4 rq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int gr = rt * 32 + 4 * j + er;
+        rq[j] = (p.res && gr < p.M) ? *reinterpret_cast<const float4*>(p.res + (size_t)gr * p.ldres + 4 * ec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int r = 4 * j + er, gr = rt * 32 + r;
+        const float4 a = *reinterpret_cast<const float4*>(tb + r * 256 + ((ec ^ (r & 15)) << 4));
+        float v0 = a.x + b.x, v1 = a.y + b.y, v2 = a.z + b.z, v3 = a.w + b.w;
+        if (p.res) { v0 += rq[j].x; v1 += rq[j].y; v2 += rq[j].z; v3 += rq[j].w; }
+        if (gr < p.M) {
+            *reinterpret_cast<float4*>(p.out + (size_t)gr * p.ldo + 4 * ec) = make_float4(v0, v1, v2, v3);
+            if (p.out2) *reinterpret_cast<float4*>(p.out2 + (size_t)gr * p.ldo2 + 4 * ec) = make_float4(v0, v1, v2, v3);
+            if (p.out16) *reinterpret_cast<uint2*>(p.out16 + (size_t)gr * p.ldo16 + 4 * ec) = pack_h16x4<kF16>(v0, v1, v2, v3);
+        }
+    }
+}
+
 // 1x1 convolution of a 16-bit channels-last map (the RDB's local feature fusion, mmedit RDB.lff called from
 // ciaosr_net.py:337): out[m][n] = sum_k A[m][k] W16[n][k] + bias[n] + res[m][n], N % 4 == 0, written as fp32 to `out` (and `out2`
 // when given) and as 16-bit to `out16` when given (the next block's input group, which makes its cast launch unnecessary).
@@ -651,8 +746,15 @@ int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int
         q.out = out; q.ldo = ldo; q.out2 = out2; q.ldo2 = ldo2; q.out16 = out16; q.ldo16 = ldo16;
         q.M = M; q.K = K; q.nks = K >> 4; q.wpitch = K * 2 + 16;
         const size_t lds = (size_t)SK_N * q.wpitch;
-        CIAOSR_BIG_LDS(conv1x1_skinny_h16_kernel, lds);
         ProfScope prof(tag, s);
+        static const bool quarter_lines = getenv("CIAOSR_CONV1X1_QUARTER_LINES") != nullptr;       // developer A/B switch: the round-3 kernel
+        if ((K & 63) == 0 && !quarter_lines) {
+            const size_t lds8 = lds + 8 * 8192;
+            CIAOSR_BIG_LDS(conv1x1_lines_h16_kernel, lds8);
+            hipLaunchKernelGGL(conv1x1_lines_h16_kernel, dim3(ceil_div(M, 256)), dim3(512), lds8, s, q);
+            return launch_status("conv1x1_lines" CIAOSR_H16_SUFFIX);
+        }
+        CIAOSR_BIG_LDS(conv1x1_skinny_h16_kernel, lds);
         hipLaunchKernelGGL(conv1x1_skinny_h16_kernel, dim3(ceil_div(M, 128)), dim3(256), lds, s, q);
         return launch_status("conv1x1_skinny" CIAOSR_H16_SUFFIX);
     }
