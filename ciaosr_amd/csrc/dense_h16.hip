@@ -229,8 +229,10 @@ __global__ __launch_bounds__(256) void dense_h16_kernel(DenseH16P p) {
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < DMT; ++u) {
-            const int unit = t + 256 * u;                 // (r, q, lane)
-            const int ul = unit & 63, q = (unit >> 6) & 3, r = unit >> 8;
+            // unit = (pixel, 4-channel group): the eight lanes of a pixel write the 128 B (fp32) / 64 B (16-bit) of its 32 channels of this
+            // pass -- whole lines, 8 pixels per store instruction instead of 32 pixels x 32 B (see the dma kernel below)
+            const int unit = t + 256 * u;
+            const int pidx = unit >> 3, oct = unit & 7, q = oct >> 1, r = pidx >> 5, ul = ((oct & 1) << 5) | (pidx & 31);
             float4 v = red[((0 * DMT + r) * 4 + q) * 64 + ul];
 #pragma unroll
             for (int ww = 1; ww < 4; ++ww) {
@@ -434,9 +436,12 @@ __global__ __launch_bounds__(256, 2) void dense_h16_dma_kernel(DenseH16P p) {
             __syncthreads();
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
-                const int unit = t + 256 * u;             // (r, q2, lane), 640 units
+                // unit = (pixel idx, channel quad): the four lanes of a pixel write 64 B (fp32) / 32 B (16-bit) of ITS row, so a store
+                // instruction covers 16 pixels instead of 32 (the lane = pixel order of the accumulators put 32 pixels x 32 B -- 32
+                // quarter-used lines -- into every instruction: the vector L1's tag rate)
+                const int unit = t + 256 * u;             // 640 units
                 if (unit < DMT * 2 * 64) {
-                    const int ul = unit & 63, q2 = (unit >> 6) & 1, r = unit >> 7;
+                    const int pidx = unit >> 2, quad = unit & 3, q2 = quad >> 1, r = pidx >> 5, ul = ((quad & 1) << 5) | (pidx & 31);
                     float4 v = red[((0 * DMT + r) * 2 + q2) * 64 + ul];
 #pragma unroll
                     for (int ww = 1; ww < 4; ++ww) {
