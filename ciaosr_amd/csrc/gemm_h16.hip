@@ -405,6 +405,34 @@ __global__ __launch_bounds__(512) void gemm_h16_wide_kernel(Gemm16P p) {
         }
         buf = (buf + 1) & (WNS - 1);
     }
+    // Plain fp32 output (what the launcher sends here): the tile leaves in WHOLE 128-B lines.  store_tile writes 16 B per lane for 32
+    // different rows per instruction (lane = output row in the accumulator layout); here each wave turns its 32 MT x 32 column halves
+    // around in 4 MT KB of the (now idle) stage buffers -- ds_write_b128 in the accumulator layout, chunk-swizzled, ds_read_b128 row-major
+    // -- and a store instruction covers 8 rows x 128 B.
+    if (!p.c_bf16 && !p.bias && p.alpha == 1.f && (p.ldc & 3) == 0) {
+        __syncthreads();                                   // every wave is done with the last stage
+        unsigned char* ot = lds16 + w * (32 * MT * 128);
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 32 * mt + li, n4 = 2 * q + lh;
+                    *reinterpret_cast<float4*>(ot + r * 128 + ((n4 ^ (r & 7)) << 4)) =
+                        make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
+                }
+            const int rr = lane >> 3, c = lane & 7;
+#pragma unroll
+            for (int j = 0; j < 4 * MT; ++j) {
+                const int r = 8 * j + rr, m = m0 + 32 * MT * wm + r, n = n0 + 64 * wn + 32 * nt + 4 * c;
+                const float4 v = *reinterpret_cast<const float4*>(ot + r * 128 + ((c ^ (r & 7)) << 4));
+                if (m < p.M && n < p.N) *reinterpret_cast<float4*>(C + (size_t)m * p.ldc + n) = v;
+            }
+        }
+        return;
+    }
     // store_tile's column arithmetic is 64 wn + ...: the four wave columns of the wide tile need nothing else
     store_tile<MT>(p, acc, m0, n0, wm, wn, li, lh);
 }
