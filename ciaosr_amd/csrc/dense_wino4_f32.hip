@@ -396,7 +396,6 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
         const unsigned o_img = TABLE ? (unsigned)img * p.out_img_bytes : img_off;
         const unsigned o_ld = TABLE ? (unsigned)p.ld_out : (unsigned)p.ldx;
         const int o_col = TABLE ? 64 * (int)blockIdx.z : p.col_out;
-        const int tyw = li >> 3, txw = li & 7;
         float4 bias4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) bias4[q] = TABLE ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
@@ -411,9 +410,12 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[(it + 1) & 1][q] = xch[((pw * 8 + it + 1) * 4 + q) * 64 + lane];
             }
-            const int y = ty0 + 4 * tyw + 2 * h + yy, xx = tx0 + 4 * txw + x;
-            const bool ok = y < p.H && xx < p.W;
-            const unsigned pix = o_img + (unsigned)(y * p.W + xx) * o_ld * 4u + (unsigned)(o_col + 32 * nt + 4 * lh) * 4u;
+            // The values of this (yy, x) -- one pixel of each of the wave's 32 tiles, 32 channels = 128 B a pixel -- leave in WHOLE lines:
+            // written in the accumulator layout (lane = tile) a store instruction covered 32 pixels x 32 B, 32 quarter-used lines (the
+            // vector L1's tag rate: the store loop was ~19 % of the kernel over a block's eight layers).  They are turned around in the
+            // 4 KB of the partner's exchange slot `it`, whose values this wave took into registers an iteration ago: ds_write_b128 at
+            // (tile li, chunk 2 q + lh), chunk-swizzled, ds_read_b128 as (tile 8 j + lane / 8, chunk lane % 8) -> 8 pixels x 128 B a store.
+            unsigned char* tb = reinterpret_cast<unsigned char*>(xch + ((pw * 8 + it) * 4) * 64);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4 ov = o[it & 1][q];
@@ -426,9 +428,20 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
                     v.z = fmaxf(own[q][yy][x][2] + ov.z + bias4[q].z, 0.f);
                     v.w = fmaxf(own[q][yy][x][3] + ov.w + bias4[q].w, 0.f);
                 }
+                *reinterpret_cast<float4*>(tb + li * 128 + (((2 * q + lh) ^ (li & 7)) << 4)) = v;
+            }
+            const int sr = lane >> 3, sc = lane & 7;
+            const int xx = tx0 + 4 * sr + x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int tl = 8 * j + sr;                                    // tile (tyw = j, txw = sr)
+                const float4 v = *reinterpret_cast<const float4*>(tb + tl * 128 + ((sc ^ (tl & 7)) << 4));
+                const int y = ty0 + 4 * j + 2 * h + yy;
+                const bool ok = y < p.H && xx < p.W;
+                const unsigned pix = o_img + (unsigned)(y * p.W + xx) * o_ld * 4u + (unsigned)(o_col + 32 * nt + 4 * sc) * 4u;
                 i32x4 iv;
                 iv.x = __float_as_int(v.x); iv.y = __float_as_int(v.y); iv.z = __float_as_int(v.z); iv.w = __float_as_int(v.w);
-                __builtin_amdgcn_raw_buffer_store_b128(iv, ors, (int)(ok ? pix + (unsigned)q * 32u : kOobW4), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(iv, ors, (int)(ok ? pix : kOobW4), 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
