@@ -848,6 +848,40 @@ def main():
                     gbs = wk[0] / (st[tag]['total_ms'] * 1e-3) / 1e9
                     hb[tag] = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
                                    frac=round(gbs / PEAK_HBM_GBS, 4), ms_per_tile=round(st[tag]['total_ms'], 4))
+            # K4 with 16-bit wk / wv / z (ciaosr_local_attention_bf16, SURVEY 8(d): 11 056 B per query): the kernel alone on one staged chunk's
+            # worth of synthetic operands (the staged route itself stays fp32)
+            try:
+                Qc = 30000
+                g_ = torch.Generator(device='cpu').manual_seed(5)
+                U_ = torch.randn(HW, 10 * 64, generator=g_).to(dev)
+                # the indices of a real chunk: the first 30 000 queries of the tile's x4 target grid (neighbouring queries share LR pixels)
+                side_ = int(round(HW ** 0.5))
+                cc_, cl_ = hip_ops.make_coord_cell(side_ * 4, side_ * 4, dev)
+                qi_, ki_, _ = hip_ops.head_indices(cc_[:Qc].contiguous(), cl_[:Qc].contiguous(), side_, side_, want_rel=False)
+                wk_ = torch.randn(Qc * 4, 576, generator=g_).to(dev).to(torch.bfloat16)
+                wv_ = torch.randn(Qc * 4, 640, generator=g_).to(dev).to(torch.bfloat16)
+                for _ in range(2):
+                    hip_ops.local_attention_16(U_, 64, 64, qi_, ki_, wk_, wv_)
+                with hip_ops.profile():
+                    for _ in range(5):
+                        hip_ops.local_attention_16(U_, 64, 64, qi_, ki_, wk_, wv_)
+                    torch.cuda.synchronize(dev)
+                t16 = hip_ops.profile.results()['local_attention_bf16']['avg_ms']
+                wkf_, wvf_ = wk_.float(), wv_.float()
+                hip_ops.local_attention(U_, 64, 64, qi_, ki_, wkf_, wvf_)
+                with hip_ops.profile():
+                    for _ in range(5):
+                        hip_ops.local_attention(U_, 64, 64, qi_, ki_, wkf_, wvf_)
+                    torch.cuda.synchronize(dev)
+                t32 = hip_ops.profile.results()['local_attention']['avg_ms']
+                del wkf_, wvf_
+                b16 = Qc * (2.0 * 4 * 576 + 2.0 * 4 * 640 + 2.0 * 640 + 16) + 2.0 * 64 * 4 * HW
+                hb['local_attention_bf16'] = dict(bound='hbm', achieved=round(b16 / (t16 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                                  frac=round(b16 / (t16 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_chunk=round(t16, 4),
+                                                  queries=Qc, bytes_per_query=round(b16 / Qc), fp32_kernel_same_chunk_ms=round(t32, 4))
+                del U_, wk_, wv_
+            except Exception as e:                  # noqa: BLE001  (an extra: never the reason a bench line is lost)
+                hb['local_attention_bf16'] = dict(error=repr(e)[:200])
             roof['staged_path_hbm_kernels'] = hb
             # (2) the other precision / the other single-tile config, for the record (not the headline); every 16-bit figure carries
             # the roofline object of ITS dominant kernel (one profiled pass of the same input)

@@ -125,6 +125,8 @@ SIGNATURES = {
     'ciaosr_pack_head_chain_f16': (_I, [C.POINTER(HeadWeightsT), _I, _P, _P]),
     'ciaosr_head_indices_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'ciaosr_local_attention_f32': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
+    'ciaosr_local_attention_bf16': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
+    'ciaosr_local_attention_f16': (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _F, _P]),
     'ciaosr_gather_rows_f32': (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
     'ciaosr_mlp_workspace_bytes': (_S, [C.POINTER(MlpT), _I]),
     'ciaosr_mlp_forward_f32': (_I, [_P, _I, C.POINTER(MlpT), _I, _I, _P, _I, _P, _S, _P]),

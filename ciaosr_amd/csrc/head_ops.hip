@@ -203,6 +203,151 @@ __global__ __launch_bounds__(256) void local_attention_kernel(LocalAttnP p) {
     }
 }
 
+// K4 with 16-bit wk / wv / z (11 056 B per query at C = 64 against 22 064 in fp32): the staged route's HBM-bound kernel with
+// the three big operands in bf16 or IEEE half -- same fp32 arithmetic on the widened values, z rounded to nearest even (half: saturating).
+// One wave per query as above; a lane moves 8 B (4 elements) of wk / wv / z per step.
+struct LocalAttn16P {
+    const float* U;
+    int ldu, D, Dv;
+    const int* q_idx;
+    const int* k_idx;
+    const unsigned short* wk; int ldwk;
+    const unsigned short* wv; int ldwv;
+    unsigned short* z; int ldz;
+    int Q, J;
+    float scale;
+};
+
+template <bool F16>
+__device__ __forceinline__ float4 widen4(uint2 v) {
+    return make_float4(h16_lo<F16>(v.x), h16_hi<F16>(v.x), h16_lo<F16>(v.y), h16_hi<F16>(v.y));
+}
+
+// VW = elements a lane moves per step: 8 (16 B of wk / wv / z, two float4 of U) where every row length and leading dimension is a multiple
+// of 8 -- at 4 the kernel issues as many memory instructions as the fp32 one for half the bytes and runs no faster -- else 4.
+template <int J, bool F16, int VW>
+__global__ __launch_bounds__(256) void local_attention_h16_kernel(LocalAttn16P p) {
+    const int lane = threadIdx.x & 63;
+    const long q = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= p.Q) return;
+    const int qi = p.q_idx[q];
+    int kp[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) kp[j] = p.k_idx[q * J + j];
+    float logit[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) logit[j] = 0.f;
+    constexpr int NV = VW / 4;                               // float4 per step
+    if (qi >= 0) {
+        const float4* qrow = reinterpret_cast<const float4*>(p.U + (size_t)qi * p.ldu);
+        for (int t = lane; t < p.D / VW; t += 64) {
+            float4 qv[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) qv[v] = qrow[NV * t + v];
+            _Pragma("unroll") for (int j = 0; j < J; ++j) {
+                const float4* krow = reinterpret_cast<const float4*>(p.U + (size_t)kp[j] * p.ldu);
+                const unsigned short* wrow = p.wk + (size_t)(q * J + j) * p.ldwk;
+                float4 wv[NV];
+                if constexpr (VW == 8) {
+                    const uint4 w8 = reinterpret_cast<const uint4*>(wrow)[t];
+                    wv[0] = widen4<F16>(make_uint2(w8.x, w8.y)); wv[1] = widen4<F16>(make_uint2(w8.z, w8.w));
+                } else {
+                    wv[0] = widen4<F16>(reinterpret_cast<const uint2*>(wrow)[t]);
+                }
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 kv = krow[NV * t + v];
+                    logit[j] += qv[v].x * (kv.x * wv[v].x) + qv[v].y * (kv.y * wv[v].y) + qv[v].z * (kv.z * wv[v].z) + qv[v].w * (kv.w * wv[v].w);
+                }
+            }
+        }
+    }
+    float m = -INFINITY;
+    _Pragma("unroll") for (int j = 0; j < J; ++j) {
+        logit[j] = wsum(logit[j]) / p.scale;
+        m = fmaxf(m, logit[j]);
+    }
+    float den = 0.f;
+    _Pragma("unroll") for (int j = 0; j < J; ++j) {
+        logit[j] = expf(logit[j] - m);
+        den += logit[j];
+    }
+    _Pragma("unroll") for (int j = 0; j < J; ++j) logit[j] /= den;
+    unsigned short* zrow = p.z + (size_t)q * p.ldz;
+    for (int t = lane; t < p.Dv / VW; t += 64) {
+        float4 acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        _Pragma("unroll") for (int j = 0; j < J; ++j) {
+            const float4* vrow = reinterpret_cast<const float4*>(p.U + (size_t)kp[j] * p.ldu);
+            const unsigned short* wrow = p.wv + (size_t)(q * J + j) * p.ldwv;
+            float4 ww[NV];
+            if constexpr (VW == 8) {
+                const uint4 w8 = reinterpret_cast<const uint4*>(wrow)[t];
+                ww[0] = widen4<F16>(make_uint2(w8.x, w8.y)); ww[1] = widen4<F16>(make_uint2(w8.z, w8.w));
+            } else {
+                ww[0] = widen4<F16>(reinterpret_cast<const uint2*>(wrow)[t]);
+            }
+            const float a = logit[j];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4 vv = vrow[NV * t + v];
+                acc[v].x += a * (vv.x * ww[v].x);
+                acc[v].y += a * (vv.y * ww[v].y);
+                acc[v].z += a * (vv.z * ww[v].z);
+                acc[v].w += a * (vv.w * ww[v].w);
+            }
+        }
+        if constexpr (VW == 8) {
+            const uint2 lo = pack_h16x4<F16>(acc[0].x, acc[0].y, acc[0].z, acc[0].w), hi = pack_h16x4<F16>(acc[1].x, acc[1].y, acc[1].z, acc[1].w);
+            reinterpret_cast<uint4*>(zrow)[t] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            reinterpret_cast<uint2*>(zrow)[t] = pack_h16x4<F16>(acc[0].x, acc[0].y, acc[0].z, acc[0].w);
+        }
+    }
+}
+
+template <bool F16, int VW>
+static int local_attention_h16_vw(const LocalAttn16P& p, hipStream_t s) {
+    const dim3 grid(ceil_div(p.Q, 4));
+    if (p.J == 4) hipLaunchKernelGGL((local_attention_h16_kernel<4, F16, VW>), grid, dim3(256), 0, s, p);
+    else if (p.J == 9) hipLaunchKernelGGL((local_attention_h16_kernel<9, F16, VW>), grid, dim3(256), 0, s, p);
+    else if (p.J == 1) hipLaunchKernelGGL((local_attention_h16_kernel<1, F16, VW>), grid, dim3(256), 0, s, p);
+    else return CIAOSR_ERR_BAD_ARG;
+    return CIAOSR_OK;
+}
+
+template <bool F16>
+static int local_attention_h16(const LocalAttn16P& p, hipStream_t s) {
+    ProfScope prof(F16 ? "local_attention_f16" : "local_attention_bf16", s);
+    const bool wide = ((p.D | p.Dv | p.ldwk | p.ldwv | p.ldz | p.ldu) & 7) == 0 && (((size_t)p.wk | (size_t)p.wv | (size_t)p.z) & 15) == 0;
+    const int rc = wide ? local_attention_h16_vw<F16, 8>(p, s) : local_attention_h16_vw<F16, 4>(p, s);
+    if (rc != CIAOSR_OK) return rc;
+    return launch_status(F16 ? "local_attention_f16" : "local_attention_bf16");
+}
+
+static int local_attention_16_entry(bool f16, const float* unfold, int ld_u, int C, int Cn, const int* q_idx, const int* k_idx, const void* wk,
+                                    int ld_wk, const void* wv, int ld_wv, void* z, int ld_z, int Q, int J, float softmax_scale, void* stream) {
+    CIAOSR_CHECK_ARG(unfold && q_idx && k_idx && wk && wv && z && Q > 0);
+    CIAOSR_CHECK_ARG((J == 1 || J == 4 || J == 9) && (C & 3) == 0 && (Cn & 3) == 0);
+    CIAOSR_CHECK_ARG((ld_u & 3) == 0 && (ld_wk & 3) == 0 && (ld_wv & 3) == 0 && (ld_z & 3) == 0);
+    CIAOSR_CHECK_ARG(((size_t)wk & 7) == 0 && ((size_t)wv & 7) == 0 && ((size_t)z & 7) == 0);
+    LocalAttn16P p{unfold, ld_u, 9 * C, 9 * C + Cn, q_idx, k_idx, reinterpret_cast<const unsigned short*>(wk), ld_wk,
+                   reinterpret_cast<const unsigned short*>(wv), ld_wv, reinterpret_cast<unsigned short*>(z), ld_z, Q, J, softmax_scale};
+    return f16 ? local_attention_h16<true>(p, (hipStream_t)stream) : local_attention_h16<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int ciaosr_local_attention_bf16(const float* unfold, int ld_u, int C, int Cn, const int* q_idx, const int* k_idx, const void* wk,
+                                           int ld_wk, const void* wv, int ld_wv, void* z, int ld_z, int Q, int J, float softmax_scale,
+                                           void* stream) {
+    return local_attention_16_entry(false, unfold, ld_u, C, Cn, q_idx, k_idx, wk, ld_wk, wv, ld_wv, z, ld_z, Q, J, softmax_scale, stream);
+}
+extern "C" int ciaosr_local_attention_f16(const float* unfold, int ld_u, int C, int Cn, const int* q_idx, const int* k_idx, const void* wk,
+                                          int ld_wk, const void* wv, int ld_wv, void* z, int ld_z, int Q, int J, float softmax_scale,
+                                          void* stream) {
+    return local_attention_16_entry(true, unfold, ld_u, C, Cn, q_idx, k_idx, wk, ld_wk, wv, ld_wv, z, ld_z, Q, J, softmax_scale, stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // decode: rgb = W_last . h + b_last + bilinear_border(x_lr; coord)
 // ---------------------------------------------------------------------------------------------

@@ -165,6 +165,19 @@ def local_attention(unfold, C_, Cn, q_idx, k_idx, wk, wv, softmax_scale=1.0):
     return z
 
 
+def local_attention_16(unfold, C_, Cn, q_idx, k_idx, wk16, wv16, softmax_scale=1.0):
+    """K4 with wk / wv / z as torch.bfloat16 or torch.float16 tensors (ciaosr_local_attention_bf16 / _f16): half the HBM bytes per query."""
+    require_gpu(unfold, q_idx, k_idx)
+    if not (wk16.is_cuda and wv16.is_cuda and wk16.dtype == wv16.dtype and wk16.dtype in (torch.bfloat16, torch.float16)):
+        raise CiaoSRHipError(f'local_attention_16: wk / wv must be bfloat16 or float16 tensors on the GPU, got {wk16.dtype} / {wv16.dtype}')
+    Q, J = k_idx.shape
+    z = torch.empty(Q, 9 * C_ + Cn, dtype=wk16.dtype, device=unfold.device)
+    _lib.call('ciaosr_local_attention_' + ('bf16' if wk16.dtype == torch.bfloat16 else 'f16'), ptr(unfold), unfold.stride(0), C_, Cn,
+              ptr(q_idx), ptr(k_idx), ptr(wk16), wk16.stride(0), ptr(wv16), wv16.stride(0), ptr(z), z.stride(0), Q, J, float(softmax_scale),
+              stream_ptr())
+    return z
+
+
 def _f3(vals):
     return (C.c_float * 3)(*[float(v) for v in vals])
 

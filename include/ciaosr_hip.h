@@ -298,6 +298,16 @@ int ciaosr_local_attention_f32(const float* unfold, int ld_u, int C, int Cn, con
                                const int* k_idx, const float* wk, int ld_wk, const float* wv, int ld_wv,
                                float* z, int ld_z, int Q, int J, float softmax_scale, void* stream);
 
+/* The same kernel with wk, wv and z as 16-bit arrays (bf16 / IEEE half, round to nearest even, half saturating; leading dimensions in
+ * ELEMENTS, multiples of 4; 8-byte aligned): the staged route's HBM-bound step at half the bytes (11 056 B per query at
+ * C = 64 against 22 064).  unfold, the logits, the softmax and the sums stay fp32.  net:211-216. */
+int ciaosr_local_attention_bf16(const float* unfold, int ld_u, int C, int Cn, const int* q_idx,
+                                const int* k_idx, const void* wk, int ld_wk, const void* wv, int ld_wv,
+                                void* z, int ld_z, int Q, int J, float softmax_scale, void* stream);
+int ciaosr_local_attention_f16(const float* unfold, int ld_u, int C, int Cn, const int* q_idx,
+                               const int* k_idx, const void* wk, int ld_wk, const void* wv, int ld_wv,
+                               void* z, int ld_z, int Q, int J, float softmax_scale, void* stream);
+
 /* Staged K1 "gather rows" (net:145-146,176-196), the MLP inputs exactly as the reference assembles them:
  *   q_rows [Q][ld_q]      = unfold[q_idx[q]][0:9C]                     (zeros when the query falls outside, net:145)
  *   inp_k  [Q*J][ld_k]    = [ unfold[k_idx][0:9C]      | rel_y rel_x | scale_y scale_x ]      (net:195)

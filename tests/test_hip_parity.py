@@ -736,6 +736,36 @@ def test_staged_local_attention_kernel(dev):
     assert (z - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_staged_local_attention_kernel_16bit_operands(dev, dtype):
+    """ciaosr_local_attention_bf16 / _f16 (K4 with 16-bit wk / wv / z): exactly the fp32 kernel's arithmetic on the
+    widened operands -- z equals the fp32 kernel's result on the SAME (rounded) wk / wv up to its own rounding to 16 bits -- and within
+    the element type's precision of the torch evaluation of net:211-216 on the unrounded operands.  J = 4 and 9, a ragged Q."""
+    from ciaosr_amd import hip_ops
+    td = torch.bfloat16 if dtype == 'bf16' else torch.float16
+    for J, C, Cn in ((4, 16, 16), (9, 16, 16), (4, 20, 20)):       # 9C = 144 / 160: 16-byte steps; 9C = 180: the 8-byte form
+        H, W, Q = 9, 11, 701
+        U = randn((H * W, 9 * C + Cn), 40).to(dev)
+        q_idx = torch.randint(0, H * W, (Q,), generator=torch.Generator().manual_seed(1)).int().to(dev)
+        q_idx[5] = -1                                              # a query outside the map: zero logits, uniform attention
+        k_idx = torch.randint(0, H * W, (Q, J), generator=torch.Generator().manual_seed(2)).int().to(dev)
+        wk, wv = randn((Q * J, 9 * C), 41).to(dev), randn((Q * J, 9 * C + Cn), 42).to(dev)
+        wk16, wv16 = wk.to(td), wv.to(td)
+        z16 = hip_ops.local_attention_16(U, C, Cn, q_idx, k_idx, wk16, wv16, softmax_scale=1.5)
+        assert z16.dtype == td
+        z32 = hip_ops.local_attention(U, C, Cn, q_idx, k_idx, wk16.float(), wv16.float(), softmax_scale=1.5)
+        # (the two kernels are compiled separately: their fp32 sums may differ in the last bit, hence an ulp of the 16-bit type, not bitwise)
+        eps = 2.0 ** -8 if dtype == 'bf16' else 2.0 ** -11
+        d = (z16.float() - z32).abs().max().item()
+        assert d <= eps * max(1.0, z32.abs().max().item()), (dtype, J, d)
+        qv = U[q_idx.clamp(min=0).long(), :9 * C] * (q_idx >= 0).unsqueeze(1)
+        kv = U[k_idx.long().view(-1)]
+        logit = (qv.unsqueeze(1) * (kv[:, :9 * C] * wk).view(Q, J, -1)).sum(-1)
+        a = (logit / 1.5).softmax(-1)
+        want = (a.unsqueeze(-1) * (kv * wv).view(Q, J, -1)).sum(1)
+        assert (z16.float() - want).abs().max() < 8 * eps * max(1.0, want.abs().max().item()), (dtype, J)
+
+
 # ------------------------------------------------------------------------------------------------
 # encoder trunks (implicit-GEMM convolutions)
 # ------------------------------------------------------------------------------------------------
