@@ -130,6 +130,9 @@ SIGNATURES = {
     'ciaosr_gather_rows_f32': (_I, [_P, _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P]),
     'ciaosr_mlp_workspace_bytes': (_S, [C.POINTER(MlpT), _I]),
     'ciaosr_mlp_forward_f32': (_I, [_P, _I, C.POINTER(MlpT), _I, _I, _P, _I, _P, _S, _P]),
+    'ciaosr_mlp_workspace_bytes_16': (_S, [C.POINTER(MlpT), _I]),
+    'ciaosr_mlp_forward_bf16': (_I, [_P, _I, C.POINTER(MlpT), _I, _P, _I, _P, _S, _P]),
+    'ciaosr_mlp_forward_f16': (_I, [_P, _I, C.POINTER(MlpT), _I, _P, _I, _P, _S, _P]),
     'ciaosr_decode_residual_f32': (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _I, _I, _I, _P, _P]),
     'ciaosr_head_workspace_bytes': (_S, [_I, _I, C.POINTER(HeadWeightsT), _I]),
     'ciaosr_head_forward_f32': (_I, [_P, _I, _I, C.POINTER(HeadWeightsT), C.POINTER(CsAttnWeightsT), _P, _P, _P,

@@ -62,6 +62,7 @@ struct Gemm16P {
     //   EPI 2: stats[row] = (row max, 1 / row sum) -> probabilities exp(v - max) / sum as 16-bit into C16 (columns [N, npad) zeroed)
     float2* part; int n_part;
     const float2* stats; int npad;
+    int relu = 0;                    // fused epilogue (bias given): v = max(v, 0) before it is written (staged MLP layers)
 };
 
 // store epilogue of one 256 x 128 tile: accumulator quad q of (mt, nt) = row m0 + 128 wm + 32 mt + li, columns n0 + 64 wn + 32 nt + 8 q + 4 lh .. +3
@@ -86,6 +87,7 @@ __device__ __forceinline__ void store_tile(const Gemm16P& p, const f32x16 (&acc)
                         const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
                         v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
                     }
+                    if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                     if (p.C2) *reinterpret_cast<float4*>(p.C2 + (size_t)m * p.ldc2 + n) = make_float4(v0, v1, v2, v3);
                     if (p.C16) *reinterpret_cast<uint2*>(p.C16 + (size_t)m * p.ldc16 + n) = pack_h16x4<kF16>(v0, v1, v2, v3);
                 }
@@ -558,6 +560,28 @@ int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int l
     const int rc = launch_gemm16<0>(p, pick_mt(M, p.tiles_n), s);
     if (rc != CIAOSR_OK) return rc;
     return launch_status("gemm" CIAOSR_H16_SUFFIX);
+}
+
+// One Linear of the staged 16-bit MLP (mlp_refiner.py:87-102): C = [relu](A . W^T + bias), A and W 16-bit, C fp32 or 16-bit.
+// N a multiple of 4, K a multiple of 8 (the caller pads both operands with zero columns).
+int linear_h16(const unsigned short* A, int lda, const unsigned short* W16, int ldw, const float* bias, bool relu, void* C, int ldc, bool c_16bit,
+               int M, int N, int K, hipStream_t s, const char* tag) {
+    CIAOSR_CHECK_ARG(A && W16 && bias && C && M > 0 && N > 0 && (N & 3) == 0 && K > 0 && (K & 7) == 0);
+    CIAOSR_CHECK_ARG((lda & 7) == 0 && (ldw & 7) == 0 && (ldc & 3) == 0 && aligned16(A) && aligned16(W16) && aligned16(bias) && (((size_t)C) & 7) == 0);
+    Gemm16P p;
+    p.A = A; p.lda = lda; p.B = W16; p.ldb = ldw; p.C = C; p.ldc = ldc; p.c_bf16 = c_16bit ? 1 : 0;
+    p.M = M; p.N = N; p.K = K; p.alpha = 1.f;
+    p.bias = bias; p.res = nullptr; p.ldres = 0; p.C2 = nullptr; p.ldc2 = 0; p.C16 = nullptr; p.ldc16 = 0;
+    p.part = nullptr; p.n_part = 0; p.stats = nullptr; p.npad = 0;
+    p.relu = relu ? 1 : 0;
+    const size_t ab = ((size_t)(M - 1) * lda + K) * 2, bb = ((size_t)(N - 1) * ldw + K) * 2;
+    CIAOSR_CHECK_ARG(ab < 0xFFFFFF00ull && bb < 0xFFFFFF00ull);
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    p.tiles_n = ceil_div(N, GN);
+    ProfScope prof(tag, s);
+    const int rc = launch_gemm16<0>(p, pick_mt(M, p.tiles_n), s);
+    if (rc != CIAOSR_OK) return rc;
+    return launch_status("linear" CIAOSR_H16_SUFFIX);
 }
 
 int cast_rows_h16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s) {

@@ -410,6 +410,73 @@ extern "C" int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp
     return CIAOSR_OK;
 }
 
+// ---- staged MLP with 16-bit operands (SURVEY 8(b-2) "ciaosr_mlp5_bf16"): every Linear on the 16-bit MFMA GEMM, activations 16-bit between layers,
+// fp32 accumulation, biases and the last layer's output fp32.  ReLU MLPs only (what the 16-bit modes are defined for).
+static size_t round8(size_t v) { return (v + 7) & ~(size_t)7; }
+extern "C" size_t ciaosr_mlp_workspace_bytes_16(const ciaosr_mlp_t* m, int rows) {
+    if (!m || rows <= 0 || !mlp_ok(*m)) return 0;
+    size_t wmax = 0, kmax = round8((size_t)m->in_dim);
+    for (int i = 0; i < m->n_layers; ++i) {
+        wmax = std::max(wmax, round8((size_t)m->width[i]));
+        if (i + 1 < m->n_layers) kmax = std::max(kmax, round8((size_t)m->width[i]));
+    }
+    // x as 16 bits, two ping-pong activation buffers, one layer's weights as 16 bits; 256 B of slack per buffer for alignment
+    return ((size_t)rows * round8((size_t)m->in_dim) + 2 * (size_t)rows * wmax + wmax * kmax) * 2 + 4 * 256;
+}
+
+template <typename CastFn, typename LinFn>
+static int mlp_forward_16(CastFn cast_rows, LinFn linear, const float* x, int ld_x, const ciaosr_mlp_t* m, int rows, float* out, int ld_out,
+                          void* workspace, size_t workspace_bytes, hipStream_t s) {
+    CIAOSR_CHECK_ARG(x && m && out && rows > 0 && mlp_ok(*m) && ld_x >= m->in_dim && (ld_x & 3) == 0 && (ld_out & 3) == 0);
+    CIAOSR_CHECK_ARG(m->n_layers == 1 || mlp_act(*m) == CIAOSR_ACT_RELU);
+    for (int i = 0; i < m->n_layers; ++i) CIAOSR_CHECK_ARG((m->width[i] & 3) == 0 || i + 1 == m->n_layers);
+    if (workspace_bytes < ciaosr_mlp_workspace_bytes_16(m, rows)) return CIAOSR_ERR_WORKSPACE;
+    Arena ar(workspace, workspace_bytes);
+    size_t wmax = 0, kmax = round8((size_t)m->in_dim);
+    for (int i = 0; i < m->n_layers; ++i) {
+        wmax = std::max(wmax, round8((size_t)m->width[i]));
+        if (i + 1 < m->n_layers) kmax = std::max(kmax, round8((size_t)m->width[i]));
+    }
+    const int k0 = (int)round8((size_t)m->in_dim);
+    unsigned short* x16 = ar.take<unsigned short>((size_t)rows * k0);
+    unsigned short* pp[2] = {ar.take<unsigned short>((size_t)rows * wmax), ar.take<unsigned short>((size_t)rows * wmax)};
+    unsigned short* w16 = ar.take<unsigned short>(wmax * kmax);
+    if (!ar.ok) return CIAOSR_ERR_WORKSPACE;
+    // cast_rows zeroes the pad columns [cols, ld_dst): K is padded to a multiple of 8 on both operands
+    int rc = cast_rows(x, ld_x, x16, k0, (long)rows, (m->in_dim + 3) & ~3, s);
+    if (rc != CIAOSR_OK) return rc;
+    const unsigned short* cur = x16;
+    int ld_cur = k0, k_cur = k0, k_real = m->in_dim;
+    for (int i = 0; i < m->n_layers; ++i) {
+        const bool last = i + 1 == m->n_layers;
+        const int N = m->width[i];
+        rc = cast_rows(m->weight[i], m->ld[i], w16, k_cur, (long)N, (k_real + 3) & ~3, s);
+        if (rc != CIAOSR_OK) return rc;
+        if (last) {
+            // an output width that is no multiple of 4 (imnet_q: 3) goes through a padded scratch row in the free ping-pong buffer
+            if ((N & 3) == 0) rc = linear(cur, ld_cur, w16, k_cur, m->bias[i], false, out, ld_out, false, rows, N, k_cur, s, "mlp_layer_16");
+            else return CIAOSR_ERR_UNSUPPORTED;
+        } else {
+            const int ldn = (int)round8((size_t)N);
+            unsigned short* dst = pp[i & 1];
+            if (ldn != N && hipMemsetAsync(dst, 0, (size_t)rows * ldn * 2, s) != hipSuccess) return CIAOSR_ERR_LAUNCH;
+            rc = linear(cur, ld_cur, w16, k_cur, m->bias[i], true, dst, ldn, true, rows, N, k_cur, s, "mlp_layer_16");
+            cur = dst; ld_cur = ldn; k_cur = ldn; k_real = N;
+        }
+        if (rc != CIAOSR_OK) return rc;
+    }
+    return CIAOSR_OK;
+}
+
+extern "C" int ciaosr_mlp_forward_bf16(const float* x, int ld_x, const ciaosr_mlp_t* m, int rows, float* out, int ld_out, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    return mlp_forward_16(b16::cast_rows_h16, b16::linear_h16, x, ld_x, m, rows, out, ld_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+extern "C" int ciaosr_mlp_forward_f16(const float* x, int ld_x, const ciaosr_mlp_t* m, int rows, float* out, int ld_out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    return mlp_forward_16(f16::cast_rows_h16, f16::linear_h16, x, ld_x, m, rows, out, ld_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // ---- weight stream of the weights-stationary 16-bit head (head_chain_h16.hip) ---------------------------------------------------------
 static bool chain_weights_ok(const ciaosr_head_weights_t* w) {
     if (!w || !mlp_ok(w->k) || !mlp_ok(w->v)) return false;

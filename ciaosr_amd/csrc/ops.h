@@ -176,6 +176,8 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
     int gemm_h16_nt(const unsigned short* A, int lda, const unsigned short* B, int ldb, void* C, int ldc, bool c_bf16, int M, int N,  \
                     int K, float alpha, hipStream_t s, const char* tag);                                                              \
     int cast_rows_h16(const float* src, int ld_src, unsigned short* dst, int ld_dst, long rows, int cols, hipStream_t s);             \
+    int linear_h16(const unsigned short* A, int lda, const unsigned short* W16, int ldw, const float* bias, bool relu, void* C, int ldc,      \
+                   bool c_16bit, int M, int N, int K, hipStream_t s, const char* tag);                                                      \
     int softmax_rows_h16(const float* S, long rows, int L, int ld, unsigned short* P, int ldp, hipStream_t s);                        \
     int head_kv_fused_h16(const FusedKVP& p, hipStream_t s);                                                                          \
     int head_decode_fused_h16(const FusedQP& p, hipStream_t s);                                                                       \

@@ -214,7 +214,7 @@ class PackedHead:
         return rgb
 
     @torch.no_grad()
-    def forward_as_written(self, feature_chw, x_lr_chw, coord, cell, chunk=None, options=None):
+    def forward_as_written(self, feature_chw, x_lr_chw, coord, cell, chunk=None, options=None, half=None):
         """The reference's op order, stage by stage through the staged C entry points, with NO algebraic
         restructuring (no layer-1 hoist, no logit table, no fusion): K1 gather rows (net:145-196) ->
         imnet_k / imnet_v on every (query, sample) row (net:202-206) -> K4 local attention (net:211-216) ->
@@ -245,9 +245,16 @@ class PackedHead:
             q1 = min(Q, q0 + step)
             cq, cl = coord[q0:q1].contiguous(), cell[q0:q1].contiguous()
             q_rows, inp_k, inp_v, q_idx, k_idx = hip_ops.gather_rows(U, Cc, Cn, cq, cl, H, W, st.local_size)
-            wk = hip_ops.mlp_forward(inp_k, st.k)
-            wv = hip_ops.mlp_forward(inp_v, st.v)
-            z = hip_ops.local_attention(U, Cc, Cn, q_idx, k_idx, wk, wv, softmax_scale=st.softmax_scale)
+            if half is None:
+                wk = hip_ops.mlp_forward(inp_k, st.k)
+                wv = hip_ops.mlp_forward(inp_v, st.v)
+                z = hip_ops.local_attention(U, Cc, Cn, q_idx, k_idx, wk, wv, softmax_scale=st.softmax_scale)
+            else:
+                # the staged 16-bit entry points: imnet_k / imnet_v on the 16-bit GEMM, K4 on 16-bit wk / wv / z
+                td = torch.bfloat16 if half == 'bf16' else torch.float16
+                wk = hip_ops.mlp_forward_16(inp_k, st.k, half).to(td)
+                wv = hip_ops.mlp_forward_16(inp_v, st.v, half).to(td)
+                z = hip_ops.local_attention_16(U, Cc, Cn, q_idx, k_idx, wk, wv, softmax_scale=st.softmax_scale).float()
             h = hip_ops.mlp_forward(z, st.q, n_run=nq - 1)
             out[q0:q1] = hip_ops.decode_residual(h, w_last, b_last, x_lr_chw, cq, H, W)
         return out

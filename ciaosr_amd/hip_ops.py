@@ -327,6 +327,18 @@ def mlp_forward(x, mlp_struct, n_run=0):
     return out
 
 
+def mlp_forward_16(x, mlp_struct, half='bf16'):
+    """MLPRefiner.forward with every Linear on the 16-bit MFMA GEMM (ciaosr_mlp_forward_bf16 / _f16): fp32 in, fp32 out."""
+    require_gpu(x)
+    rows = x.shape[0]
+    out = torch.empty(rows, mlp_struct.width[mlp_struct.n_layers - 1], dtype=torch.float32, device=x.device)
+    nbytes = _lib.load().ciaosr_mlp_workspace_bytes_16(C.byref(mlp_struct), rows)
+    ws = workspace(nbytes, x.device, slot='mlp16')
+    _lib.call('ciaosr_mlp_forward_' + half, ptr(x), x.stride(0), C.byref(mlp_struct), rows, ptr(out), out.stride(0), ptr(ws), ws.numel(),
+              stream_ptr())
+    return out
+
+
 def decode_residual(h, w_last, b_last, x_lr_chw, coord, H, W):
     require_gpu(h, w_last, b_last, x_lr_chw, coord)
     Q = h.shape[0]

@@ -326,6 +326,17 @@ size_t ciaosr_mlp_workspace_bytes(const ciaosr_mlp_t* m, int rows);
 int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp_t* m, int n_run, int rows, float* out, int ld_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same MLP with every Linear on the 16-bit MFMA GEMM (bf16 / IEEE half inputs, fp32 accumulation and biases, 16-bit activations
+ * between the layers, fp32 output): ReLU MLPs whose layer widths are multiples of 4 (imnet_k / imnet_v; imnet_q's 3-wide output layer is
+ * CIAOSR_ERR_UNSUPPORTED: run it up to its last hidden layer in fp32 or use the fused head).  Weights are rounded per call from
+ * m->weight (single 16-bit weights: the precision of `opt->bf16_single` / the f16 mode).  workspace >= ciaosr_mlp_workspace_bytes_16(m, rows).
+ * mlp_refiner.py:87-102. */
+size_t ciaosr_mlp_workspace_bytes_16(const ciaosr_mlp_t* m, int rows);
+int ciaosr_mlp_forward_bf16(const float* x, int ld_x, const ciaosr_mlp_t* m, int rows, float* out, int ld_out,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int ciaosr_mlp_forward_f16(const float* x, int ld_x, const ciaosr_mlp_t* m, int rows, float* out, int ld_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* Staged decode tail (net:107-108,221): rgb[q] = W_last . h[q] + b_last + bilinear_border(x_lr_nchw; coord[q]).
  * h [Q][ld_h] (width columns), w_last [3][ld_w]; x_lr_nchw NULL = no residual. */
 int ciaosr_decode_residual_f32(const float* h, int ld_h, int width, const float* w_last, int ld_w, const float* b_last,

@@ -667,6 +667,27 @@ def test_as_written_staged_route_vs_golden_and_fused(dev):
     assert (fused - written).abs().max() < 5e-5 * max(1.0, written.abs().max().item())
 
 
+@pytest.mark.parametrize('half', ['bf16', 'f16'])
+def test_staged_route_through_the_16bit_mlp_and_k4_entry_points(dev, half):
+    """the staged route with imnet_k / imnet_v on ciaosr_mlp_forward_bf16 / _f16 (every Linear on the 16-bit MFMA GEMM,
+    single 16-bit weights, 16-bit activations between layers) and K4 on ciaosr_local_attention_bf16 / _f16 (16-bit wk / wv / z), against
+    the fp32 staged route on the same head: within the element type's own distance (bf16-single is the mode that does NOT meet the PSNR
+    gate of the product -- these entry points exist for the staged measurements, the product's 16-bit head is the fused route)."""
+    from ciaosr_amd.coords import make_coord, make_cell
+    g = _my_generator(64, (256,) * 4, seeded_head(64, 3, head_gain=2.0), dev, eval_bsize=2000)
+    feat = randn((1, 64, 21, 30), 11).to(dev)
+    ht, wt = 37, 41
+    coord, cell = make_coord((ht, wt)).to(dev), make_cell((ht, wt)).to(dev)
+    x = (randn((1, 3, 21, 30), 12) * 0.3).to(dev)
+    fp32 = g._head.forward_as_written(feat[0], x[0], coord, cell, chunk=700).cpu()
+    got = g._head.forward_as_written(feat[0], x[0], coord, cell, chunk=700, half=half).cpu()
+    scale = max(1.0, fp32.abs().max().item())
+    d = (got - fp32).abs().max().item()
+    print(f'staged {half}: max |delta| vs the fp32 staged route {d:.3e} (scale {scale:.2f})')
+    assert torch.isfinite(got).all()
+    assert d < (6e-2 if half == 'bf16' else 8e-3) * scale, (half, d)
+
+
 def test_gather_rows_matches_reference_assembly(dev):
     """K1 alone: inp_k / inp_v / q rows against torch indexing of the same unfold rows (net:145,176-196)."""
     from ciaosr_amd import hip_ops
