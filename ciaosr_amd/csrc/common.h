@@ -53,6 +53,15 @@ static inline bool allow_big_lds(LdsAttrOnce& once, K kernel, size_t bytes) {
     return true;
 }
 
+// Ordering point of an exchange through LDS between the lanes of ONE wave (accumulator layout -> row-major transposes in the store
+// epilogues): the hardware runs a wave's LDS instructions in order, so no instruction is needed -- the wavefront-scope fences and the
+// wave barrier only forbid the COMPILER to move the read phase above the write phase (or a rewrite of the buffer above its last read).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 int launch_status(const char* what);
 
 // ciaosr_options_t hygiene, checked by every entry point that takes one: unknown route bits and out-of-range fields are refused

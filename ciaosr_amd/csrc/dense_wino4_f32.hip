@@ -430,6 +430,7 @@ __global__ __launch_bounds__(256) void dense_wino4_f32_kernel(DenseWino4P p) {
                 }
                 *reinterpret_cast<float4*>(tb + li * 128 + (((2 * q + lh) ^ (li & 7)) << 4)) = v;
             }
+            wave_lds_sync();                               // lanes read what OTHER lanes of this wave wrote
             const int sr = lane >> 3, sc = lane & 7;
             const int xx = tx0 + 4 * sr + x;
 #pragma unroll

@@ -417,6 +417,7 @@ __global__ __launch_bounds__(512) void gemm_h16_wide_kernel(Gemm16P p) {
         float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+            if (nt) wave_lds_sync();                       // the buffer is rewritten: after the last read of the first half
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(512) void gemm_h16_wide_kernel(Gemm16P p) {
                     *reinterpret_cast<float4*>(ot + r * 128 + ((n4 ^ (r & 7)) << 4)) =
                         make_float4(acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]);
                 }
+            wave_lds_sync();                               // lanes read what OTHER lanes of this wave wrote
             const int rr = lane >> 3, c = lane & 7;
 #pragma unroll
             for (int j = 0; j < 4 * MT; ++j) {
@@ -759,6 +761,7 @@ __global__ __launch_bounds__(512) void conv1x1_lines_h16_kernel(Skinny16P p) {
             *reinterpret_cast<float4*>(tb + li * 256 + ((n4 ^ (li & 15)) << 4)) =
                 make_float4(acc[nt][4 * q], acc[nt][4 * q + 1], acc[nt][4 * q + 2], acc[nt][4 * q + 3]);
         }
+    wave_lds_sync();                                       // lanes read what OTHER lanes of this wave wrote
     const int er = lane >> 4, ec = lane & 15;
     const float4 b = *reinterpret_cast<const float4*>(p.bias + 4 * ec);
     float4 rq[8];

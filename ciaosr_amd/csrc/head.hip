@@ -429,6 +429,9 @@ static int mlp_forward_16(CastFn cast_rows, LinFn linear, const float* x, int ld
                           void* workspace, size_t workspace_bytes, hipStream_t s) {
     CIAOSR_CHECK_ARG(x && m && out && rows > 0 && mlp_ok(*m) && ld_x >= m->in_dim && (ld_x & 3) == 0 && (ld_out & 3) == 0);
     CIAOSR_CHECK_ARG(m->n_layers == 1 || mlp_act(*m) == CIAOSR_ACT_RELU);
+    // cast_rows converts whole 4-column groups: with in_dim % 4 != 0 the group past in_dim would carry x padding / the next weight row
+    // into the contraction (the model's own in_dim is 9C + 4 or 10C + 4 with C % 4 == 0)
+    CIAOSR_CHECK_ARG((m->in_dim & 3) == 0);
     for (int i = 0; i < m->n_layers; ++i) CIAOSR_CHECK_ARG((m->width[i] & 3) == 0 || i + 1 == m->n_layers);
     if (workspace_bytes < ciaosr_mlp_workspace_bytes_16(m, rows)) return CIAOSR_ERR_WORKSPACE;
     Arena ar(workspace, workspace_bytes);

@@ -39,11 +39,26 @@ class BasicRestorer(nn.Module):
         self.test_cfg = _as_cfg(test_cfg)
         self.fp16_enabled = False
         self.generator = build_backbone(generator)
-        # the generator sees the restorer's test_cfg (one dict, looked up per call): `allow_f16_substitute` is read from it
-        if hasattr(self.generator, 'bind_test_cfg'):
-            self.generator.bind_test_cfg(self.test_cfg)
+        # the generator sees the restorer's test_cfg (looked up per call): `allow_f16_substitute` is read from it
+        self._bind_generator_cfg()
         self.init_weights(pretrained)
         self.pixel_loss = build_loss(pixel_loss)
+
+    # `test_cfg` is a property so that REASSIGNING it (`restorer.test_cfg = {...}`, what mmedit's apis do) re-binds the generator's view
+    # as well; mutating the dict in place is seen without that.
+    @property
+    def test_cfg(self):
+        return self.__dict__.get('_test_cfg')
+
+    @test_cfg.setter
+    def test_cfg(self, cfg):
+        self.__dict__['_test_cfg'] = _as_cfg(cfg)
+        self._bind_generator_cfg()
+
+    def _bind_generator_cfg(self):
+        gen = self.__dict__.get('_modules', {}).get('generator', None)
+        if gen is not None and hasattr(gen, 'bind_test_cfg'):
+            gen.bind_test_cfg(self.__dict__.get('_test_cfg'))
 
     def init_weights(self, pretrained=None):
         self.generator.init_weights(pretrained)
@@ -151,8 +166,14 @@ class CiaoSR(BasicRestorer):
         tails, the HBM-bound softmax / patch kernels) fill with the other tile's workgroups instead of idling the chip
         (-2 % fp32, -3.5 % bf16 on a 6-tile image).  Every tile is computed exactly as on one stream (own scratch per
         stream) and the blend stays on the caller's stream in the reference order (h outer, w inner), so the result is
-        bitwise the single-stream result.  Off by default because per-kernel event timings (bench.py's roofline leg,
-        rocprof) are meaningless while two streams share the chip."""
+        bitwise the single-stream result.  `tile_streams` is off by default because per-kernel event timings (bench.py's
+        roofline leg, rocprof) are meaningless while two streams share the chip.
+
+        `test_cfg.encoder_ahead` (default TRUE since round 5, see `_clip_test_encoder_ahead`) DOES put a second stream under an
+        image of more than `tile_batch` tiles: the next batch's trunk runs on a cached side stream (fork / join by events,
+        `record_stream` on the hand-over buffers, two batches of feature maps live).  Bitwise the one-stream image; set
+        `test_cfg.encoder_ahead = False` for per-kernel timing, rocprof attribution of a multi-batch image, or when calling under
+        your own stream capture ("test_cfg extensions")."""
         sf = self.test_cfg.get('scale', None)
         b, c, h, w = img_lq.shape
         tile, origins = tile_grid(h, w, self.test_cfg.get('tile', None), self.test_cfg.get('tile_overlap', None))

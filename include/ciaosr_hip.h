@@ -327,7 +327,7 @@ int ciaosr_mlp_forward_f32(const float* x, int ld_x, const ciaosr_mlp_t* m, int 
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* The same MLP with every Linear on the 16-bit MFMA GEMM (bf16 / IEEE half inputs, fp32 accumulation and biases, 16-bit activations
- * between the layers, fp32 output): ReLU MLPs whose layer widths are multiples of 4 (imnet_k / imnet_v; imnet_q's 3-wide output layer is
+ * between the layers, fp32 output): ReLU MLPs whose in_dim and layer widths are multiples of 4 (else CIAOSR_ERR_BAD_ARG; imnet_k / imnet_v; imnet_q's 3-wide output layer is
  * CIAOSR_ERR_UNSUPPORTED: run it up to its last hidden layer in fp32 or use the fused head).  Weights are rounded per call from
  * m->weight (single 16-bit weights: the precision of `opt->bf16_single` / the f16 mode).  workspace >= ciaosr_mlp_workspace_bytes_16(m, rows).
  * mlp_refiner.py:87-102. */

@@ -163,6 +163,20 @@ def test_dims_wiring():
         m.init_weights(pretrained=3)
 
 
+def test_reassigned_test_cfg_reaches_the_generator():
+    """`restorer.test_cfg = {...}` (reassignment, what mmedit's apis do before a test run) re-binds the dict the generator reads its
+    extensions from; in-place edits are seen too."""
+    r = _small_restorer(dict(scale=2))
+    g = r.generator
+    assert g._test_cfg is r.test_cfg and r.test_cfg.scale == 2
+    r.test_cfg['allow_f16_substitute'] = True
+    assert g._test_cfg.get('allow_f16_substitute') is True
+    r.test_cfg = dict(scale=3, tile=64)
+    assert g._test_cfg is r.test_cfg and g._test_cfg.get('allow_f16_substitute', False) is False and r.test_cfg.tile == 64
+    r.test_cfg = None
+    assert g._test_cfg is None and r.test_cfg is None
+
+
 def test_tile_grid_matches_reference_lists():
     from ciaosr_amd.restorer import tile_grid, tile_starts
     assert tile_starts(1356, 192, 32) == list(range(0, 1356 - 192, 160)) + [1356 - 192]

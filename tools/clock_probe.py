@@ -1,6 +1,6 @@
 """Developer probe: what clock and power the GPU runs at under one kernel mix.  Loops `restore()` on a 192x192 tile in the given precision
 for SECONDS while sampling `rocm-smi` (sclk, power, temperature) once a second from a child process.
-   python tools/clock_watch.py [f16|bf16|fp32] [seconds]"""
+   python tools/clock_probe.py [f16|bf16|fp32] [seconds]"""
 import os
 import subprocess
 import sys
