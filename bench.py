@@ -180,6 +180,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
         'softmax_stats': (4.0 * HW * (HW / 4), 'byte'),       # one read of the fp32 logit matrix
         'local_attention': (Q * (4.0 * J * D + 4.0 * J * Dv + 4.0 * Dv + 16) + 2.0 * C * 4 * HW, 'byte'),
         'head_rows': (R * 4.0 * 2 * hidden * 2, 'byte'),
+        # K1 as the reference assembles the MLP inputs (21 936 B / query at C = 64): write inp_k, inp_v, q rows; read coords + the feature rows once
+        'gather_rows': (Q * (4.0 * J * (D + 4) + 4.0 * J * (Dv + 4) + 4.0 * D + 16) + 2.0 * C * 4 * HW, 'byte'),
     }
     return table.get(tag)
 
@@ -280,10 +282,10 @@ def _cpu_model():
 
 
 def _thread_counts():
-    """Thread counts the CPU baseline is timed at: 16 (beyond that the port's small ops only add contention on the hosts seen so far)
-    and every core this process may run on ('N = all physical cores'); the faster one is reported."""
+    """Thread counts the CPU baseline is swept over: 16, 32, 64, 128 and every core this process may run on ('N = all physical
+    cores'), capped at what the host has; the fastest is reported.  Each leg is bounded (see cpu_baseline_c3)."""
     a = _avail_cores()
-    return sorted({min(a, 16), a})
+    return sorted({min(a, n) for n in (16, 32, 64, 128)} | {a})
 
 
 def cpu_baseline_c2(scale=4):
@@ -327,17 +329,23 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
     n_chunks = -(-Q // eval_bsize)
     last = (Q - (n_chunks - 1) * eval_bsize) / eval_bsize
     tried, best = {}, None
-    for n_thr in _thread_counts():                                          # the bounded sample at 16 threads and at every core: the faster counts
+    t_sweep = time.perf_counter()
+    for n_thr in _thread_counts():                                          # the bounded sample at 16 / 32 / 64 / 128 / all threads: the fastest counts
+        if best is not None and time.perf_counter() - t_sweep > 150.0:      # the whole baseline leg stays within a few minutes
+            tried[str(n_thr)] = 'not run: sweep budget (150 s) spent'
+            continue
         torch.set_num_threads(n_thr)
         with torch.no_grad():
             orc.encoder_features(x[..., :48, :48], params)                     # warm-up of the thread pool / allocator
             t0 = time.perf_counter()
-            feat = orc.encoder_features(x, params)
+            # the trunk decides whether this thread count goes on (60-s cap, checked between its residual dense blocks)
+            feat = orc.encoder_features(x, params, deadline=t0 + 60.0) if best is not None else orc.encoder_features(x, params)
             t_enc = time.perf_counter() - t0
-            if best is not None and t_enc > 2.0 * best[2]:
-                # a thread count at which the trunk alone is over twice as slow is not going to be the faster one: the rest of its sample
+            if feat is None or (best is not None and t_enc > 1.5 * best[2]):
+                # a thread count at which the trunk alone is this much slower is not going to be the fastest: the rest of its sample
                 # (minutes at 256 threads on a 2 x 64-core host: the port's small ops drown in synchronisation) is not run
-                tried[str(n_thr)] = f'not completed: RDN trunk {t_enc:.1f} s against {best[2]:.1f} s at {best[1]} threads'
+                tried[str(n_thr)] = (f'not completed: RDN trunk ' + ('> 60 s (abandoned)' if feat is None else f'{t_enc:.1f} s') +
+                                     f' against {best[2]:.1f} s at {best[1]} threads')
                 continue
             t0 = time.perf_counter()
             orc.query_rgb(feat, coord, cell, params)                           # one chunk as the reference runs it
@@ -402,6 +410,166 @@ def live_pmc_traffic(kernel_substr, unit_workload, precision, timeout_s=300):
         finally:
             shutil.rmtree(d, ignore_errors=True)
     return round(2.0 * vals['FETCH_SIZE'][0] + vals['WRITE_SIZE'][0]), vals['FETCH_SIZE'][1]
+
+
+STAGED_PMC = os.path.join(REPO, 'profiles', 'r6_c3tile_staged_pmc_hbm_traffic.json')
+STAGED_STATS = os.path.join(REPO, 'profiles', 'r6_c3tile_staged_kernel_stats.csv')
+
+
+def staged_counter_bytes(kernel_substr, waves_per_query):
+    """HBM bytes per query of a one-wave-per-unit staged kernel from the committed rocprofv3 --pmc passes of `bench.py --workload c3tile
+    --head-route as-written` (tools/profile_round.sh -> tools/pmc_summary.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, divided by the
+    launch's wavefronts), or None."""
+    if not os.path.exists(STAGED_PMC):
+        return None
+    hits = [v for k, v in json.load(open(STAGED_PMC)).items() if kernel_substr in k and 'hbm_bytes_per_wave' in v]
+    return hits[0]['hbm_bytes_per_wave'] * waves_per_query if hits else None
+
+
+def staged_rocprof_ms(kernel_substr):
+    """(average ns, calls) of a staged kernel in the committed rocprofv3 --kernel-trace --stats summary, or None."""
+    import csv
+    if not os.path.exists(STAGED_STATS):
+        return None
+    for r in csv.DictReader(open(STAGED_STATS)):
+        if kernel_substr in r['Name']:
+            return float(r['AverageNs']), int(r['Calls'])
+    return None
+
+
+def staged_hbm_rooflines(model, tl, Q, HW, tile_lr, scale, dev):
+    """K1 / K4 of the two staged routes on one tile, HIP events on the launch stream: flat scalars (k4_*, k1_*) for the driver's record plus
+    the per-kernel objects.  K4 = local_attention_kernel<4> (ciaosr_net.py:203-216): Q x 22 064 B; K1 = gather_rows_kernel
+    (ciaosr_net.py:176-196): Q x 21 936 B, both SURVEY 8(d).  `head_rows` is the staged C route's hoisted K1 (layer-1 table rows + the
+    4-column tail instead of the 580 / 644-wide inputs)."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd._lib import HEAD_STAGED
+    out, hb = {}, {}
+
+    def obj(tag, total_ms, key_ms='ms_per_tile'):
+        wk = kernel_work(tag, Q, HW)
+        gbs = wk[0] / (total_ms * 1e-3) / 1e9
+        return dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s', frac=round(gbs / PEAK_HBM_GBS, 4),
+                    algorithmic_bytes_per_query=round(wk[0] / Q), **{key_ms: round(total_ms, 4)})
+    try:
+        staged = hip_ops.Options('fp32', head_route=HEAD_STAGED)
+        model.restore(tl, options=staged)
+        with hip_ops.profile():
+            model.restore(tl, options=staged)
+            torch.cuda.synchronize(dev)
+        st = hip_ops.profile.results()
+        for tag in ('local_attention', 'head_rows'):
+            if tag in st:
+                hb[tag] = obj(tag, st[tag]['total_ms'])
+                hb[tag]['launches'] = st[tag]['launches']
+        # the reference's op order (as-written route): K1 as SURVEY 8(d) prices it, and K4 once more behind the un-hoisted MLPs
+        gen = model.generator
+        x = model.normalize(tl)
+        feat = hip_ops.hwc_to_nchw(gen._encoder_hip.forward_hwc(x[0], None))
+        cc, cl = hip_ops.make_coord_cell(tile_lr * scale, tile_lr * scale, dev)
+        gen._head.forward_as_written(feat, x[0], cc, cl, chunk=gen.eval_bsize)
+        with hip_ops.profile():
+            gen._head.forward_as_written(feat, x[0], cc, cl, chunk=gen.eval_bsize)
+            torch.cuda.synchronize(dev)
+        aw = hip_ops.profile.results()
+        if 'gather_rows' in aw:
+            hb['gather_rows'] = obj('gather_rows', aw['gather_rows']['total_ms'])
+            hb['gather_rows']['launches'] = aw['gather_rows']['launches']
+        if 'local_attention' in aw:
+            hb['local_attention_as_written_route'] = obj('local_attention', aw['local_attention']['total_ms'])
+        del feat, x
+    except Exception as e:                  # noqa: BLE001  (an extra: never the reason a bench line is lost)
+        hb['error'] = repr(e)[:300]
+    # K4 with 16-bit wk / wv / z (ciaosr_local_attention_bf16, SURVEY 8(d): 11 056 B per query): the kernel alone on one staged chunk's
+    # worth of synthetic operands with the indices of a real chunk (neighbouring queries share LR pixels)
+    try:
+        Qc = 30000
+        g_ = torch.Generator(device='cpu').manual_seed(5)
+        U_ = torch.randn(HW, 10 * 64, generator=g_).to(dev)
+        side_ = int(round(HW ** 0.5))
+        cc_, cl_ = hip_ops.make_coord_cell(side_ * 4, side_ * 4, dev)
+        qi_, ki_, _ = hip_ops.head_indices(cc_[:Qc].contiguous(), cl_[:Qc].contiguous(), side_, side_, want_rel=False)
+        wk_ = torch.randn(Qc * 4, 576, generator=g_).to(dev).to(torch.bfloat16)
+        wv_ = torch.randn(Qc * 4, 640, generator=g_).to(dev).to(torch.bfloat16)
+        for _ in range(2):
+            hip_ops.local_attention_16(U_, 64, 64, qi_, ki_, wk_, wv_)
+        with hip_ops.profile():
+            for _ in range(5):
+                hip_ops.local_attention_16(U_, 64, 64, qi_, ki_, wk_, wv_)
+            torch.cuda.synchronize(dev)
+        t16 = hip_ops.profile.results()['local_attention_bf16']['avg_ms']
+        wkf_, wvf_ = wk_.float(), wv_.float()
+        hip_ops.local_attention(U_, 64, 64, qi_, ki_, wkf_, wvf_)
+        with hip_ops.profile():
+            for _ in range(5):
+                hip_ops.local_attention(U_, 64, 64, qi_, ki_, wkf_, wvf_)
+            torch.cuda.synchronize(dev)
+        t32 = hip_ops.profile.results()['local_attention']['avg_ms']
+        del wkf_, wvf_
+        b16 = Qc * (2.0 * 4 * 576 + 2.0 * 4 * 640 + 2.0 * 640 + 16) + 2.0 * 64 * 4 * HW
+        hb['local_attention_bf16'] = dict(bound='hbm', achieved=round(b16 / (t16 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
+                                          frac=round(b16 / (t16 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_chunk=round(t16, 4),
+                                          queries=Qc, bytes_per_query=round(b16 / Qc), fp32_kernel_same_chunk_ms=round(t32, 4))
+        del U_, wk_, wv_
+    except Exception as e:                  # noqa: BLE001
+        hb['local_attention_bf16'] = dict(error=repr(e)[:200])
+    # flat scalars (the driver's record keeps scalars of `roofline`): live HIP-event figures + the committed rocprof / counter evidence
+    k4, k1, k1h = hb.get('local_attention'), hb.get('gather_rows'), hb.get('head_rows')
+    if k4:
+        out.update(k4_hbm_frac=k4['frac'], k4_hbm_gbs=k4['achieved'], k4_ms_per_tile=k4['ms_per_tile'], k4_bytes_per_query=k4['algorithmic_bytes_per_query'])
+    b = staged_counter_bytes('local_attention_kernel<4>', 1)
+    if b:
+        out.update(k4_counter_bytes_per_query=round(b, 1), k4_counter_over_algorithmic=round(b / kernel_work('local_attention', Q, HW)[0] * Q, 3))
+    r = staged_rocprof_ms('local_attention_kernel<4>')
+    if r:       # the committed --stats row: average launch of one eval_bsize chunk (the tile's 20 launches: 19 x 30 000 + 19 824 queries)
+        out.update(k4_rocprof_avg_launch_ms=round(r[0] / 1e6, 4),
+                   k4_rocprof_hbm_frac=round(kernel_work('local_attention', Q, HW)[0] / -(-Q // 30000) / (r[0] * 1e-9) / 1e9 / PEAK_HBM_GBS, 4))
+    if k1:
+        out.update(k1_hbm_frac=k1['frac'], k1_hbm_gbs=k1['achieved'], k1_ms_per_tile=k1['ms_per_tile'], k1_bytes_per_query=k1['algorithmic_bytes_per_query'])
+    b = staged_counter_bytes('gather_rows_kernel', 4)
+    if b:
+        out.update(k1_counter_bytes_per_query=round(b, 1))
+    if k1h:
+        out.update(k1_hoisted_hbm_frac=k1h['frac'])
+    if 'frac' in hb.get('local_attention_bf16', {}):
+        out.update(k4_16bit_hbm_frac=hb['local_attention_bf16']['frac'])
+    out['staged_path_hbm_kernels'] = hb
+    return out
+
+
+def scale_model(model, ms_1gpu, n_tiles, hh, ww, dev, link_gbs=48.0):
+    """What the tile-sharded C4 run should show, from THIS run's single-GPU measurements (no multi-GPU hardware on this pool: a prediction
+    the driver's eventual 8-GPU SCALE run can be compared with, not a measurement).  Per image rank 0 does everything only it can do --
+    every tile's blend, tile_finalize, denorm_clamp (t_rank0_only, timed here on scratch buffers) -- plus its own tiles; a peer computes
+    its tiles and hands each 768 x 768 x 3 fp32 output (7.08 MB) to rank 0 over its own xGMI link under the next tile's compute, so only the
+    LAST tile's transfer is exposed (7.08 MB / `link_gbs`, one direction of one link; ~153 GB/s aggregate per link pair, 48 taken as a
+    conservative RCCL point-to-point rate).  predicted = max over ranks; efficiency = t(1) / (N t(N))."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.tile_shard import partition
+    E = torch.zeros(3, hh, ww, device=dev)
+    Wt = torch.ones_like(E)
+    tile_out = torch.zeros(768 * 768, 3, device=dev)
+
+    def extra():
+        for _ in range(n_tiles):
+            hip_ops.tile_blend(E, Wt, tile_out, 0, 0, 768, 768)
+        hip_ops.denorm_clamp(hip_ops.tile_finalize(E, Wt), hh, ww, model.rgb_mean, model.rgb_std)
+    extra()
+    t_extra = time_steps(extra, 2, dev)
+    del E, Wt, tile_out
+    t_tile = (ms_1gpu - t_extra) / n_tiles
+    tile_mb = 768 * 768 * 3 * 4 / 1e6
+    t_xfer = tile_mb / 1e3 / link_gbs * 1e3
+    out = dict(note='PREDICTION from the 1-GPU measurements of this run (strong scaling of the one C3 image, tile t -> rank t mod N, rank 0 blends)',
+               ms_per_tile_compute=round(t_tile, 3), rank0_only_ms_per_image=round(t_extra, 3), tile_mb=round(tile_mb, 2),
+               exposed_transfer_ms=round(t_xfer, 3), link_gbs_assumed=link_gbs)
+    for n in (2, 4, 8):
+        parts = [len(p_) for p_ in partition(n_tiles, n, 1.0)]
+        t_rank = [parts[0] * t_tile + t_extra + t_xfer] + [k * t_tile + t_xfer for k in parts[1:]]
+        t_n = max(t_rank)
+        out[f'n{n}'] = dict(tiles_per_rank=parts, predicted_ms_per_step=round(t_n, 1), predicted_mpix_s=round(hh * ww / 1e6 / (t_n * 1e-3), 2),
+                            predicted_efficiency=round(ms_1gpu / (n * t_n), 4), critical_rank=int(max(range(n), key=lambda r: t_rank[r])))
+    return out
 
 
 def other_configs(dev):
@@ -509,6 +677,11 @@ def main():
                     help='N > 1, tile sharding: fraction of the full rounds rank 0 (which also blends every tile and finalizes the image) '
                          'takes a tile in (tile_shard.tile_owners; it always sits out the ragged last round); a number in [0, 1], or "auto": '
                          'rank 0 times its blend + finalize + de-normalise work against a tile and every rank takes its answer')
+    ap.add_argument('--head-route', default='fused', choices=['fused', 'staged', 'as-written', 'as-written-bf16', 'as-written-f16'],
+                    help='one-tile workloads only (c3tile / c2), for profiling the HBM-bound staged kernels under rocprofv3: staged = the per-layer '
+                         'GEMM route of the C library (head_rows K1\', local_attention K4); as-written = the reference\'s op order through the staged '
+                         'entry points (gather_rows K1 -> imnet_k / imnet_v -> local_attention K4 -> imnet_q), -bf16 / -f16: with the 16-bit MLP and '
+                         'K4 entry points.  The headline route is `fused`')
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS),
                     help='c3 (default; the config BASELINE.json\'s metric is quoted on): LR 1356x2040, 117 tiles; c3s: LR 339x510 (6 tiles); '
                          'c3tile: one 192x192 LR tile; c2: LR 48x48 (BASELINE configs[1]); c2q: C2 with its query range sharded over the ranks '
@@ -554,7 +727,11 @@ def main():
         # ranks as the communicator itself counts them: an all-reduce of ones over RCCL (also: the communicator exists before the
         # first grouped point-to-point call)
         rccl_ranks = ensure_communicator(None, dev)
-        assert rccl_ranks == world == dist.get_world_size()
+        if not (rccl_ranks == world == dist.get_world_size() == args.gpus):
+            # one clear line, non-zero exit: a bench line whose value was produced by fewer ranks than --gpus must never be printed
+            print(f'bench.py: FATAL: --gpus {args.gpus} but the {backend} communicator counts {rccl_ranks} rank(s) '
+                  f'(WORLD_SIZE {world}, torch.distributed world {dist.get_world_size()}); no result line printed', file=sys.stderr, flush=True)
+            sys.exit(4)
 
     from ciaosr_amd import hip_ops, _lib
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
@@ -562,6 +739,12 @@ def main():
     from ciaosr_amd.coords import make_coord, make_cell
     _lib.load()
     opt = hip_ops.Options(args.precision, bf16_single=int(args.bf16_single and args.precision == 'bf16'))
+    if args.head_route != 'fused':
+        if world > 1 or args.workload not in ('c3tile', 'c2'):
+            raise SystemExit('--head-route staged / as-written* is a one-tile, one-GPU profiling workload (--workload c3tile or c2)')
+        if args.head_route == 'staged':
+            from ciaosr_amd._lib import HEAD_STAGED
+            opt = opt.replace(head_route=HEAD_STAGED)
 
     scale = 4
     lr_h, lr_w, n_tiles_img, wl_desc = WORKLOADS[args.workload]
@@ -604,9 +787,22 @@ def main():
         dist.broadcast_object_list(box, src=0)
         return box[0]
 
+    def step_as_written():
+        """One tile in the reference's op order through the staged entry points (PackedHead.forward_as_written): trunk -> cs_attn -> per
+        eval_bsize chunk [K1 gather_rows -> imnet_k, imnet_v -> K4 local_attention -> imnet_q -> last Linear + bilinear residual]."""
+        gen = model.generator
+        half = {'as-written': None, 'as-written-bf16': 'bf16', 'as-written-f16': 'f16'}[args.head_route]
+        x = model.normalize(lq)
+        feat = hip_ops.hwc_to_nchw(gen._encoder_hip.forward_hwc(x[0], opt))
+        cc, cl = hip_ops.make_coord_cell(lr_h * scale, lr_w * scale, dev)
+        rgb = gen._head.forward_as_written(feat, x[0], cc, cl, chunk=gen.eval_bsize, options=opt, half=half)
+        return hip_ops.denorm_clamp(rgb.contiguous(), lr_h * scale, lr_w * scale, model.rgb_mean, model.rgb_std)
+
     def step():
         if watchdog is not None:
             watchdog.beat()
+        if args.head_route.startswith('as-written'):
+            return step_as_written()
         if world == 1:
             return model.restore(lq, options=opt)
         x = model.normalize(lq)
@@ -831,58 +1027,10 @@ def main():
                     line['exposed_tail_ms'] = round(tail['last_own_tile'].elapsed_time(tail['ready']), 3)
         if world == 1 and not args.no_extras and roof is not None:
             extras = {}
-            # (1) the HBM-bound kernels of the staged route (north star: >= 40 % of the HBM roofline on the local-attention
-            # kernel K4) on ONE tile of this workload right after the timed region: one staged pass, HIP events
-            from ciaosr_amd._lib import HEAD_STAGED
+            # (1) the HBM-bound kernels of the staged routes (north star: >= 40 % of the HBM roofline on the local-attention kernel K4;
+            # K1 gather-rows and K4 are the HBM-bound stages) on ONE tile of this workload right after the timed region
             tl = synthetic_pair(tile_lr, tile_lr, scale)[0].to(dev)
-            staged = hip_ops.Options('fp32', head_route=HEAD_STAGED)
-            model.restore(tl, options=staged)
-            with hip_ops.profile():
-                model.restore(tl, options=staged)
-                torch.cuda.synchronize(dev)
-            st = hip_ops.profile.results()
-            hb = {}
-            for tag in ('local_attention', 'head_rows'):
-                wk = kernel_work(tag, Q, HW)
-                if tag in st and wk:
-                    gbs = wk[0] / (st[tag]['total_ms'] * 1e-3) / 1e9
-                    hb[tag] = dict(bound='hbm', achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                   frac=round(gbs / PEAK_HBM_GBS, 4), ms_per_tile=round(st[tag]['total_ms'], 4))
-            # K4 with 16-bit wk / wv / z (ciaosr_local_attention_bf16, SURVEY 8(d): 11 056 B per query): the kernel alone on one staged chunk's
-            # worth of synthetic operands (the staged route itself stays fp32)
-            try:
-                Qc = 30000
-                g_ = torch.Generator(device='cpu').manual_seed(5)
-                U_ = torch.randn(HW, 10 * 64, generator=g_).to(dev)
-                # the indices of a real chunk: the first 30 000 queries of the tile's x4 target grid (neighbouring queries share LR pixels)
-                side_ = int(round(HW ** 0.5))
-                cc_, cl_ = hip_ops.make_coord_cell(side_ * 4, side_ * 4, dev)
-                qi_, ki_, _ = hip_ops.head_indices(cc_[:Qc].contiguous(), cl_[:Qc].contiguous(), side_, side_, want_rel=False)
-                wk_ = torch.randn(Qc * 4, 576, generator=g_).to(dev).to(torch.bfloat16)
-                wv_ = torch.randn(Qc * 4, 640, generator=g_).to(dev).to(torch.bfloat16)
-                for _ in range(2):
-                    hip_ops.local_attention_16(U_, 64, 64, qi_, ki_, wk_, wv_)
-                with hip_ops.profile():
-                    for _ in range(5):
-                        hip_ops.local_attention_16(U_, 64, 64, qi_, ki_, wk_, wv_)
-                    torch.cuda.synchronize(dev)
-                t16 = hip_ops.profile.results()['local_attention_bf16']['avg_ms']
-                wkf_, wvf_ = wk_.float(), wv_.float()
-                hip_ops.local_attention(U_, 64, 64, qi_, ki_, wkf_, wvf_)
-                with hip_ops.profile():
-                    for _ in range(5):
-                        hip_ops.local_attention(U_, 64, 64, qi_, ki_, wkf_, wvf_)
-                    torch.cuda.synchronize(dev)
-                t32 = hip_ops.profile.results()['local_attention']['avg_ms']
-                del wkf_, wvf_
-                b16 = Qc * (2.0 * 4 * 576 + 2.0 * 4 * 640 + 2.0 * 640 + 16) + 2.0 * 64 * 4 * HW
-                hb['local_attention_bf16'] = dict(bound='hbm', achieved=round(b16 / (t16 * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s',
-                                                  frac=round(b16 / (t16 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), ms_per_chunk=round(t16, 4),
-                                                  queries=Qc, bytes_per_query=round(b16 / Qc), fp32_kernel_same_chunk_ms=round(t32, 4))
-                del U_, wk_, wv_
-            except Exception as e:                  # noqa: BLE001  (an extra: never the reason a bench line is lost)
-                hb['local_attention_bf16'] = dict(error=repr(e)[:200])
-            roof['staged_path_hbm_kernels'] = hb
+            roof.update(staged_hbm_rooflines(model, tl, Q, HW, tile_lr, scale, dev))
             # (2) the other precision / the other single-tile config, for the record (not the headline); every 16-bit figure carries
             # the roofline object of ITS dominant kernel (one profiled pass of the same input)
             def mode_roofline(inp, o, precision, n_t):
@@ -967,6 +1115,18 @@ def main():
                 line['cpu_baseline'] = cpu_baseline_c2(scale)
             else:
                 line['cpu_baseline'] = cpu_baseline_c3(n_tiles_img, out_pixels, scale)
+        if world == 1 and args.workload == 'c3' and args.head_route == 'fused':
+            line['scale_model'] = scale_model(model, ms, n_tiles_img, lr_h * scale, lr_w * scale, dev)
+        # key order of the printed line: the contract's keys, the flat roofline scalars, the CPU baseline and the scaling model FIRST; the bulky
+        # per-kernel tables and extras last (a consumer that keeps only the head or only the tail of a > 16-KB line still gets the headline)
+        if line.get('roofline'):
+            ro = line['roofline']
+            line['roofline'] = {**{k: v for k, v in ro.items() if not isinstance(v, (dict, list))},
+                                **{k: v for k, v in ro.items() if isinstance(v, (dict, list))}}
+        tail_keys = ('kernels_ms_per_step', 'rccl_probe', 'extras')
+        line = {**{k: v for k, v in line.items() if k not in tail_keys and k != 'roofline'},
+                **({'roofline': line['roofline']} if 'roofline' in line else {}),
+                **{k: line[k] for k in tail_keys if k in line}}
         print(json.dumps(line), flush=True)
     if world > 1:
         watchdog.beat()

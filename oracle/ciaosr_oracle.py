@@ -222,12 +222,17 @@ def _conv(x, params, name, pad):
     return F.conv2d(x, params[name + '.weight'], params[name + '.bias'], padding=pad)
 
 
-def rdn_features(x, params):
+def rdn_features(x, params, deadline=None):
+    """`deadline` (time.perf_counter() value; bench.py's cpu_baseline thread sweep only): give up -- return None -- once it has passed,
+    checked between residual dense blocks."""
+    import time
     s1 = _conv(x, params, 'sfe1', 1)
     h = _conv(s1, params, 'sfe2', 1)
     nb = 1 + max(int(k.split('.')[1]) for k in params if k.startswith('rdbs.'))
     local = []
     for b in range(nb):
+        if deadline is not None and time.perf_counter() > deadline:
+            return None
         nl = 1 + max(int(k.split('.')[3]) for k in params if k.startswith(f'rdbs.{b}.layers.'))
         t = h
         for l in range(nl):
@@ -247,9 +252,9 @@ def edsr_features(x, params, res_scale=1.0):
     return _conv(h, params, 'conv_after_body', 1) + f
 
 
-def encoder_features(x, params):
+def encoder_features(x, params, deadline=None):
     if 'sfe1.weight' in params:
-        return rdn_features(x, params)
+        return rdn_features(x, params, deadline)
     if 'conv_first.weight' in params and 'body.0.conv1.weight' in params:
         return edsr_features(x, params)
     raise KeyError('unknown encoder parameter naming')

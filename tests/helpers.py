@@ -11,6 +11,15 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 SQRT6 = math.sqrt(6.0)
 
 
+def free_port():
+    """A TCP port the OS hands out as free right now, for a torch.distributed rendezvous on 127.0.0.1 (fixed port numbers collide with other
+    jobs on a shared box -- and with a previous test's listener still in TIME_WAIT)."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        return sock.getsockname()[1]
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'))
     return {k: z[k] for k in z.files}

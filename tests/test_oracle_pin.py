@@ -195,3 +195,18 @@ def test_sensitivity_of_fixture():
     P = weights_from(fx)
     out = orc.query_rgb(_t(fx['feature']), _t(fx['coord']), _t(fx['cell']), P, softmax_scale=1e9)
     assert (out - _t(fx['out'])).abs().max() > 5e-2
+
+
+def test_full_width_intermediates_match_reference():
+    """The oracle's z (local attention output = imnet_q's argument) and its RGB on the 256 sampled queries of `k4_c64_x4` against the
+    reference's own intermediates (module hooks on the unmodified reference, tools/make_golden.py::gen_k4_c64): full model widths
+    (C = 64: 576 / 640), the sqrt(6)-gain fixture's logits of std ~40."""
+    fx = load_golden('k4_c64_x4')
+    P = seeded_head(64, int(fx['weight_seed']))
+    feat = randn((1, 64, 48, 48), fx['feat_seed'])
+    ht, wt = [int(v) for v in fx['target']]
+    idx = _t(fx['idx']).long()
+    coord, cell = make_coord((ht, wt))[idx].unsqueeze(0), make_cell((ht, wt))[idx].unsqueeze(0)
+    out, inter = orc.query_rgb(feat, coord, cell, P, return_intermediates=True)
+    assert (inter['z'][0] - _t(fx['z'])).abs().max() < 5e-5 * max(1.0, float(np.abs(fx['z']).max()))
+    assert (out[0] - _t(fx['out'])).abs().max() < 1e-4

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from tests.helpers import load_golden, weights_from
+from tests.helpers import free_port, load_golden, weights_from
 
 
 def _cpu_blend(E, Wt, out, y0, x0, th, tw):
@@ -63,7 +63,7 @@ def test_two_rank_gloo_equals_single_process_bitwise():
     single = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, 29591, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, free_port(), ret), nprocs=2, join=True)
     assert torch.equal(ret['out'], single)
     # and both equal the reference's own tiled output (after denorm/clamp)
     mean = torch.tensor((0.4488, 0.4371, 0.4040)).view(1, 1, 3)
@@ -82,7 +82,7 @@ def test_ragged_rounds_and_lighter_rank0_shares_are_bitwise_the_single_process_r
     single = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29597 + world, ret, share), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), ret, share), nprocs=world, join=True)
     assert torch.equal(ret['out'], single)
     assert len(partition(12, world, share)[0]) == {(3, 1.0): 4, (3, 0.5): 2, (4, 0.0): 0}[(world, share)]
 
@@ -131,7 +131,7 @@ def test_step_deadline_ends_a_rank_whose_peer_never_delivers():
     import time
     t0 = time.time()
     with pytest.raises(Exception) as err:
-        mp.spawn(_hung_peer_worker, args=(2, 29611), nprocs=2, join=True)
+        mp.spawn(_hung_peer_worker, args=(2, free_port()), nprocs=2, join=True)
     assert 'exit code 3' in str(err.value), str(err.value)
     assert time.time() - t0 < 18
 
@@ -184,7 +184,7 @@ def test_query_sharded_two_rank_gloo_equals_single_process():
     single = query_sharded_predict(feature_fn, predict_fn, coord, cell, 0, 1, chunk=200)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_query_worker, args=(2, 29593, ret), nprocs=2, join=True)
+    mp.spawn(_query_worker, args=(2, free_port(), ret), nprocs=2, join=True)
     # the torch-CPU stand-in head is not bitwise row-independent (GEMM blocking depends on the row count); the HIP head is
     # (bench.py asserts bitwise equality on the GPU)
     assert (ret['out'] - single).abs().max() < 1e-5
@@ -215,7 +215,7 @@ def test_image_sharded_eval_results_are_collected_in_dataset_order():
     from ciaosr_amd.dataset import SRFolderDataset
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_collect_worker, args=(2, 29595, ret), nprocs=2, join=True)
+    mp.spawn(_collect_worker, args=(2, free_port(), ret), nprocs=2, join=True)
     single = [dict(eval_result=dict(PSNR=float(10 + i), SSIM=0.1 * i)) for i in range(7)]
     assert ret['out'] == single
     assert SRFolderDataset.evaluate(ret['out']) == SRFolderDataset.evaluate(single)
@@ -261,5 +261,5 @@ def test_loopback_on_a_one_rank_group_runs_the_exchange_code_and_is_bitwise():
     single = sharded_clip_test(shape, 48, 16, 2, tile_fn, _cpu_blend, _cpu_finalize, 0, 1)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_loopback_worker, args=(1, 29621, ret), nprocs=1, join=True)
+    mp.spawn(_loopback_worker, args=(1, free_port(), ret), nprocs=1, join=True)
     assert torch.equal(ret['out'], single)

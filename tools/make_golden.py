@@ -134,6 +134,41 @@ def gen_head_c64(ref):
          weight_seed=np.array(0), target=np.array([ht, wt]))
 
 
+def gen_k4_c64(ref):
+    """Full-width K1 / K4 reference vectors: the model and feature map of `head_c64_x4` (weight seed 0, feature seed 7; nothing but the
+    seeds is needed to rebuild them), 256 queries sampled from its 36 864; the REFERENCE's own intermediates of one query_rgb call on them,
+    taken with module hooks (no reference code changed): inp_k / inp_v = the arguments of imnet_k / imnet_v (ciaosr_net.py:195-202; first 64
+    queries only), wk / wv = their outputs (:202, :205), z = the argument of imnet_q (:211-221: softmax(q . (key * wk)) @ (value * wv))."""
+    m = edsr_generator(ref, mid=64, blocks=1).eval()
+    sha = seeded_init_(m, seed=0, gain=1.0, head_gain=SQRT6)
+    feat = randn((1, 64, 48, 48), 7)
+    coord, cell, (ht, wt) = coords_for(48, 48, 4)
+    idx = torch.randperm(ht * wt, generator=torch.Generator().manual_seed(41))[:256].sort().values
+    # queries on the image border included (clamped shifts): force the four corners and two edge mid-points in
+    idx[:6] = torch.tensor([0, wt - 1, (ht - 1) * wt, ht * wt - 1, wt // 2, (ht // 2) * wt])
+    idx = idx.sort().values
+    cap = dict(inp_k=[], inp_v=[], wk=[], wv=[], z=[])
+    def tap(inp_key, out_key):
+        def hook(mod, a, o):                              # returns None: the module's output is left alone
+            cap[inp_key].append(a[0].detach().clone())
+            cap[out_key].append(o.detach().clone())
+        return hook
+
+    def tap_q(mod, a):
+        cap['z'].append(a[0].detach().clone())
+    hooks = [m.imnet_k.register_forward_hook(tap('inp_k', 'wk')), m.imnet_v.register_forward_hook(tap('inp_v', 'wv')),
+             m.imnet_q.register_forward_pre_hook(tap_q)]
+    with torch.no_grad():
+        out = m.query_rgb([feat], coord[:, idx], cell[:, idx])
+    for h in hooks:
+        h.remove()
+    assert len(cap['wk']) == 4 and len(cap['wv']) == 4 and len(cap['z']) == 1
+    stack = lambda lst: torch.stack(lst, dim=1)           # four shifts -> [256, 4, width], (query, sample) rows like the C ABI's
+    save('k4_c64_x4', idx=idx, wk=stack(cap['wk']), wv=stack(cap['wv']), z=cap['z'][0], out=out[0],
+         inp_k=stack(cap['inp_k'])[:64], inp_v=stack(cap['inp_v'])[:64], sha=np.array(sha), feat_seed=np.array(7),
+         weight_seed=np.array(0), target=np.array([ht, wt]))
+
+
 def gen_head_c64_x3p3(ref):
     """Non-integer scale with rounding ties: LR 48x48 -> 158x158."""
     m = edsr_generator(ref, mid=64, blocks=1).eval()
@@ -200,6 +235,29 @@ def gen_head_c180(ref):
         out = m.batched_predict([feat], coord, cell)
     save('head_c180_x3p3', out=out[0], sha=np.array(sha), feat_seed=np.array(8), weight_seed=np.array(5),
          target=np.array([ht, wt]))
+
+
+def gen_head_c180_stress(ref):
+    """The SwinIR-width head (C = 180: 1620 / 1624 / 1804 / 1800) on a feature map with TRAINED-LIKE statistics -- what BASELINE config 5's
+    16-bit modes must survive and the Gaussian `head_c180_x3p3` does not show: per-channel log-normal scales (std 0.6 .. 60, overall ~10),
+    per-channel DC offsets, a step edge down the middle, magnitudes > 100; default-init-scale head weights (head_gain 1, as in the RDN stress
+    fixtures).  LR 24x24 -> x3.3 through the reference's batched_predict; the feature map is stored (its exp() would not be host-stable)."""
+    m = edsr_generator(ref, mid=180, blocks=1).eval()
+    sha = seeded_init_(m, seed=6, gain=1.0, head_gain=1.0)
+    g = torch.Generator().manual_seed(9)
+    base = torch.randn((1, 180, 24, 24), generator=g)
+    zc = torch.randn(180, generator=g)
+    sc = torch.tensor([10.0 * math.exp(0.9 * z - 0.81) for z in zc.double().tolist()], dtype=torch.float64).float()
+    off = torch.randn(180, generator=g) * 5.0
+    feat = base * sc.view(1, -1, 1, 1) + off.view(1, -1, 1, 1)
+    feat[..., :, 12:] += (torch.randn(180, generator=g) * 8.0).view(1, -1, 1, 1)           # step edge
+    coord, cell, (ht, wt) = coords_for(24, 24, 3.3)
+    with torch.no_grad():
+        nl = m.cs_attn(feat)
+        out = m.batched_predict([feat], coord, cell)
+    print(f'  head_c180_stress: feature std {feat.std():.2f} max {feat.abs().max():.1f}; non-local std {nl.std():.2f} max {nl.abs().max():.1f}; '
+          f'out std {out.std():.3f} range [{out.min():.2f}, {out.max():.2f}]')
+    save('head_c180_stress_x3p3', out=out[0], feature=feat, sha=np.array(sha), weight_seed=np.array(6), target=np.array([ht, wt]))
 
 
 def gen_csattn_big(ref):
@@ -453,7 +511,7 @@ def gen_swinir48(ref):
 
 ALL = dict(tiny_head=gen_tiny_head, tiny_variants=gen_tiny_head_variants, tiny_act=gen_tiny_head_act, csattn_scales=gen_csattn_scales, head_c64=gen_head_c64,
            head_c64_x3p3=gen_head_c64_x3p3, nearest_idx=gen_nearest_idx, csattn=gen_csattn,
-           head_c180=gen_head_c180, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir, swinir48=gen_swinir48, stress=gen_stress)
+           head_c180=gen_head_c180, k4_c64=gen_k4_c64, head_c180_stress=gen_head_c180_stress, e2e=gen_e2e, csattn_big=gen_csattn_big, e2e_tile192=gen_e2e_tile192, tiling=gen_tiling, swinir=gen_swinir, swinir48=gen_swinir48, stress=gen_stress)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()

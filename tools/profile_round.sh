@@ -2,7 +2,7 @@
 # Round profile capture on the GPU box: default bench line (C3) + rocprofv3 kernel stats + HBM-traffic PMC passes.
 #   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r2 [quick]'
 # Writes gpurun_out/prof_<tag>/...; copy the summaries to profiles/ afterwards (tools/trace_summary.py, pmc_summary.py).
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
@@ -29,6 +29,10 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --no-live-pmc --no-cpu-baseline --no-extras --no-rccl-probe --workload c3tile --steps 2 --warmup 1 > /dev/null 2> $O/pmc_write.err
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -o q -- python3 $R/bench.py --no-live-pmc --no-cpu-baseline --no-extras --no-rccl-probe --workload c3tile --steps 2 --warmup 1 > /dev/null 2> $O/pmc_sq.err
 fi
+# K1 / K4 of the staged routes (north star: >= 40 % of the HBM roofline on the local-attention kernel) on the C3 tile: kernel stats + FETCH / WRITE
+# counters of `--head-route as-written` (gather_rows_kernel = K1, local_attention_kernel<4> = K4), `staged` (head_rows_kernel = the hoisted K1)
+# and `as-written-bf16` / `-f16` (local_attention_h16_kernel); summarise with tools/staged_summary.sh -> profiles/<tag>_c3tile_staged_*
+bash $R/tools/profile_staged.sh $TAG
 # keep the merge-back small: the per-launch traces are only needed as the stats CSVs / counter CSVs
 find $O -name "*kernel_trace.csv" -path "*pmc*" -delete
 find $O -name "*kernel_trace.csv" -size +20M -delete
