@@ -1056,12 +1056,12 @@ def main():
                 return ro
 
             if args.workload in ('c3', 'c3s', 'c3tile'):
-                modes = [('bf16', hip_ops.Options('bf16'), 'bf16'), ('f16', hip_ops.Options('f16'), 'f16'),
-                         ('f16_pairs', hip_ops.Options('f16-pairs'), 'f16-pairs')]
+                modes = [('bf16', hip_ops.Options('bf16'), 'bf16'), ('bf16_single', hip_ops.Options('bf16-single'), 'bf16-single'),
+                         ('f16', hip_ops.Options('f16'), 'f16'), ('f16_pairs', hip_ops.Options('f16-pairs'), 'f16-pairs')]
                 if 'f16x3' in hip_ops.PRECISIONS:
                     modes.append(('f16x3', hip_ops.Options('f16x3'), 'f16x3'))
                     modes.append(('f16x3_fast', hip_ops.Options('f16x3-fast'), 'f16x3-fast'))
-                o16, oh = modes[0][1], modes[1][1]
+                o16, oh = modes[0][1], modes[2][1]
                 for nm, o, prec in modes:
                     model.restore(tl, options=o)
                     extras[f'c3_tile_{nm}_mode_ms'] = round(time_steps(lambda: model.restore(tl, options=o), 3, dev), 3)

@@ -474,6 +474,286 @@ __global__ __launch_bounds__(256, 2) void dense_h16_dma_kernel(DenseH16P p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the layer re-cut around the L2 -> CU DELIVERY limit (dense_h16_wide_kernel).
+//
+// Both kernels above stream every weight fragment of the layer from L2 into EVERY 12x12-pixel workgroup: per 64-channel input group a
+// workgroup moves 72 KB of weights + 25 KB of halo patch for 2592 CU-cycles of MFMA issue = 37 B/clk per CU, against the 21 B/clk per CU that
+// L2 delivers to fragments every CU streams (tools/ubench/l2_stream.hip): an operand-delivery ceiling of ~57 % before any latency, and the
+// K-slice reduction through LDS (164 KB written and read back per workgroup and layer) on top.  Here
+//   * a workgroup = 512 threads = ONE per CU owns a 16 x 32-pixel tile (16 MFMA pixel tiles: one per tile row) x all 64 output channels:
+//     3.6x the pixels per weight byte, halo factor 1.20 instead of 1.36 -> 16 B/clk per CU at the full MFMA rate;
+//   * the waves split PIXELS, not K: wave w owns tile rows 2w, 2w + 1 and both output-channel halves (4 accumulator tiles, 64 registers);
+//     every product of an output is summed inside one accumulator -- no K-slice reduction, no second pass through LDS;
+//   * weights AND halo patch of a STAGE -- 32 input channels (two k16 steps; 16 channels when every weight is a hi + lo pair) -- come by
+//     LDS-DMA (`buffer_load_dwordx4 ... lds`, 1-KB pieces: a pre-packed weight fragment IS one piece) into one of two stage buffers while
+//     the previous stage computes; all eight waves read the same weight fragments from LDS (ds_read_b128 of lane-contiguous 1-KB blocks:
+//     conflict-free), activations from the patch, whose 16-B channel chunks are XOR-swizzled with the pixel index on the SOURCE side of the
+//     DMA so that every 16-lane group of a ds_read_b128 touches 16 distinct bank quads (brute-forced below in wide_swizzle_ok);
+//     LDS reads: 2 weight + 2 activation fragments per 4 MFMAs = 128 B/clk per CU at the full rate (half the LDS peak);
+//   * one barrier per stage; the DMA pieces of stage n + 1 (<= 10 per wave) are issued one per tap between the MFMAs of stage n;
+//   * PERSISTENT workgroups walk (image, tile) items b, b + grid, ...: the next item's first stage lands during the current item's last
+//     one, and the batch fills the chip evenly (7 images x 72 tiles of a 192x192 map = 504 items on 256 CUs: 98 %);
+//   * epilogue per item: bias + ReLU in the accumulator layout, then a per-wave 4-KB LDS transpose so that the stores leave as whole
+//     128-B lines (16-bit copy always; fp32 copy when the caller keeps one).
+// Per image the MACs and their order depend on the tile position only (stage order rotated by the tile index, like above): a tile's
+// result does not depend on the batch it is computed in.  Summation order differs from the 12x12 kernels (no K split): same products.
+constexpr int WTH = 16, WTW = 32;                // output tile (pixels)
+constexpr int WPH = WTH + 2, WPW = WTW + 2;      // with the 1-pixel halo
+constexpr int WNPIX = WPH * WPW;                 // 612
+
+template <int KS> struct WideGeom {              // KS = k16 steps per stage: 2 (one 16-bit weight per product) or 1 (hi + lo pairs)
+    static constexpr int NW = 2 / KS;                                   // weight sets
+    static constexpr int CPP = 2 * KS;                                  // 16-B chunks per patch pixel and stage
+    static constexpr int PIX_BYTES = 16 * CPP;
+    static constexpr int PATCH_PIECES = (WNPIX * CPP + 63) / 64;        // 39 / 20
+    static constexpr int PATCH_BYTES = PATCH_PIECES * 1024;
+    static constexpr int W_PIECES = 9 * KS * 2 * NW;                    // 36
+    static constexpr int STAGE_BYTES = PATCH_BYTES + W_PIECES * 1024;   // 76 800 / 57 344
+    static constexpr int PIECES = PATCH_PIECES + W_PIECES;              // 75 / 56
+    static constexpr int SLOTS = (PIECES + 7) / 8;                      // DMA pieces per wave and stage: 10 / 7
+    static constexpr int PSLOTS = (PATCH_PIECES + 7) / 8;               // ... of which patch pieces (per-lane source offsets): 5 / 3
+    static constexpr int FMASK = CPP - 1;
+    static constexpr int FSHIFT = KS == 2 ? 2 : 3;                      // swizzle key of pixel P: (P >> FSHIFT) & FMASK
+    static constexpr size_t LDS = 2 * (size_t)STAGE_BYTES;              // 153 600 / 114 688
+};
+
+// every 16-lane group of the activation ds_read_b128 of every (tile row, tap) must touch 16 distinct 16-B bank quads
+template <int KS>
+constexpr bool wide_swizzle_ok() {
+    using G = WideGeom<KS>;
+    constexpr int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                   {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    for (int y = 0; y < WTH; ++y)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int ks = 0; ks < KS; ++ks)
+                for (int g = 0; g < 4; ++g) {
+                    unsigned seen = 0;
+                    for (int i = 0; i < 16; ++i) {
+                        const int lane = groups[g][i], li = lane & 31, lh = lane >> 5;
+                        const int P = (y + tap / 3) * WPW + li + tap % 3;
+                        const int j = (KS == 2 ? 2 * ks + lh : lh) ^ ((P >> G::FSHIFT) & G::FMASK);
+                        const int quad = ((P * G::PIX_BYTES + 16 * j) >> 4) & 15;
+                        if (seen & (1u << quad)) return false;
+                        seen |= 1u << quad;
+                    }
+                }
+    return true;
+}
+static_assert(wide_swizzle_ok<2>() && wide_swizzle_ok<1>(), "activation reads of the wide dense kernel must be bank-conflict-free");
+
+struct DenseWideP {
+    DenseH16P d;
+    int tiles_x, tiles_per_img, n_items;        // 16x32 tiles per image row / per image; (image, tile) items of the launch
+    unsigned wf_bytes;                           // bytes of one weight fragment array (2 * nks KB)
+};
+
+template <bool LO>
+__global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
+    constexpr int KS = LO ? 1 : 2;
+    using G = WideGeom<KS>;
+    constexpr int NW = G::NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const DenseH16P& p = pp.d;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
+    const unsigned img_bytes = (unsigned)((size_t)p.H * p.W * p.ldxb * 2);
+    const i32x4 desc_x = {(int)(unsigned)(size_t)p.xb, (int)(((size_t)p.xb >> 32) & 0xFFFFu), (int)p.xb_bytes, 0x00020000};
+    const i32x4 desc_w = {(int)(unsigned)(size_t)p.wf, (int)(((size_t)p.wf >> 32) & 0xFFFFu), (int)pp.wf_bytes, 0x00020000};
+    const void* wlo = LO ? (const void*)p.wf_lo : (const void*)p.wf;
+    const i32x4 desc_wl = {(int)(unsigned)(size_t)wlo, (int)(((size_t)wlo >> 32) & 0xFFFFu), (int)pp.wf_bytes, 0x00020000};
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int NST = p.groups * (4 / KS);         // stages of the layer
+    const int kpt = 4 * p.groups;                // k16 steps per tap
+
+    auto dma = [&](unsigned dst, unsigned voff, const i32x4& desc) {
+        unsigned keep;
+        const unsigned sdst = __builtin_amdgcn_readfirstlane(dst);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sdst), "s"(desc) : "memory");
+    };
+    // per-lane source offsets of this wave's patch pieces for the tile at (ty0, tx0): piece q = w + 8 s fills LDS chunks 64 q .. 64 q + 63
+    // = (pixel c / CPP, slot c % CPP), and slot holds the pixel's channel chunk slot ^ key(pixel)
+    unsigned goff[G::PSLOTS];
+    auto set_goff = [&](int ty0, int tx0) {
+#pragma unroll
+        for (int s = 0; s < G::PSLOTS; ++s) {
+            const int c = 64 * (w + 8 * s) + lane;
+            const int P = c / G::CPP, slot = c % G::CPP;
+            const int py = P / WPW, px = P - py * WPW;
+            const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
+            const bool ok = P < WNPIX && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const int j = slot ^ ((P >> G::FSHIFT) & G::FMASK);
+            goff[s] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)p.ldxb * 2u + (unsigned)j * 16u) : kOobD;
+        }
+    };
+    // DMA piece `s` of this wave for physical stage hg of image img into stage buffer buf
+    auto dma_slot = [&](int s, int buf, int hg, int img) {
+        const int q = w + 8 * s;                              // wave-uniform
+        const unsigned base = lds0 + (unsigned)buf * (unsigned)G::STAGE_BYTES;
+        if (s < G::PSLOTS && q < G::PATCH_PIECES) {
+            const unsigned add = (unsigned)hg * (unsigned)G::PIX_BYTES + (unsigned)img * img_bytes;
+            dma(base + 1024u * (unsigned)q, goff[s < G::PSLOTS ? s : 0] == kOobD ? kOobD : goff[s < G::PSLOTS ? s : 0] + add, desc_x);
+        } else if (q >= G::PATCH_PIECES && q < G::PIECES) {
+            const int wp = q - G::PATCH_PIECES;               // ((tap KS + ks) 2 + nt) NW + lo
+            const int lo = wp % NW, t2 = wp / NW, nt = t2 & 1, t3 = t2 >> 1, ks = t3 % KS, tap = t3 / KS;
+            const unsigned fi = (unsigned)(nt * p.nks + tap * kpt + KS * hg + ks);
+            dma(base + (unsigned)G::PATCH_BYTES + 1024u * (unsigned)wp, fi * 1024u + (unsigned)lane * 16u, lo ? desc_wl : desc_w);
+        }
+    };
+
+    // activation fragment addresses (tile-relative, the same for every item): tile row yr = 2 w + r, tap -> byte offset in a stage buffer
+    int baddr[2][9];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int P = (2 * w + r + tap / 3) * WPW + li + tap % 3;
+            baddr[r][tap] = P * G::PIX_BYTES + ((lh ^ ((P >> G::FSHIFT) & G::FMASK)) << 4);
+        }
+    const int waddr = G::PATCH_BYTES + lane * 16;
+
+    f32x16 acc[2][2];                             // [nt][r]
+    const int grid = (int)gridDim.x;
+    int item = (int)blockIdx.x;
+    if (item >= pp.n_items) return;
+    int S = 0;                                    // stages done: buffer parity
+    {   // very first stage of this workgroup
+        const int tl = item % pp.tiles_per_img;
+        set_goff((tl / pp.tiles_x) * WTH, (tl % pp.tiles_x) * WTW);
+        const int rot0 = tl % NST;
+#pragma unroll
+        for (int s = 0; s < G::SLOTS; ++s) dma_slot(s, 0, rot0, item / pp.tiles_per_img);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (; item < pp.n_items; item += grid) {
+        const int img = item / pp.tiles_per_img, tl = item - img * pp.tiles_per_img;
+        const int ty0 = (tl / pp.tiles_x) * WTH, tx0 = (tl % pp.tiles_x) * WTW;
+        const int rot = tl % NST;
+        const int nitem = item + grid;
+        const bool has_next = nitem < pp.n_items;
+        const int nimg = has_next ? nitem / pp.tiles_per_img : 0, ntl = has_next ? nitem - nimg * pp.tiles_per_img : 0;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
+#pragma unroll 1
+        for (int st = 0; st < NST; ++st) {
+            const bool last = st + 1 == NST;
+            if (last && has_next) set_goff((ntl / pp.tiles_x) * WTH, (ntl % pp.tiles_x) * WTW);     // the DMAs of this stage fetch the next item
+            const bool more = !last || has_next;
+            int nhg = st + 1 + rot;                                   // physical stage the DMAs of this stage fetch
+            if (nhg >= NST) nhg -= NST;
+            if (last) nhg = has_next ? ntl % NST : 0;
+            const int nim = last ? nimg : img;
+            const int buf = S & 1;
+            const unsigned char* pb = lds + buf * G::STAGE_BYTES;
+            uint4 a[3][2][NW], b[3][2];                               // [set][nt][weight set], [set][r]: operands are read TWO steps ahead
+            auto load_ab = [&](int set, int tap, int ks) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int lo = 0; lo < NW; ++lo)
+                        a[set][nt][lo] = *reinterpret_cast<const uint4*>(pb + waddr + (((tap * KS + ks) * 2 + nt) * NW + lo) * 1024);
+#pragma unroll
+                for (int r = 0; r < 2; ++r) b[set][r] = *reinterpret_cast<const uint4*>(pb + (baddr[r][tap] ^ (ks << 5)));
+            };
+            // (with eight waves on the LDS port a ds_read_b128 takes longer than the 4 MFMAs of one step: one step of lookahead left the
+            // waves parked in s_waitcnt for 41 % of their cycles, SQ_WAIT_ANY)
+            load_ab(0, 0, 0);
+            load_ab(1, 1 / KS, 1 % KS);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int idx = tap * KS + ks, cur = idx % 3;
+                    if (idx + 2 < 9 * KS) load_ab((idx + 2) % 3, (idx + 2) / KS, (idx + 2) % KS);
+#pragma unroll
+                    for (int lo = 0; lo < NW; ++lo)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 2; ++r) acc[nt][r] = mfma_h16<kF16>(a[cur][nt][lo], b[cur][r], acc[nt][r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // The DMA pieces of the next stage leave EARLY (two per tap over the first taps), so that they have the rest of the stage to
+                // land before the wait in front of the barrier, and the two waves of a SIMD (w, w + 4) issue them one tap apart: a piece costs
+                // its wave 60-180 cycles of issue, which the partner's MFMAs cover only if it is not stuck in the same place
+                if (more) {
+                    if (w < 4) {
+                        if (2 * tap < G::SLOTS) dma_slot(2 * tap < G::SLOTS ? 2 * tap : 0, buf ^ 1, nhg, nim);
+                        if (2 * tap + 1 < G::SLOTS) dma_slot(2 * tap + 1 < G::SLOTS ? 2 * tap + 1 : 0, buf ^ 1, nhg, nim);
+                    } else if (tap >= 1) {
+                        if (2 * tap - 2 < G::SLOTS) dma_slot(2 * tap - 2 < G::SLOTS ? 2 * tap - 2 : 0, buf ^ 1, nhg, nim);
+                        if (2 * tap - 1 < G::SLOTS) dma_slot(2 * tap - 1 < G::SLOTS ? 2 * tap - 1 : 0, buf ^ 1, nhg, nim);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            ++S;
+        }
+        // ---- epilogue of this item: the stage buffer just computed from is free (the other one holds the next item's first stage);
+        // this wave's 4-KB region of it turns the accumulator layout (lane = pixel, 4 consecutive channels per quad) into pixel rows
+        {
+            unsigned char* tb = lds + ((S - 1) & 1) * G::STAGE_BYTES + w * 4096;
+            const int pr0 = lane >> 3, c8 = lane & 7;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int y = ty0 + 2 * w + r;
+                const bool y_ok = y < p.H;
+                // 16-bit copy: [32 pixels][64 channels x 2 B], 16-B chunks swizzled with the pixel
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
+                        const float v0 = fmaxf(acc[nt][r][4 * q] + bb.x, 0.f), v1 = fmaxf(acc[nt][r][4 * q + 1] + bb.y, 0.f);
+                        const float v2 = fmaxf(acc[nt][r][4 * q + 2] + bb.z, 0.f), v3 = fmaxf(acc[nt][r][4 * q + 3] + bb.w, 0.f);
+                        acc[nt][r][4 * q] = v0; acc[nt][r][4 * q + 1] = v1; acc[nt][r][4 * q + 2] = v2; acc[nt][r][4 * q + 3] = v3;
+                        *reinterpret_cast<uint2*>(tb + li * 128 + (((4 * nt + q) ^ (li & 7)) << 4) + 8 * lh) = pack_h16x4<kF16>(v0, v1, v2, v3);
+                    }
+                wave_lds_sync();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pr = 8 * j + pr0, x = tx0 + pr;
+                    const uint4 v = *reinterpret_cast<const uint4*>(tb + pr * 128 + ((c8 ^ (pr & 7)) << 4));
+                    if (y_ok && x < p.W)
+                        *reinterpret_cast<uint4*>(p.xb_out + ((size_t)img * p.H * p.W + (size_t)y * p.W + x) * p.ldxb + p.col_out + 8 * c8) = v;
+                }
+                wave_lds_sync();
+                if (p.x) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(tb + li * 128 + (((2 * q + lh) ^ (li & 7)) << 4)) =
+                                make_float4(acc[nt][r][4 * q], acc[nt][r][4 * q + 1], acc[nt][r][4 * q + 2], acc[nt][r][4 * q + 3]);
+                        wave_lds_sync();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int pr = 8 * j + pr0, x = tx0 + pr;
+                            const float4 v = *reinterpret_cast<const float4*>(tb + pr * 128 + ((c8 ^ (pr & 7)) << 4));
+                            if (y_ok && x < p.W)
+                                *reinterpret_cast<float4*>(p.x + ((size_t)img * p.H * p.W + (size_t)y * p.W + x) * p.ldx + p.col_out + 32 * nt + 4 * c8) = v;
+                        }
+                        wave_lds_sync();
+                    }
+                }
+            }
+        }
+        if (has_next) __syncthreads();            // the next stage's DMA pieces land in the buffer the transposes used
+    }
+}
+
+bool dense_h16_wide_ok(int H, int W) { return ceil_div(H, WTH) * ceil_div(W, WTW) >= 32; }
+
 // fp32 columns [col, col+64) of X -> the same columns of the bf16 copy
 __global__ void cast_group_h16_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ Xb, int ldxb, int col,
                                        long HW) {
@@ -498,8 +778,11 @@ int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int co
 }
 
 // dense layer l of a block: input groups 0..l of Xb, output group l+1 (fp32 into X, bf16 into Xb); n_img images back to back
+// route: 0 = automatic (the 16x32-tile persistent kernel of round 6 from 32 such tiles per image on, else the 12x12-tile kernels),
+// 1 = the 12x12-tile kernels whatever the map size (developer A/B and the parity test of the two cuts).  Chosen by the size of ONE image:
+// a tile's result does not depend on the batch it is computed in.
 int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16, const void* frag16_lo,
-                     const float* bias, int n_img, hipStream_t s) {
+                     const float* bias, int n_img, hipStream_t s, int route) {
     CIAOSR_CHECK_ARG(Xb && frag16 && bias && (ldx & 3) == 0 && (ldxb & 7) == 0);      // X null: no fp32 copy of the output
     const size_t xb_bytes = (size_t)n_img * H * W * ldxb * 2;
     CIAOSR_CHECK_ARG(n_img >= 1 && xb_bytes < 0xFFFFFF00ull);
@@ -516,6 +799,23 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
     CIAOSR_BIG_LDS(dense_h16_kernel<false>, kDenseLds);
     CIAOSR_BIG_LDS(dense_h16_dma_kernel, kDense2Lds);
     ProfScope prof("enc_dense" CIAOSR_H16_SUFFIX, s);
+    if (route != 1 && dense_h16_wide_ok(H, W)) {
+        DenseWideP wp;
+        wp.d = p;
+        wp.tiles_x = ceil_div(W, WTW);
+        wp.tiles_per_img = wp.tiles_x * ceil_div(H, WTH);
+        wp.n_items = wp.tiles_per_img * n_img;
+        wp.wf_bytes = (unsigned)((size_t)2 * p.nks * 1024);
+        const int grid = wp.n_items < 256 ? wp.n_items : 256;        // persistent: one workgroup per CU
+        if (p.wf_lo) {
+            CIAOSR_BIG_LDS(dense_h16_wide_kernel<true>, WideGeom<1>::LDS);
+            hipLaunchKernelGGL(dense_h16_wide_kernel<true>, dim3(grid), dim3(512), WideGeom<1>::LDS, s, wp);
+        } else {
+            CIAOSR_BIG_LDS(dense_h16_wide_kernel<false>, WideGeom<2>::LDS);
+            hipLaunchKernelGGL(dense_h16_wide_kernel<false>, dim3(grid), dim3(512), WideGeom<2>::LDS, s, wp);
+        }
+        return launch_status("dense_wide" CIAOSR_H16_SUFFIX);
+    }
     // no process-global switches in the product library: the developer A/B knobs exist in the CIAOSR_PROBE build only
 #ifdef CIAOSR_PROBE
     static const int variant = getenv("CIAOSR_DENSE_V") ? atoi(getenv("CIAOSR_DENSE_V")) : 2;     // 1 = the round-2 kernel

@@ -183,7 +183,8 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
                 const ciaosr_conv_t& c = w->dense[b * NL + l];
                 CIAOSR_CHECK_ARG(conv_ok(c, C + G * l, G, 3));
                 RUN(h16_ops(prec).dense_layer(lff16 ? nullptr : x, cb, Xb, cb, H, W, l, c.frag16,
-                                              (prec == kF16 ? !pairs16 : (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, B, s));
+                                              (prec == kF16 ? !pairs16 : (opt && opt->bf16_single)) ? nullptr : c.frag16_lo, c.bias, B, s,
+                                              dd == 1 ? 1 : 0));
             }
             if (lff16) {
                 // RDB output = x + lff(dense) from the 16-bit rows: fp32 to the global concat and the next block's input, 16-bit to the

@@ -193,7 +193,7 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
     int dense_h16_tiles(int H, int W);                                                                                                \
     int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);                       \
     int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,                     \
-                        const void* frag16_lo, const float* bias, int n_img, hipStream_t s);                                          \
+                        const void* frag16_lo, const float* bias, int n_img, hipStream_t s, int route);                               \
     int conv1x1_h16(const unsigned short* A, int lda, const unsigned short* W16, int ldw, const float* bias, const float* res,        \
                     int ldres, float* out, int ldo, float* out2, int ldo2, unsigned short* out16, int ldo16, int M, int N, int K,     \
                     hipStream_t s, const char* tag);                                                                                  \

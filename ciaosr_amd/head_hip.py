@@ -38,6 +38,7 @@ class PackedHead:
     def _pack_mlp(self, mlp, col_perm=None, row_perm=None, frag_layers=()):
         st = _lib.MlpT()
         lin = mlp.linears()
+        self._bias_tmp = {}
         if len(lin) > _lib.MAX_LAYERS:
             raise _lib.CiaoSRHipError(f'MLP deeper than {_lib.MAX_LAYERS} Linear layers')
         st.n_layers = len(lin)
@@ -57,6 +58,7 @@ class PackedHead:
             hip_ops.require_gpu(w, b)
             keep += [w, b]
             self._last_wb = (w, b)
+            self._bias_tmp[i] = b
             st.width[i] = w.shape[0]
             st.weight[i] = w.data_ptr()
             st.ld[i] = w.stride(0)
@@ -76,16 +78,21 @@ class PackedHead:
         st.in_dim = lin[0].weight.shape[1]
         return st, keep, srcs
 
-    def struct(self, half=None):
+    def struct(self, half=None, single=False):
         """The ciaosr_head_weights_t of the net.  half=None: fp32 fragments only (the _f32 entry).  half='bf16' | 'f16': the copy that also
         carries the 16-bit hi + lo fragment pairs of that element type and the weight stream of the chained kv kernel -- packed when the
-        mode is first used."""
+        mode is first used.  single=True (half='bf16' only; `Options('bf16', bf16_single=1)` = 'bf16-single'): the copy for ONE bf16 weight
+        per product, packed so that it meets the PSNR gate -- see `_build_single`."""
         key = self._version_key()
         if self._st is None or self._key != key:
             self._build()
             self._st_half = {}
         if half not in ('bf16', 'f16'):
             return self._st
+        if single and half == 'bf16':
+            if 'bf16-single' not in self._st_half:
+                self._st_half['bf16-single'] = self._build_single()
+            return self._st_half['bf16-single'][0]
         if half not in self._st_half:
             st = _lib.HeadWeightsT()
             C.memmove(C.byref(st), C.byref(self._st), C.sizeof(st))
@@ -104,6 +111,106 @@ class PackedHead:
             keep += self._pack_chain(st, half)
             self._st_half[half] = (st, keep)
         return self._st_half[half][0]
+
+    # ---- one bf16 weight per product that meets the gate (round 6) ---------------------------------------------------------------------
+    # Round-to-nearest single-bf16 weights fail the 0.01 dB gate on the full C3 tile (0.042 dB) although the rms error is small: the weight
+    # rounding error dW is ONE fixed perturbation for the whole image, and its response to the common (mean) part of the post-ReLU
+    # activations is the same for every query -- a coherent error that PSNR does not average out.  Two pack-time measures remove
+    # that term (tools/bf16_single_lab.py, profiles/r6_bf16_single_rounding_lab*.txt: 0.042 -> 0.0038 dB on the C3 tile, 0.0014 / 0.0027 dB
+    # on the trained-like stress vectors; 0.006-0.008 dB at the 30-dB level, where the bf16 ACTIVATIONS' rms error is what shows):
+    #   * error-feedback rounding along K: the running rounding error of a row is carried into the next element, so every prefix sum of
+    #     dW -- the row sum in particular -- stays within half an ulp (the response to the all-ones component of the activations vanishes);
+    #   * calibrated bias correction b' = b + dW E[x]: the mean input vector E[x] of every rounded layer is measured ONCE per model, at
+    #     pack time, on a fixed synthetic 48x48 image through the fp32 trunk and the fp32 staged head (input-independent, deterministic).
+    # The kernels are the bf16_single ones; nothing changes at run time.
+    @staticmethod
+    def _ef_round_bf16(w):
+        """Error-feedback round-to-bf16 of every row of w [N, K] (fp32, any device) along K; returns fp32 values that ARE bf16 numbers."""
+        w64 = w.detach().double().cpu()
+        out = torch.empty(w64.shape, dtype=torch.float32)
+        e = torch.zeros(w64.shape[0], dtype=torch.float64)
+        for k in range(w64.shape[1]):
+            t = w64[:, k] + e
+            q = t.float().to(torch.bfloat16).float()
+            e = t - q.double()
+            out[:, k] = q
+        return out.to(w.device)
+
+    @torch.no_grad()
+    def _calibration_means(self):
+        """Mean input vector (device channel order) of the Linear layers the bf16 head rounds: layers 1.. of imnet_k / imnet_v, layers 0..n-2
+        of imnet_q, on the x4 grid of a fixed synthetic 48x48 LR image through this generator's own fp32 trunk, cs_attn and staged head."""
+        from .init_utils import synthetic_pair
+        net = self.net
+        enc = getattr(net, '_encoder_hip', None)
+        if enc is None or not enc.supported() or not getattr(net, 'feat_unfold', True):
+            raise _lib.CiaoSRHipError("precision 'bf16-single' needs the HIP trunk and the unfold head for its pack-time calibration")
+        st = self.struct()
+        dev = net.imnet_q.layers[0].weight.device
+        lq = synthetic_pair(48, 48, 4)[0].to(dev)
+        x = (lq - torch.tensor((0.4488, 0.4371, 0.4040), device=dev).view(1, 3, 1, 1)).contiguous()
+        feat_hwc = enc.forward_hwc(x[0], None)
+        H, W, Cc = feat_hwc.shape
+        Cn = st.nonlocal_channels
+        U = hip_ops.patch_rows(feat_hwc, 3, 1, 1, H, W)
+        if net.non_local_attn:
+            nl = hip_ops.nchw_to_hwc(net.cs_attn(hip_ops.hwc_to_nchw(feat_hwc).unsqueeze(0))[0].contiguous())
+            U = torch.cat([U, nl.view(H * W, Cn)], dim=1).contiguous()
+        cc, cl = hip_ops.make_coord_cell(H * 4, W * 4, dev)
+        q_rows, inp_k, inp_v, q_idx, k_idx = hip_ops.gather_rows(U, Cc, Cn, cc, cl, H, W, st.local_size)
+        means = {}
+        for nm, inp, m in (('k', inp_k, st.k), ('v', inp_v, st.v)):
+            for l in range(1, m.n_layers):
+                means[(nm, l)] = hip_ops.mlp_forward(inp, m, n_run=l).double().mean(0).float()
+        wk, wv = hip_ops.mlp_forward(inp_k, st.k), hip_ops.mlp_forward(inp_v, st.v)
+        z = hip_ops.local_attention(U, Cc, Cn, q_idx, k_idx, wk, wv, softmax_scale=st.softmax_scale)
+        means[('q', 0)] = z.double().mean(0).float()
+        for l in range(1, st.q.n_layers):
+            means[('q', l)] = hip_ops.mlp_forward(z, st.q, n_run=l).double().mean(0).float()
+        return means
+
+    @torch.no_grad()
+    def _build_single(self):
+        """(struct, kept tensors) of the 'bf16-single' weight form: error-feedback-rounded weights + calibrated biases (comment above) of
+        every layer the bf16 kernels take from 16-bit fragments; everything else points at the fp32 struct's tensors."""
+        means = self._calibration_means()
+        st = _lib.HeadWeightsT()
+        C.memmove(C.byref(st), C.byref(self._st), C.sizeof(st))
+        keep = []
+        lib = _lib.load()
+        for name in ('k', 'v', 'q'):
+            m = getattr(st, name)
+            for i, w in self._srcs[name]:
+                n, k = w.shape
+                wq = self._ef_round_bf16(w).contiguous()
+                mu = means.get((name, i))
+                b_old = self._bias_of[(name, i)]
+                b_new = b_old.clone()
+                if mu is not None:
+                    d = (w.double() - wq.double())[:, :mu.numel()]
+                    b_new += (d @ mu.double()).float()
+                f = torch.empty(lib.ciaosr_fragment_bf16_bytes(n, k), dtype=torch.uint8, device=w.device)
+                lo = torch.empty_like(f)                     # all zeros by construction (wq is a bf16 number): unused by the single kernels
+                _lib.call('ciaosr_pack_fragments_bf16_pair', hip_ops.ptr(wq), wq.stride(0), n, k, hip_ops.ptr(f), hip_ops.ptr(lo), hip_ops.stream_ptr())
+                keep += [wq, b_new, f, lo]
+                m.weight[i] = wq.data_ptr()
+                m.ld[i] = wq.stride(0)
+                m.bias[i] = b_new.data_ptr()
+                m.frag16[i] = f.data_ptr()
+                m.frag16_lo[i] = lo.data_ptr()
+        # imnet_q's 3-row output layer: the chained decode kernel takes it from the weight stream as 16-bit values too (single form: one bf16
+        # per weight), so it gets the same treatment; the kernels with an fp32 tail then see bf16-valued fp32 weights + the corrected bias
+        nl = st.q.n_layers - 1
+        w_last, b_last = self._q_last
+        wq = self._ef_round_bf16(w_last).contiguous()
+        mu = means[('q', nl)]
+        b_new = b_last.clone() + ((w_last.double() - wq.double())[:, :mu.numel()] @ mu.double()).float()
+        keep += [wq, b_new]
+        st.q.weight[nl] = wq.data_ptr()
+        st.q.ld[nl] = wq.stride(0)
+        st.q.bias[nl] = b_new.data_ptr()
+        keep += self._pack_chain(st, 'bf16')
+        return st, keep
 
     @staticmethod
     def _pack_chain(st, half):
@@ -145,7 +252,9 @@ class PackedHead:
         st.no_unfold = 0 if unfold else 1
         keep = []
         nk, nv, nq = len(net.imnet_k.linears()), len(net.imnet_v.linears()), len(net.imnet_q.linears())
+        self._bias_of = {}
         st.k, kk, sk = self._pack_mlp(net.imnet_k, col_perm=k_cols, row_perm=perm, frag_layers=range(1, nk))
+        self._bias_of.update({('k', i): b for i, b in self._bias_tmp.items()})
         st.k_out_wino = None
         st.k_out_wino4 = None
         st.chain16 = None
@@ -166,7 +275,9 @@ class PackedHead:
             st.k_out_wino = fw.data_ptr()
             st.k_out_wino4 = fw4.data_ptr()
         st.v, kv, sv = self._pack_mlp(net.imnet_v, col_perm=v_cols, row_perm=v_rows, frag_layers=range(1, nv))
+        self._bias_of.update({('v', i): b for i, b in self._bias_tmp.items()})
         st.q, kq, sq = self._pack_mlp(net.imnet_q, col_perm=v_rows, frag_layers=range(0, nq - 1))
+        self._bias_of.update({('q', i): b for i, b in self._bias_tmp.items()})
         self._q_last = self._last_wb
         self._keep = kk + kv + kq
         self._srcs = {'k': sk, 'v': sv, 'q': sq}
@@ -190,7 +301,7 @@ class PackedHead:
         hip_ops.require_gpu(feature_hwc if feature_hwc is not None else feature_chw, x_lr_chw, coord, cell)
         Cc, H, W = feature_chw.shape
         Q = coord.shape[0]
-        st = self.struct(opt.half)
+        st = self.struct(opt.half, single=bool(opt.bf16_single))
         gw = hip_ops.grid_width_of(coord) if (opt.half and not opt.query_grid_w) else 0
         if gw:                        # traversal hint of the 16-bit chained head kernel: the queries are a make_coord grid
             key = (opt, gw)

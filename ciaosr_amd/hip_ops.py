@@ -211,7 +211,7 @@ def tile_finalize(E, Wt):
     return out
 
 
-PRECISIONS = ('fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast')       # what Options(precision) / test_cfg.precision accept
+PRECISIONS = ('fp32', 'bf16', 'bf16-single', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast')       # what Options(precision) / test_cfg.precision accept
 
 
 class Options:
@@ -228,6 +228,9 @@ class Options:
     __slots__ = ('precision',) + _C_FIELDS + ('_c',)
 
     def __init__(self, precision='fp32', **kw):
+        if precision in ('bf16-single', 'bf16_single'):          # ONE bf16 weight per product, error-feedback rounding + calibrated biases (head_hip.py)
+            precision = 'bf16'
+            kw.setdefault('bf16_single', 1)
         if precision in ('f16-pairs', 'f16_pairs', 'f16p'):      # the fp32-tolerance fast mode: half activations, half weight PAIRS
             precision = 'f16'
             kw.setdefault('f16_pairs', 1)

@@ -149,13 +149,13 @@ class CiaoSR(BasicRestorer):
         if hasattr(gen, 'effective_options'):
             opt = gen.effective_options(opt)
         head = getattr(gen, '_head', None)
-        if head is not None:
-            head.struct(opt.half)
         enc = getattr(gen, '_encoder_hip', None)
         if enc is not None and enc.supported():
             enc.struct(opt.half)
         if getattr(gen, 'non_local_attn', False):
             gen.cs_attn.packed()
+        if head is not None:      # last: the 'bf16-single' form runs a pack-time calibration through the (packed) fp32 trunk and cs_attn
+            head.struct(opt.half, single=bool(opt.bf16_single))
 
     @torch.no_grad()
     def clip_test(self, img_lq, model=None, tile_fn=None, options=None):
@@ -282,14 +282,15 @@ class CiaoSR(BasicRestorer):
 
     def tile_batch(self, options=None):
         """Tiles per encoder call (`test_cfg.tile_batch`, an extension; at most 16: 32-bit buffer offsets into the batched block buffer).
-        Default 8 -- except where the trunk's dense layers run the F(4x4, 3x3) Winograd kernel (fp32 trunk, dense_direct = 0), whose
-        workgroup covers 16 x 32 pixels: a 192 x 192 tile is 72 workgroups, 8 tiles are 576 = 2.25 rounds of the 256 CUs (a third
-        round at a quarter of the chip), 7 tiles are 504 = 1.97."""
+        Default 7 where the trunk's dense layers run a kernel whose workgroup covers 16 x 32 pixels -- the F(4x4, 3x3) Winograd kernel
+        of the fp32 trunk (dense_direct = 0) and, since round 6, the 16-bit dense kernel (dense_direct != 1): a 192 x 192 tile is 72
+        workgroups / items, 8 tiles are 576 = 2.25 rounds of the 256 CUs (a third round at a quarter of the chip), 7 tiles are 504 =
+        1.97 -- else 8."""
         v = self.test_cfg.get('tile_batch', None)
         if v is None:
             opt = self.options(options)
             fp32_trunk = opt.precision == 'fp32' or (opt.precision == 'f16' and opt.f16_pairs == 2)       # 'f16x3' keeps the fp32 trunk
-            v = 7 if fp32_trunk and not opt.dense_direct else 8
+            v = 7 if (opt.dense_direct == 0 if fp32_trunk else opt.dense_direct != 1) else 8
         return min(int(v or 1), 16)
 
     def options(self, options=None):

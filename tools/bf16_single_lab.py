@@ -56,28 +56,132 @@ def apply_rule(model, rule, where):
         t.copy_(ef_rows(w2, restart).reshape(t.shape).to(t.device))
 
 
+def head_means(model, lq, dev, stride=7):
+    """Mean INPUT vector of every Linear layer >= 1 of imnet_k / imnet_v (hidden activations) and of every layer of imnet_q (z, hidden
+    activations) over a strided sample of the queries of `lq`'s x4 target grid, from the fp32 staged entry points; device channel order is
+    undone for z (imnet_q layer 0 is the only consumer of a permuted input here)."""
+    from ciaosr_amd.head_hip import unfold_perm
+    gen = model.generator
+    x = model.normalize(lq)
+    feat = hip_ops.hwc_to_nchw(gen._encoder_hip.forward_hwc(x[0], None))
+    C, H, W = feat.shape
+    st = gen._head.struct()
+    U = hip_ops.patch_rows(hip_ops.nchw_to_hwc(feat), 3, 1, 1, H, W)
+    nl = hip_ops.nchw_to_hwc(gen.cs_attn(feat.unsqueeze(0))[0].contiguous())
+    U = torch.cat([U, nl.view(H * W, C)], dim=1).contiguous()
+    cc, cl = hip_ops.make_coord_cell(H * 4, W * 4, dev)
+    cc, cl = cc[::stride].contiguous(), cl[::stride].contiguous()
+    q_rows, inp_k, inp_v, q_idx, k_idx = hip_ops.gather_rows(U, C, C, cc, cl, H, W, st.local_size)
+    means = {}
+    for nm, inp, m in (('imnet_k', inp_k, st.k), ('imnet_v', inp_v, st.v)):
+        for l in range(1, m.n_layers):
+            means[(nm, l)] = hip_ops.mlp_forward(inp, m, n_run=l).double().mean(0).float().cpu()
+    wk, wv = hip_ops.mlp_forward(inp_k, st.k), hip_ops.mlp_forward(inp_v, st.v)
+    z = hip_ops.local_attention(U, C, C, q_idx, k_idx, wk, wv, softmax_scale=st.softmax_scale)
+    perm = unfold_perm(C, dev)                       # z_dev[d] = z_ref[perm[d]]
+    zm = z.double().mean(0).float()
+    z_ref = torch.empty_like(zm)
+    z_ref[perm] = zm[:9 * C]
+    z_ref[9 * C:] = zm[9 * C:]
+    means[('imnet_q', 0)] = z_ref.cpu()
+    for l in range(1, st.q.n_layers):
+        means[('imnet_q', l)] = hip_ops.mlp_forward(z, st.q, n_run=l).double().mean(0).float().cpu()
+    return means
+
+
+SKIP_Q_LAST = False
+
+
+def bias_correct(model, means, rule):
+    """b' = b + (W - Q) @ E[x] for every head Linear whose input mean is known; Q = the weights as `rule` rounds them (and the model's weights
+    become Q, so that the pack kernels' round-to-nearest is the identity)."""
+    gen = model.generator
+    for nm in ('imnet_k', 'imnet_v', 'imnet_q'):
+        lin = getattr(gen, nm).linears()
+        for l, layer in enumerate(lin):
+            if (nm, l) not in means or (SKIP_Q_LAST and nm == 'imnet_q' and l == len(lin) - 1):
+                continue
+            w = layer.weight.detach().cpu()
+            qw = bf16(w) if rule == 'rne' else ef_rows(w)
+            corr = ((w.double() - qw.double()) @ means[(nm, l)].double()).float()
+            with torch.no_grad():
+                layer.weight.copy_(qw.to(layer.weight.device))
+                layer.bias.add_(corr.to(layer.bias.device))
+
+
 dev = torch.device('cuda:0')
-fx = load_golden('e2e_rdn_x4_tile192')
-lq, gt = synthetic_pair(192, 192, 4)
-ref_s4 = _t(fx['out_s4'])
-noise = torch.randn(ref_s4.shape, generator=torch.Generator().manual_seed(GT30_SEED), dtype=torch.float64) * 10 ** (-30 / 20)
-gt30 = ref_s4.double() + noise
-psnr30 = lambda a: -10 * math.log10((a.double() - gt30).pow(2).mean().item())
+FIX = 'tile'
+if len(sys.argv) > 1 and sys.argv[1].startswith('--fixture='):
+    FIX = sys.argv.pop(1).split('=', 1)[1]            # tile | stress48 | stress64
 O = hip_ops.Options
-cases = [('rne', 'all'), ('ef', 'all'), ('ef-taps', 'all'), ('ef', 'head'), ('ef', 'trunk')]
+if FIX == 'tile':
+    fx = load_golden('e2e_rdn_x4_tile192')
+    lq, gt = synthetic_pair(192, 192, 4)
+    ref_cmp = _t(fx['out_s4'])
+    sub = lambda o: o[..., ::4, ::4]
+    psnr_ref_gt = float(fx['psnr_ref_gt'])
+    opt = O('bf16', bf16_single=1)
+
+    def make_model():
+        m = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
+        seeded_init_(m, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=SQRT6)
+        return m
+else:
+    from ciaosr_amd.init_utils import trained_like_
+    size = int(FIX[len('stress'):])
+    fx = load_golden(f'stress_rdn_x4_{size}')
+    lq = _t(fx['lq'])
+    _, gt = synthetic_pair(size, size, 4)
+    ref_cmp = _t(fx['out'])
+    sub = lambda o: o
+    psnr_ref_gt = psnr_tensors(ref_cmp, gt, crop_border=4)
+    opt = O('bf16', bf16_single=1, dense_min_tiles=1, csa_composed_min=1)       # the big-map 16-bit kernels forced on these small maps
+
+    def make_model():
+        m = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
+        seeded_init_(m, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=float(fx['head_gain']))
+        trained_like_(m, seed=int(fx['weight_seed']), sigma=float(fx['sigma']))
+        return m
+noise = torch.randn(ref_cmp.shape, generator=torch.Generator().manual_seed(GT30_SEED), dtype=torch.float64) * 10 ** (-30 / 20)
+gt30 = ref_cmp.double() + noise
+psnr30 = lambda a: -10 * math.log10((a.double() - gt30).pow(2).mean().item())
+cases = [('rne', 'all'), ('ef', 'all'), ('ef-taps', 'all'), ('ef', 'head'), ('ef', 'trunk'),
+         # head: calibrated bias correction b' = b + (W - Q) E[x] (means from the fp32 staged evaluation of `cal`) on top of rne / ef rounding;
+         # trunk: rne or ef-taps.  cal = tile: the test input itself (upper bound of what calibration can do); cal48: a 48x48 synthetic image
+         ('rne+bc', 'tile:rne'), ('ef+bc', 'tile:rne'), ('ef+bc', 'tile:ef-taps'), ('rne+bc', 'cal48:rne'), ('ef+bc', 'cal48:rne'), ('ef+bc', 'cal48:ef-taps')]
 if len(sys.argv) > 1:
-    cases = [tuple(a.split(':')) for a in sys.argv[1:]]
+    cases = [tuple(a.split(':', 1)) for a in sys.argv[1:]]
 for rule, where in cases:
-    model = _restorer('rdn', 4, dev, dict(scale=4, tile=192, tile_overlap=32))
-    seeded_init_(model, seed=int(fx['weight_seed']), gain=float(fx['gain']), head_gain=SQRT6)
-    apply_rule(model, rule, where)
+    model = make_model()
+    SKIP_Q_LAST = rule.endswith('-noq4')
+    if SKIP_Q_LAST:
+        rule = rule[:-5]
+    if rule == 'product':                 # the product's own 'bf16-single' packing (head_hip.py::_build_single) on the unmodified model
+        model = model.to(dev)
+        out = model.restore(lq.to(dev), options=O('bf16-single', **({} if FIX == 'tile' else dict(dense_min_tiles=1, csa_composed_min=1)))).cpu()
+        got = sub(out)
+        d = (got - ref_cmp).double()
+        dp = abs(psnr_tensors(out, gt, crop_border=4) - psnr_ref_gt)
+        print(f'[{FIX}] product bf16-single: max|d| {d.abs().max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e} mean {d.mean().item():+.2e} '
+              f'PSNR delta {dp:.5f} dB, at 30 dB {abs(psnr30(got) - psnr30(ref_cmp)):.5f} dB', flush=True)
+        continue
+    if rule.endswith('+bc'):
+        cal, trunk_rule = where.split(':')
+        model = model.to(dev)
+        cal_lq = (lq if cal == 'tile' else synthetic_pair(48, 48, 4)[0]).to(dev)
+        means = head_means(model, cal_lq, dev, stride=7 if (cal == 'tile' and FIX == 'tile') else 1)
+        model = model.cpu()
+        bias_correct(model, means, rule[:-3])
+        apply_rule(model, trunk_rule, 'trunk')
+    else:
+        apply_rule(model, rule, where)
     model = model.to(dev)
-    out = model.restore(lq.to(dev), options=O('bf16', bf16_single=1)).cpu()
-    got = out[..., ::4, ::4]
-    d = (got - ref_s4).double()
-    r0 = ref_s4.double() - ref_s4.double().mean()
+    out = model.restore(lq.to(dev), options=opt).cpu()
+    got = sub(out)
+    d = (got - ref_cmp).double()
+    r0 = ref_cmp.double() - ref_cmp.double().mean()
     slope = (d * r0).sum().item() / (r0 * r0).sum().item()
-    dp = abs(psnr_tensors(out, gt, crop_border=4) - float(fx['psnr_ref_gt']))
-    print(f'bf16-single, rounding {rule:8s} on {where:5s}: max|d| {d.abs().max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e} '
-          f'slope {slope:+.2e}  PSNR delta {dp:.5f} dB, at 30 dB {abs(psnr30(got) - psnr30(ref_s4)):.5f} dB', flush=True)
+    dp = abs(psnr_tensors(out, gt, crop_border=4) - psnr_ref_gt)
+    print(f'[{FIX}] bf16-single, rounding {rule:8s} on {where:14s}: max|d| {d.abs().max().item():.3e} rms {d.pow(2).mean().sqrt().item():.3e} '
+          f'slope {slope:+.2e} mean {d.mean().item():+.2e}  PSNR delta {dp:.5f} dB, at 30 dB {abs(psnr30(got) - psnr30(ref_cmp)):.5f} dB', flush=True)
     del model

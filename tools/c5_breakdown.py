@@ -34,7 +34,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(10):
     f = model.generator.gen_feature(x)
 torch.cuda.synchronize()
-print(f'  gen_feature (SwinIR trunk, PyTorch-ROCm): {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms')
+print(f'  gen_feature (SwinIR trunk, HIP: swinir.hip): {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms')
 with hip_ops.profile():
     model.restore(lq, coord, cell)
     torch.cuda.synchronize()
