@@ -330,9 +330,13 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
     last = (Q - (n_chunks - 1) * eval_bsize) / eval_bsize
     tried, best = {}, None
     t_sweep = time.perf_counter()
+    slower_in_a_row = 0
     for n_thr in _thread_counts():                                          # the bounded sample at 16 / 32 / 64 / 128 / all threads: the fastest counts
         if best is not None and time.perf_counter() - t_sweep > 150.0:      # the whole baseline leg stays within a few minutes
             tried[str(n_thr)] = 'not run: sweep budget (150 s) spent'
+            continue
+        if slower_in_a_row >= 2:                                            # two larger thread counts in a row were already slower: more threads
+            tried[str(n_thr)] = 'not run: the two thread counts before it were slower than the best'      # only add synchronisation
             continue
         torch.set_num_threads(n_thr)
         with torch.no_grad():
@@ -346,6 +350,7 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
                 # (minutes at 256 threads on a 2 x 64-core host: the port's small ops drown in synchronisation) is not run
                 tried[str(n_thr)] = (f'not completed: RDN trunk ' + ('> 60 s (abandoned)' if feat is None else f'{t_enc:.1f} s') +
                                      f' against {best[2]:.1f} s at {best[1]} threads')
+                slower_in_a_row += 1
                 continue
             t0 = time.perf_counter()
             orc.query_rgb(feat, coord, cell, params)                           # one chunk as the reference runs it
@@ -357,6 +362,7 @@ def cpu_baseline_c3(n_tiles, out_pixels, scale=4, tile=192, eval_bsize=30000):
         t_csa = max(t_chunk - t_head, 0.0)
         ref_s = t_enc + (n_chunks - 1) * t_chunk + (t_csa + last * t_head)
         tried[str(n_thr)] = round(ref_s, 2)
+        slower_in_a_row = 0 if (best is None or ref_s < best[0]) else slower_in_a_row + 1
         if best is None or ref_s < best[0]:
             best = (ref_s, n_thr, t_enc, t_chunk, t_head, t_csa)
     tile_ref, n_best, t_enc, t_chunk, t_head, t_csa = best

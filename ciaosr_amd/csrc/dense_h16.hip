@@ -511,11 +511,13 @@ template <int KS> struct WideGeom {              // KS = k16 steps per stage: 2 
     static constexpr int W_PIECES = 9 * KS * 2 * NW;                    // 36
     static constexpr int STAGE_BYTES = PATCH_BYTES + W_PIECES * 1024;   // 76 800 / 57 344
     static constexpr int PIECES = PATCH_PIECES + W_PIECES;              // 75 / 56
-    static constexpr int SLOTS = (PIECES + 7) / 8;                      // DMA pieces per wave and stage: 10 / 7
-    static constexpr int PSLOTS = (PATCH_PIECES + 7) / 8;               // ... of which patch pieces (per-lane source offsets): 5 / 3
+    static constexpr int DW = 4;                                        // waves that issue the DMA pieces (0 .. 3: one per SIMD, the older of its pair)
+    static constexpr int SLOTS = (PIECES + DW - 1) / DW;                // DMA pieces per issuing wave and stage: 19 / 14
+    static constexpr int PSLOTS = (PATCH_PIECES + DW - 1) / DW;         // ... of which patch pieces (per-lane source offsets): 10 / 5
+    static constexpr int PER_TAP = (SLOTS + 6) / 7;                     // issued over the first seven taps: 3 / 2 per tap
     static constexpr int FMASK = CPP - 1;
     static constexpr int FSHIFT = KS == 2 ? 2 : 3;                      // swizzle key of pixel P: (P >> FSHIFT) & FMASK
-    static constexpr size_t LDS = 2 * (size_t)STAGE_BYTES;              // 153 600 / 114 688
+    static constexpr size_t LDS = 2 * (size_t)STAGE_BYTES + 256;        // two stage buffers + the layer's 64 biases: 153 856 / 114 944
 };
 
 // every 16-lane group of the activation ds_read_b128 of every (tile row, tap) must touch 16 distinct 16-B bank quads
@@ -548,6 +550,15 @@ struct DenseWideP {
     unsigned wf_bytes;                           // bytes of one weight fragment array (2 * nks KB)
 };
 
+#ifdef CIAOSR_PROBE      // developer probe build (make probe; tools/dense_wide_probe.py): cycle stamps of the last launch's workgroups, wave 0
+__device__ unsigned long long g_dwprobe[256 * 8];
+#define DWP_NOW() __builtin_readcyclecounter()
+#define DWP_ADD(slot, t0) do { if (threadIdx.x == 0) dwacc[slot] += __builtin_readcyclecounter() - (t0); } while (0)
+#else
+#define DWP_NOW() 0ull
+#define DWP_ADD(slot, t0) do { (void)(t0); } while (0)
+#endif
+
 template <bool LO>
 __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
     constexpr int KS = LO ? 1 : 2;
@@ -571,13 +582,13 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(sdst), "s"(desc) : "memory");
     };
-    // per-lane source offsets of this wave's patch pieces for the tile at (ty0, tx0): piece q = w + 8 s fills LDS chunks 64 q .. 64 q + 63
+    // per-lane source offsets of this wave's patch pieces for the tile at (ty0, tx0): piece q = w + 4 s (waves 0 .. 3) fills LDS chunks 64 q .. 64 q + 63
     // = (pixel c / CPP, slot c % CPP), and slot holds the pixel's channel chunk slot ^ key(pixel)
     unsigned goff[G::PSLOTS];
     auto set_goff = [&](int ty0, int tx0) {
 #pragma unroll
         for (int s = 0; s < G::PSLOTS; ++s) {
-            const int c = 64 * (w + 8 * s) + lane;
+            const int c = 64 * (w + G::DW * s) + lane;
             const int P = c / G::CPP, slot = c % G::CPP;
             const int py = P / WPW, px = P - py * WPW;
             const int gy = ty0 - 1 + py, gx = tx0 - 1 + px;
@@ -588,7 +599,7 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
     };
     // DMA piece `s` of this wave for physical stage hg of image img into stage buffer buf
     auto dma_slot = [&](int s, int buf, int hg, int img) {
-        const int q = w + 8 * s;                              // wave-uniform
+        const int q = w + G::DW * s;                          // wave-uniform
         const unsigned base = lds0 + (unsigned)buf * (unsigned)G::STAGE_BYTES;
         if (s < G::PSLOTS && q < G::PATCH_PIECES) {
             const unsigned add = (unsigned)hg * (unsigned)G::PIX_BYTES + (unsigned)img * img_bytes;
@@ -613,6 +624,12 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
     const int waddr = G::PATCH_BYTES + lane * 16;
 
     f32x16 acc[2][2];                             // [nt][r]
+    float* lbias = reinterpret_cast<float*>(lds + 2 * G::STAGE_BYTES);      // the layer's 64 biases behind the stage buffers (an epilogue that
+    if (t < 64) lbias[t] = p.bias[t];                                       // fetched them from L2 started with a dependent round trip per tile row)
+#ifdef CIAOSR_PROBE
+    unsigned long long dwacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 0 compute loop, 1 vmcnt wait, 2 barrier, 3 epilogue, 4 lifetime, 5 stages, 6 items, 7 prologue
+#endif
+    const unsigned long long dw_t0 = DWP_NOW();
     const int grid = (int)gridDim.x;
     int item = (int)blockIdx.x;
     if (item >= pp.n_items) return;
@@ -621,11 +638,14 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
         const int tl = item % pp.tiles_per_img;
         set_goff((tl / pp.tiles_x) * WTH, (tl % pp.tiles_x) * WTW);
         const int rot0 = tl % NST;
+        if (w < G::DW) {
 #pragma unroll
-        for (int s = 0; s < G::SLOTS; ++s) dma_slot(s, 0, rot0, item / pp.tiles_per_img);
+            for (int s = 0; s < G::SLOTS; ++s) dma_slot(s, 0, rot0, item / pp.tiles_per_img);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        DWP_ADD(7, dw_t0);
     }
 #pragma unroll 1
     for (; item < pp.n_items; item += grid) {
@@ -664,6 +684,7 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
             };
             // (with eight waves on the LDS port a ds_read_b128 takes longer than the 4 MFMAs of one step: one step of lookahead left the
             // waves parked in s_waitcnt for 41 % of their cycles, SQ_WAIT_ANY)
+            const unsigned long long dw_s0 = DWP_NOW();
             load_ab(0, 0, 0);
             load_ab(1, 1 / KS, 1 % KS);
 #pragma unroll
@@ -680,25 +701,33 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
                             for (int r = 0; r < 2; ++r) acc[nt][r] = mfma_h16<kF16>(a[cur][nt][lo], b[cur][r], acc[nt][r]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // The DMA pieces of the next stage leave EARLY (two per tap over the first taps), so that they have the rest of the stage to
-                // land before the wait in front of the barrier, and the two waves of a SIMD (w, w + 4) issue them one tap apart: a piece costs
-                // its wave 60-180 cycles of issue, which the partner's MFMAs cover only if it is not stuck in the same place
-                if (more) {
-                    if (w < 4) {
-                        if (2 * tap < G::SLOTS) dma_slot(2 * tap < G::SLOTS ? 2 * tap : 0, buf ^ 1, nhg, nim);
-                        if (2 * tap + 1 < G::SLOTS) dma_slot(2 * tap + 1 < G::SLOTS ? 2 * tap + 1 : 0, buf ^ 1, nhg, nim);
-                    } else if (tap >= 1) {
-                        if (2 * tap - 2 < G::SLOTS) dma_slot(2 * tap - 2 < G::SLOTS ? 2 * tap - 2 : 0, buf ^ 1, nhg, nim);
-                        if (2 * tap - 1 < G::SLOTS) dma_slot(2 * tap - 1 < G::SLOTS ? 2 * tap - 1 : 0, buf ^ 1, nhg, nim);
-                    }
+                // The DMA pieces of the next stage are issued by waves 0 .. 3 ONLY -- one wave per SIMD, the older of its pair -- two or three
+                // per tap over the first seven taps (they then have the rest of the stage to land).  A piece costs its wave 60-180 cycles of
+                // issue during which it feeds no MFMA; the probe of the first cut (every wave issuing its share, tools/dense_wide_probe.py)
+                // showed both waves of a SIMD stuck in their DMA issue at the same time: the older took 47 cycles per MFMA, the younger was
+                // starved and then ran ALONE at 30.5 -- 5590 cycles per stage against the 4608 of MFMA issue.  Now the younger wave of every
+                // SIMD is pure MFMA + LDS reads and fills the pipe whenever the older one is busy issuing.
+                if (more && w < G::DW) {
+#pragma unroll
+                    for (int e = 0; e < G::PER_TAP; ++e)
+                        if (G::PER_TAP * tap + e < G::SLOTS) dma_slot(G::PER_TAP * tap + e < G::SLOTS ? G::PER_TAP * tap + e : 0, buf ^ 1, nhg, nim);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            DWP_ADD(0, dw_s0);
+            const unsigned long long dw_s1 = DWP_NOW();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DWP_ADD(1, dw_s1);
+            const unsigned long long dw_s2 = DWP_NOW();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            DWP_ADD(2, dw_s2);
+#ifdef CIAOSR_PROBE
+            dwacc[5] += 1;
+#endif
             ++S;
         }
+        const unsigned long long dw_e0 = DWP_NOW();
         // ---- epilogue of this item: the stage buffer just computed from is free (the other one holds the next item's first stage);
         // this wave's 4-KB region of it turns the accumulator layout (lane = pixel, 4 consecutive channels per quad) into pixel rows
         {
@@ -713,7 +742,7 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float4 bb = *reinterpret_cast<const float4*>(p.bias + 32 * nt + 8 * q + 4 * lh);
+                        const float4 bb = *reinterpret_cast<const float4*>(lbias + 32 * nt + 8 * q + 4 * lh);
                         const float v0 = fmaxf(acc[nt][r][4 * q] + bb.x, 0.f), v1 = fmaxf(acc[nt][r][4 * q + 1] + bb.y, 0.f);
                         const float v2 = fmaxf(acc[nt][r][4 * q + 2] + bb.z, 0.f), v3 = fmaxf(acc[nt][r][4 * q + 3] + bb.w, 0.f);
                         acc[nt][r][4 * q] = v0; acc[nt][r][4 * q + 1] = v1; acc[nt][r][4 * q + 2] = v2; acc[nt][r][4 * q + 3] = v3;
@@ -749,7 +778,17 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
             }
         }
         if (has_next) __syncthreads();            // the next stage's DMA pieces land in the buffer the transposes used
+        DWP_ADD(3, dw_e0);
+#ifdef CIAOSR_PROBE
+        dwacc[6] += 1;
+#endif
     }
+#ifdef CIAOSR_PROBE
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        dwacc[4] = __builtin_readcyclecounter() - dw_t0;
+        for (int i = 0; i < 8; ++i) g_dwprobe[blockIdx.x * 8 + i] = dwacc[i];
+    }
+#endif
 }
 
 bool dense_h16_wide_ok(int H, int W) { return ceil_div(H, WTH) * ceil_div(W, WTW) >= 32; }
@@ -836,3 +875,11 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
 
 }  // namespace CIAOSR_H16_NS
 }  // namespace ciaosr
+
+#ifdef CIAOSR_PROBE
+#if CIAOSR_F16
+extern "C" int ciaosr_debug_probe_dw_read(unsigned long long* host, int n_words) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::f16::g_dwprobe), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+}
+#endif
+#endif

@@ -2008,6 +2008,12 @@ def test_bench_line_contract(dev):
         assert k in r, k
     assert r['bound'] in ('mfma', 'hbm') and 0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert r['staged_path_hbm_kernels']['local_attention']['frac'] >= 0.40          # north star: >= 40 % of the HBM roofline on K4
+    # ... as flat scalars of `roofline` (what the driver's record keeps), live HIP-event figures next to the committed rocprof / counter evidence
+    assert r['k4_hbm_frac'] >= 0.40 and r['k4_bytes_per_query'] == 22064 and r['k1_hbm_frac'] >= 0.40 and r['k1_bytes_per_query'] == 21936, r
+    assert r['k4_rocprof_hbm_frac'] >= 0.40 and r['k4_counter_over_algorithmic'] <= 1.3, r      # profiles/r6_c3tile_staged_*
+    keys = list(d)
+    assert keys.index('cpu_baseline') < keys.index('roofline') < keys.index('kernels_ms_per_step'), keys      # headline first, bulk last
+    assert len(d['cpu_baseline']['seconds_per_tile_by_threads']) >= 2
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
