@@ -67,7 +67,21 @@ constexpr int kAbl = CIAOSR_CHAIN_ABL;
 #endif
 constexpr int CNW = CIAOSR_CHAIN_WAVES;   // waves per workgroup: 4 (one per SIMD, two row tiles each) or 8 (two per SIMD, one row tile each)
 constexpr int CM = 8 / CNW;               // row tiles per wave
-constexpr int CPW = 16 / CNW;             // 1-KB DMA pieces of a slot a wave issues
+#ifndef CIAOSR_CHAIN_ISSUERS
+#define CIAOSR_CHAIN_ISSUERS 4    // round 6: the weight-stream pieces are issued by the first 4 waves only -- one per SIMD, the OLDER wave of its pair.
+#endif                            // A piece costs its wave 60-180 cycles of issue in which it feeds no MFMA; with every wave issuing its share at the same
+                                  // k-steps both waves of a SIMD sat in that issue together (measured on the dense kernel of this round, dense_h16.hip:
+                                  // 5590 -> 4810 cycles per stage).  The younger wave of every SIMD is now pure MFMA + LDS reads.  8 = every wave (round 5).
+constexpr int CIW = CIAOSR_CHAIN_ISSUERS < CNW ? CIAOSR_CHAIN_ISSUERS : CNW;      // issuing waves
+constexpr int CPW = 16 / CIW;             // 1-KB DMA pieces of a slot an ISSUING wave issues (the other waves: none)
+constexpr bool kSplitIssue = CIW != CNW;
+// counted waits: `s_waitcnt vmcnt(N)` with N = the vector-memory operations this wave is known to have issued BEHIND the ones it waits for;
+// the weight pieces among them exist in the issuing waves only (WITH), the other waves count without them (WITHOUT)
+template <int WITH, int WITHOUT>
+__device__ __forceinline__ void vm_wait(bool issuer) {
+    if (!kSplitIssue || issuer) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(WITH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(WITHOUT) : "memory");
+}
 constexpr int CROWS = 32 * CM * CNW;      // rows per workgroup pass (256)
 constexpr int CQ = CROWS / 4;             // queries per pass (64)
 constexpr int CSLOT = 16 * 1024;          // ring slot = 16 fragments: one tile, or the hi / the lo half of a pair tile
@@ -164,6 +178,7 @@ struct Stream {
     i32x4 desc;
     unsigned lds0;                  // LDS byte address of the ring
     unsigned voff;                  // this lane's offset inside a slot: (CPW w) KB + lane * 16
+    bool iss;                       // this wave issues weight pieces (wave-uniform)
     unsigned src0;                  // byte offset of the stream inside the blob
     int n_slots;                    // per pass
     int total;                      // slots this workgroup consumes in the launch
@@ -177,6 +192,7 @@ struct Stream {
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %2, %3 offen lds" :: "v"(vo), "s"(lds_dst), "s"(desc), "s"(soff) : "memory");
     }
     __device__ __forceinline__ void issue_whole(int slot) const {       // prologue (slot < CRING - 1): all of this wave's pieces of a slot at once
+        if (!iss) return;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * CSLOT + (voff & ~1023u));
         const unsigned src = __builtin_amdgcn_readfirstlane(src0 + (unsigned)(slot % n_slots) * CSLOT);
 #pragma unroll
@@ -189,7 +205,7 @@ struct Stream {
     // fetches and Z stores): they may stay in flight too
     template <int EXTRA = 0>
     __device__ __forceinline__ lds_cptr begin_slot(lds_cptr ring) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "i"((CRING - 2) * CPW + EXTRA) : "memory");
+        vm_wait<(CRING - 2) * CPW + EXTRA, EXTRA>(iss);
         if (!(kAbl & 128)) __builtin_amdgcn_s_barrier();
         const int nxt = cur + CRING - 1;
         const int nidx = (ridx + CRING - 1) & (CRING - 1);            // the buffer slot cur - 1 used
@@ -202,6 +218,7 @@ struct Stream {
         return s;
     }
     __device__ __forceinline__ void piece(int i) const {
+        if (!iss) return;
         dma(pf_dst + (unsigned)i * 1024u, pf_src + (unsigned)i * 1024u, pf_voff);
     }
 };
@@ -478,7 +495,8 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
     Stream st;
     st.desc = i32x4{(int)(unsigned)(size_t)p.blob, (int)(((size_t)p.blob >> 32) & 0xFFFFu), (int)p.blob_bytes, 0x00020000};
     st.lds0 = (unsigned)(size_t)(LDS3 unsigned char*)ring;
-    st.voff = (unsigned)(CPW * w) * 1024u + (unsigned)lane * 16u;
+    st.iss = !kSplitIssue || w < CIW;
+    st.voff = (unsigned)(CPW * (st.iss ? w : 0)) * 1024u + (unsigned)lane * 16u;
     st.src0 = 2 * CTAIL;
     st.n_slots = p.n_slots;
     const int my_passes = (p.n_pass - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -801,10 +819,11 @@ __global__ __launch_bounds__(64 * CNW) void head_kv_chain_kernel(ChainP p) {
             // issued KW operations by then; lines 0 .. VD - 1 are fetched in front of the loop.
             constexpr int VD = 2, OPU = 3 + PPT;
             constexpr int KW = PPT + VD * OPU;
+            constexpr int OPU0 = 3, KW0 = VD * OPU0;          // the same counts in a wave that issues no weight pieces
             auto wait_line = [&](int line) {        // uniform
-                if (line >= VD) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(KW) : "memory");
-                else if (line == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * (VD - 1) + OPU) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * OPU) : "memory");
+                if (line >= VD) vm_wait<KW, KW0>(st.iss);
+                else if (line == 0) vm_wait<2 * (VD - 1) + OPU, 2 * (VD - 1) + OPU0>(st.iss);
+                else vm_wait<2 * OPU, 2 * OPU0>(st.iss);
             };
             static_assert(VD == 2 && VD + 2 <= CNSTAGE, "a line's stage is free again two units after its reads");
             auto epilogue = [&](int u, const f32x16 (&c)[CM]) {       // whole, for the last unit (its line has been waited for)
@@ -986,7 +1005,8 @@ __global__ __launch_bounds__(64 * CNW) void head_decode_chain_kernel(DecodeChain
     Stream st;
     st.desc = i32x4{(int)(unsigned)(size_t)p.blob, (int)(((size_t)p.blob >> 32) & 0xFFFFu), (int)p.blob_bytes, 0x00020000};
     st.lds0 = (unsigned)(size_t)(LDS3 unsigned char*)ring;
-    st.voff = (unsigned)(CPW * w) * 1024u + (unsigned)lane * 16u;
+    st.iss = !kSplitIssue || w < CIW;
+    st.voff = (unsigned)(CPW * (st.iss ? w : 0)) * 1024u + (unsigned)lane * 16u;
     st.src0 = 0;
     st.n_slots = p.n_slots;
     const int my_passes = (p.n_pass - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1045,7 +1065,7 @@ __global__ __launch_bounds__(64 * CNW) void head_decode_chain_kernel(DecodeChain
                 // line L has landed: it was fetched behind the first slot of the previous line step (the first line of a pass: under the hidden
                 // layers of the pass before), and this wave has issued NP weight pieces since
                 if (L == 0 && pass_i == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(NP) : "memory");
+                else vm_wait<NP, 0>(st.iss);
                 u32x4 bz[4];
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) bz[sl] = *(const LDS3 u32x4*)(rd[sl] + par * 4096);
