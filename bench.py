@@ -225,10 +225,10 @@ _TAG2FN_16 = {'head_kv_chain': 'head_kv_chain_kernel', 'head_decode_chain': 'hea
 
 
 def offline_traffic(tag, precision):
-    """(bytes per launch, source) of a 16-bit kernel from profiles/r5_c3tile_<precision>_pmc_hbm_traffic.json (tools/pmc_summary.py over two
+    """(bytes per launch, source) of a 16-bit kernel from profiles/r6_ (else r5_) c3tile_<precision>_pmc_hbm_traffic.json (tools/pmc_summary.py over two
     rocprofv3 --pmc passes: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), or None."""
-    prec = {'f16-pairs': 'f16_pairs', 'f16x3-fast': 'f16x3_fast'}.get(precision, precision)
-    path = os.path.join(REPO, 'profiles', f'r5_c3tile_{prec}_pmc_hbm_traffic.json')
+    prec = {'f16-pairs': 'f16_pairs', 'f16x3-fast': 'f16x3_fast', 'bf16-single': 'bf16_single'}.get(precision, precision)
+    path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_c3tile_{prec}_pmc_hbm_traffic.json') for r in (6, 5)) if os.path.exists(q)), '')
     fn = next((v for k, v in _TAG2FN_16.items() if tag.startswith(k)), None)
     if not fn or not os.path.exists(path):
         return None
@@ -969,7 +969,7 @@ def main():
                           'head_kv_chain_pairs_f16': 'head_kv_chain_kernel', 'head_kv_chain_pairs_bf16': 'head_kv_chain_kernel', 'enc_dense_bf16': 'dense_h16_kernel', 'enc_dense_f16': 'dense_h16_kernel',
                           'enc_dense_gather': 'dense_f32_kernel', 'enc_dense_wino': 'dense_wino_f32_kernel', 'enc_dense_wino4': 'dense_wino4_f32_kernel'}
                 unit = 'c2' if tile_lr == 48 else 'c3tile'
-                pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (5, 4, 3))
+                pmc_path = next((q for q in (os.path.join(REPO, 'profiles', f'r{r}_{unit}_pmc_hbm_traffic.json') for r in (6, 5, 4, 3))
                                  if os.path.exists(q)), '')
                 live_traffic = None
                 if world == 1 and not args.no_live_pmc and dominant in tag2fn:

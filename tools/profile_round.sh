@@ -14,6 +14,7 @@ python3 $R/bench.py --workload c3tile --precision f16 --steps 5 --warmup 2 --no-
 python3 $R/bench.py --workload c3 --precision f16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc --no-rccl-probe > $O/c3_f16_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3 --precision f16-pairs --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc --no-rccl-probe > $O/c3_f16_pairs_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3 --precision bf16 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc --no-rccl-probe > $O/c3_bf16_bench.json 2>> $O/c3_bench.err
+python3 $R/bench.py --workload c3 --precision bf16 --bf16-single --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc --no-rccl-probe > $O/c3_bf16_single_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3 --precision f16x3 --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc --no-rccl-probe > $O/c3_f16x3_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3 --precision f16x3-fast --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-live-pmc --no-rccl-probe > $O/c3_f16x3_fast_bench.json 2>> $O/c3_bench.err
 python3 $R/bench.py --workload c3tile --precision f16x3 --steps 5 --warmup 2 --no-extras --no-cpu-baseline --no-rccl-probe > $O/c3tile_f16x3_bench.json 2>> $O/c3_bench.err
