@@ -498,11 +498,16 @@ __global__ __launch_bounds__(256, 2) void dense_h16_dma_kernel(DenseH16P p) {
 //     128-B lines (16-bit copy always; fp32 copy when the caller keeps one).
 // Per image the MACs and their order depend on the tile position only (stage order rotated by the tile index, like above): a tile's
 // result does not depend on the batch it is computed in.  Summation order differs from the 12x12 kernels (no K split): same products.
-constexpr int WTH = 16, WTW = 32;                // output tile (pixels)
-constexpr int WPH = WTH + 2, WPW = WTW + 2;      // with the 1-pixel halo
-constexpr int WNPIX = WPH * WPW;                 // 612
-
-template <int KS> struct WideGeom {              // KS = k16 steps per stage: 2 (one 16-bit weight per product) or 1 (hi + lo pairs)
+constexpr int WTW = 32;                         // output tile width (pixels): one MFMA pixel tile per tile row
+constexpr int WPW = WTW + 2;                     // with the 1-pixel halo
+// R = tile rows per wave: 2 (16 x 32-pixel tiles, the throughput shape) or 1 (8 x 32: twice the workgroups for launches that cannot fill the
+// chip with the big tiles -- a single image is 72 tiles of 16 x 32 on 256 CUs).  The accumulation order of an output -- stages in the order
+// rotated by the index of its 16 x 32 PARENT tile, taps, k-steps -- is the same in both shapes: the results are bitwise equal, so the shape
+// may be chosen by the size of the launch without a tile's result depending on its batch.
+template <int KS, int R> struct WideGeom {       // KS = k16 steps per stage: 2 (one 16-bit weight per product) or 1 (hi + lo pairs)
+    static constexpr int WTH = 8 * R;                                   // output tile height: one row per (wave, r)
+    static constexpr int WPH = WTH + 2;
+    static constexpr int WNPIX = WPH * WPW;                             // 612 / 340
     static constexpr int NW = 2 / KS;                                   // weight sets
     static constexpr int CPP = 2 * KS;                                  // 16-B chunks per patch pixel and stage
     static constexpr int PIX_BYTES = 16 * CPP;
@@ -515,6 +520,9 @@ template <int KS> struct WideGeom {              // KS = k16 steps per stage: 2 
     static constexpr int SLOTS = (PIECES + DW - 1) / DW;                // DMA pieces per issuing wave and stage: 19 / 14
     static constexpr int PSLOTS = (PATCH_PIECES + DW - 1) / DW;         // ... of which patch pieces (per-lane source offsets): 10 / 5
     static constexpr int PER_TAP = (SLOTS + 6) / 7;                     // issued over the first seven taps: 3 / 2 per tap
+    // the launch's very first stage starts computing when the patch and the weights of taps 0 .. 2 have landed (pieces are issued patch
+    // first, weights in tap order): the first PRO_SLOTS slots of every issuing wave; the rest is waited for in front of tap 3
+    static constexpr int PRO_SLOTS = (PATCH_PIECES + 3 * (W_PIECES / 9) + DW - 1) / DW;        // 13 / 8
     static constexpr int FMASK = CPP - 1;
     static constexpr int FSHIFT = KS == 2 ? 2 : 3;                      // swizzle key of pixel P: (P >> FSHIFT) & FMASK
     static constexpr size_t LDS = 2 * (size_t)STAGE_BYTES + 256;        // two stage buffers + the layer's 64 biases: 153 856 / 114 944
@@ -523,7 +531,8 @@ template <int KS> struct WideGeom {              // KS = k16 steps per stage: 2 
 // every 16-lane group of the activation ds_read_b128 of every (tile row, tap) must touch 16 distinct 16-B bank quads
 template <int KS>
 constexpr bool wide_swizzle_ok() {
-    using G = WideGeom<KS>;
+    using G = WideGeom<KS, 2>;
+    constexpr int WTH = G::WTH;
     constexpr int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
                                    {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
     for (int y = 0; y < WTH; ++y)
@@ -559,10 +568,11 @@ __device__ unsigned long long g_dwprobe[256 * 8];
 #define DWP_ADD(slot, t0) do { (void)(t0); } while (0)
 #endif
 
-template <bool LO>
+template <bool LO, int R>
 __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
     constexpr int KS = LO ? 1 : 2;
-    using G = WideGeom<KS>;
+    using G = WideGeom<KS, R>;
+    constexpr int WTH = G::WTH, WNPIX = G::WNPIX;
     constexpr int NW = G::NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const DenseH16P& p = pp.d;
@@ -613,17 +623,17 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
     };
 
     // activation fragment addresses (tile-relative, the same for every item): tile row yr = 2 w + r, tap -> byte offset in a stage buffer
-    int baddr[2][9];
+    int baddr[R][9];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int P = (2 * w + r + tap / 3) * WPW + li + tap % 3;
+            const int P = (R * w + r + tap / 3) * WPW + li + tap % 3;
             baddr[r][tap] = P * G::PIX_BYTES + ((lh ^ ((P >> G::FSHIFT) & G::FMASK)) << 4);
         }
     const int waddr = G::PATCH_BYTES + lane * 16;
 
-    f32x16 acc[2][2];                             // [nt][r]
+    f32x16 acc[2][R];                             // [nt][r]
     float* lbias = reinterpret_cast<float*>(lds + 2 * G::STAGE_BYTES);      // the layer's 64 biases behind the stage buffers (an epilogue that
     if (t < 64) lbias[t] = p.bias[t];                                       // fetched them from L2 started with a dependent round trip per tile row)
 #ifdef CIAOSR_PROBE
@@ -634,31 +644,34 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
     int item = (int)blockIdx.x;
     if (item >= pp.n_items) return;
     int S = 0;                                    // stages done: buffer parity
+    bool epi_sync = false;                        // an epilogue's LDS transposes are not yet fenced from the next DMA pieces (workgroup-uniform)
     {   // very first stage of this workgroup
         const int tl = item % pp.tiles_per_img;
         set_goff((tl / pp.tiles_x) * WTH, (tl % pp.tiles_x) * WTW);
-        const int rot0 = tl % NST;
+        const int rot0 = (((tl / pp.tiles_x) * WTH / 16) * pp.tiles_x + tl % pp.tiles_x) % NST;     // index of the 16 x 32 parent tile
         if (w < G::DW) {
 #pragma unroll
             for (int s = 0; s < G::SLOTS; ++s) dma_slot(s, 0, rot0, item / pp.tiles_per_img);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every CU pulls its first 75 KB at the same time (19 MB chip-wide: ~5 us).  Taps 0 .. 2 need the patch and a third of the weights:
+        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(G::SLOTS - G::PRO_SLOTS) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         DWP_ADD(7, dw_t0);
     }
+    bool pro_tail = true;                         // the rest of the first stage's weights is still in flight (workgroup-uniform)
 #pragma unroll 1
     for (; item < pp.n_items; item += grid) {
         const int img = item / pp.tiles_per_img, tl = item - img * pp.tiles_per_img;
         const int ty0 = (tl / pp.tiles_x) * WTH, tx0 = (tl % pp.tiles_x) * WTW;
-        const int rot = tl % NST;
+        const int rot = ((ty0 / 16) * pp.tiles_x + tl % pp.tiles_x) % NST;       // by the 16 x 32 parent tile: the same in both tile shapes
         const int nitem = item + grid;
         const bool has_next = nitem < pp.n_items;
         const int nimg = has_next ? nitem / pp.tiles_per_img : 0, ntl = has_next ? nitem - nimg * pp.tiles_per_img : 0;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < R; ++r)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[nt][r][e] = 0.f;
 #pragma unroll 1
@@ -668,11 +681,11 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
             const bool more = !last || has_next;
             int nhg = st + 1 + rot;                                   // physical stage the DMAs of this stage fetch
             if (nhg >= NST) nhg -= NST;
-            if (last) nhg = has_next ? ntl % NST : 0;
+            if (last) nhg = has_next ? (((ntl / pp.tiles_x) * WTH / 16) * pp.tiles_x + ntl % pp.tiles_x) % NST : 0;
             const int nim = last ? nimg : img;
             const int buf = S & 1;
             const unsigned char* pb = lds + buf * G::STAGE_BYTES;
-            uint4 a[3][2][NW], b[3][2];                               // [set][nt][weight set], [set][r]: operands are read TWO steps ahead
+            uint4 a[3][2][NW], b[3][R];                               // [set][nt][weight set], [set][r]: operands are read TWO steps ahead
             auto load_ab = [&](int set, int tap, int ks) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -680,7 +693,7 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
                     for (int lo = 0; lo < NW; ++lo)
                         a[set][nt][lo] = *reinterpret_cast<const uint4*>(pb + waddr + (((tap * KS + ks) * 2 + nt) * NW + lo) * 1024);
 #pragma unroll
-                for (int r = 0; r < 2; ++r) b[set][r] = *reinterpret_cast<const uint4*>(pb + (baddr[r][tap] ^ (ks << 5)));
+                for (int r = 0; r < R; ++r) b[set][r] = *reinterpret_cast<const uint4*>(pb + (baddr[r][tap] ^ (ks << 5)));
             };
             // (with eight waves on the LDS port a ds_read_b128 takes longer than the 4 MFMAs of one step: one step of lookahead left the
             // waves parked in s_waitcnt for 41 % of their cycles, SQ_WAIT_ANY)
@@ -692,13 +705,21 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
                     const int idx = tap * KS + ks, cur = idx % 3;
+                    if (idx + 2 == 3 * KS && pro_tail) {
+                        // first stage of the launch: the operands of tap 3 are READ here (two steps ahead).  Behind the prologue's last pieces
+                        // this wave has issued the next stage's pieces of the taps it has finished: those may stay in flight
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "i"(((3 * KS - 2) / KS) * G::PER_TAP) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        __builtin_amdgcn_sched_barrier(0);
+                        pro_tail = false;
+                    }
                     if (idx + 2 < 9 * KS) load_ab((idx + 2) % 3, (idx + 2) / KS, (idx + 2) % KS);
 #pragma unroll
                     for (int lo = 0; lo < NW; ++lo)
 #pragma unroll
                         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                            for (int r = 0; r < 2; ++r) acc[nt][r] = mfma_h16<kF16>(a[cur][nt][lo], b[cur][r], acc[nt][r]);
+                            for (int r = 0; r < R; ++r) acc[nt][r] = mfma_h16<kF16>(a[cur][nt][lo], b[cur][r], acc[nt][r]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 // The DMA pieces of the next stage are issued by waves 0 .. 3 ONLY -- one wave per SIMD, the older of its pair -- two or three
@@ -707,6 +728,9 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
                 // showed both waves of a SIMD stuck in their DMA issue at the same time: the older took 47 cycles per MFMA, the younger was
                 // starved and then ran ALONE at 30.5 -- 5590 cycles per stage against the 4608 of MFMA issue.  Now the younger wave of every
                 // SIMD is pure MFMA + LDS reads and fills the pipe whenever the older one is busy issuing.
+                // the barrier between the previous item's epilogue transposes and the first DMA piece into their buffer sits HERE, behind the
+                // first tap's MFMAs of the next item: a wave that leaves its epilogue early feeds the matrix pipe instead of waiting
+                if (tap == 0 && epi_sync) { __syncthreads(); epi_sync = false; }
                 if (more && w < G::DW) {
 #pragma unroll
                     for (int e = 0; e < G::PER_TAP; ++e)
@@ -734,8 +758,8 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
             unsigned char* tb = lds + ((S - 1) & 1) * G::STAGE_BYTES + w * 4096;
             const int pr0 = lane >> 3, c8 = lane & 7;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int y = ty0 + 2 * w + r;
+            for (int r = 0; r < R; ++r) {
+                const int y = ty0 + R * w + r;
                 const bool y_ok = y < p.H;
                 // 16-bit copy: [32 pixels][64 channels x 2 B], 16-B chunks swizzled with the pixel
 #pragma unroll
@@ -777,7 +801,7 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
                 }
             }
         }
-        if (has_next) __syncthreads();            // the next stage's DMA pieces land in the buffer the transposes used
+        epi_sync = has_next;                      // the next stage's DMA pieces land in the buffer the transposes used: barrier in front of them (below)
         DWP_ADD(3, dw_e0);
 #ifdef CIAOSR_PROBE
         dwacc[6] += 1;
@@ -791,7 +815,7 @@ __global__ __launch_bounds__(512) void dense_h16_wide_kernel(DenseWideP pp) {
 #endif
 }
 
-bool dense_h16_wide_ok(int H, int W) { return ceil_div(H, WTH) * ceil_div(W, WTW) >= 32; }
+bool dense_h16_wide_ok(int H, int W) { return ceil_div(H, 16) * ceil_div(W, WTW) >= 32; }
 
 // fp32 columns [col, col+64) of X -> the same columns of the bf16 copy
 __global__ void cast_group_h16_kernel(const float* __restrict__ X, int ldx, unsigned short* __restrict__ Xb, int ldxb, int col,
@@ -842,17 +866,21 @@ int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int 
         DenseWideP wp;
         wp.d = p;
         wp.tiles_x = ceil_div(W, WTW);
-        wp.tiles_per_img = wp.tiles_x * ceil_div(H, WTH);
+        // tile shape by the size of the LAUNCH (bitwise the same outputs, see WideGeom): rounds of the 256 CUs x relative cost of a round
+        const long n16 = (long)wp.tiles_x * ceil_div(H, 16) * n_img, n8 = (long)wp.tiles_x * ceil_div(H, 8) * n_img;
+        const bool small = 1.2 * (double)((n8 + 255) / 256) < 2.0 * (double)((n16 + 255) / 256);
+        wp.tiles_per_img = wp.tiles_x * ceil_div(H, small ? 8 : 16);
         wp.n_items = wp.tiles_per_img * n_img;
         wp.wf_bytes = (unsigned)((size_t)2 * p.nks * 1024);
         const int grid = wp.n_items < 256 ? wp.n_items : 256;        // persistent: one workgroup per CU
-        if (p.wf_lo) {
-            CIAOSR_BIG_LDS(dense_h16_wide_kernel<true>, WideGeom<1>::LDS);
-            hipLaunchKernelGGL(dense_h16_wide_kernel<true>, dim3(grid), dim3(512), WideGeom<1>::LDS, s, wp);
-        } else {
-            CIAOSR_BIG_LDS(dense_h16_wide_kernel<false>, WideGeom<2>::LDS);
-            hipLaunchKernelGGL(dense_h16_wide_kernel<false>, dim3(grid), dim3(512), WideGeom<2>::LDS, s, wp);
-        }
+#define CIAOSR_LAUNCH_WIDE(LO_, R_)                                                                                              \
+        do {                                                                                                                     \
+            CIAOSR_BIG_LDS((dense_h16_wide_kernel<LO_, R_>), (WideGeom<(LO_) ? 1 : 2, R_>::LDS));                                \
+            hipLaunchKernelGGL((dense_h16_wide_kernel<LO_, R_>), dim3(grid), dim3(512), (WideGeom<(LO_) ? 1 : 2, R_>::LDS), s, wp); \
+        } while (0)
+        if (p.wf_lo) { if (small) CIAOSR_LAUNCH_WIDE(true, 1); else CIAOSR_LAUNCH_WIDE(true, 2); }
+        else { if (small) CIAOSR_LAUNCH_WIDE(false, 1); else CIAOSR_LAUNCH_WIDE(false, 2); }
+#undef CIAOSR_LAUNCH_WIDE
         return launch_status("dense_wide" CIAOSR_H16_SUFFIX);
     }
     // no process-global switches in the product library: the developer A/B knobs exist in the CIAOSR_PROBE build only

@@ -90,12 +90,19 @@ typedef struct ciaosr_options {
     int decode_rows;        /* fp32 fused decode: queries per workgroup, 32 (default) or 64 */
     int bf16_single;        /* _bf16 entries: 0 (default) = every weight enters the MFMA as a bf16 PAIR hi + lo (hi = bf16(w),
                              * lo = bf16(w - hi): 16 mantissa bits, two MFMAs per product); 1 = hi only (one MFMA, 8 bits).
-                             * Rounding WEIGHTS to 8 bits is a fixed perturbation whose response is spatially coherent and
-                             * fails the 0.01 dB PSNR gate on smooth features; activations stay single bf16 */
+                             * Rounding WEIGHTS to nearest is a fixed perturbation whose response is spatially coherent and fails
+                             * the 0.01 dB PSNR gate on smooth features (0.042 dB on the full C3 tile).  A binding that
+                             * wants the single form INSIDE the gate packs the head's weights the way ciaosr_amd/head_hip.py::
+                             * _build_single does (round 6: error-feedback rounding along K -- a weight that already is a bf16
+                             * number passes through the pack entries unchanged -- and bias[i] += (w - w_q) E[x] with the layer's
+                             * mean input measured once on a calibration image): 0.0004 dB.  Activations stay single bf16 */
     int dense_direct;       /* _f32 RDN trunk, big maps: 0 (default) = dense layers in Winograd form -- F(4x4, 3x3) when ciaosr_conv_t.frag_wino4
                              * is given, else F(2x2, 3x3) when frag_wino is (fp32 arithmetic on transformed operands: not bitwise a direct
                              * convolution; the trunk stays within 2e-4 x its scale of the direct form, tests/test_hip_parity.py);
-                             * 1 = the direct halo-resident kernel (exact fmaf chains); 2 = F(2x2, 3x3) even when frag_wino4 is given */
+                             * 1 = the direct halo-resident kernel (exact fmaf chains); 2 = F(2x2, 3x3) even when frag_wino4 is given.
+                             * _bf16 / _f16 RDN trunk, big maps (round 6): 0 = the dense layers on 16x32-pixel tiles with one persistent
+                             * workgroup per CU (dense_h16_wide_kernel; from 32 such tiles per image on), 1 = the 12x12-pixel kernels of
+                             * rounds 1-3 (same 16-bit products, K split over the waves: another summation order) */
     int csa_scores_gemm;    /* _f32 cs_attn with 32 match channels: 0 (default) = correlation scores as a 3x3 diagonal box sum of the
                              * per-pixel correlation (K = 32, no patch rows); 1 = the 288-wide patch-row GEMM.  Same fp32 products, other order */
     int csa_attn_tile128;   /* _f32 cs_attn, attn.V (softmax formed in the operand staging): 0 (default) = the 192 x 256 one-workgroup-per-CU kernel

@@ -1132,8 +1132,9 @@ def test_dense_16bit_wide_tiles_vs_12x12_kernels_and_batch_invariance(dev, preci
     big maps (`dense_direct = 1` keeps them): the same 16-bit products summed in a different order, so the RDN trunk features agree to the
     element type's rounding of the layer outputs -- on a map that is a whole number of tiles and on a ragged one (150 x 170: partial
     tiles in both directions, halo outside the image on every side); against the fp32 trunk both sit at the same distance.  And a
-    tile's result must not depend on the batch it is computed in: images [A, B, A, B, A] through one batched call (5 x 72 = 360 items on
-    256 persistent workgroups: some walk two items) are bitwise the single-image results."""
+    tile's result must not depend on the batch it is computed in: images [A, B, A, B, A] and a batch of seven through one batched call
+    (persistent workgroups walking several items; the 8 x 32 tile shape of small launches against the 16 x 32 shape of full ones) are bitwise
+    the single-image results."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd.init_utils import seeded_init_, synthetic_pair
     h, w = hw
@@ -1160,9 +1161,14 @@ def test_dense_16bit_wide_tiles_vs_12x12_kernels_and_batch_invariance(dev, preci
     assert rms_new < 1.3 * rms_old + 1e-6 * scale, (rms_new, rms_old)
     assert torch.equal(enc.forward_hwc(xa, new), fa), 'rerun differs'
     fb = enc.forward_hwc(xb, new)
-    batch = enc.forward_hwc_batch(torch.stack([xa, xb, xa, xb, xa]), new)
-    for i, want in enumerate((fa, fb, fa, fb, fa)):
-        assert torch.equal(batch[i], want), (i, (batch[i] - want).abs().max().item())
+    # five images: the launch still takes the 8 x 32-pixel tile shape of small launches (like the single image); seven images of 192 x 192
+    # are 504 items of the 16 x 32 shape -- the other template instantiation, whose outputs must be bitwise the same (the accumulation order
+    # of an output does not depend on the tile shape)
+    for seq in ((0, 1, 0, 1, 0), (0, 1, 1, 0, 1, 0, 0)):
+        want = [(fa, fb)[i] for i in seq]
+        batch = enc.forward_hwc_batch(torch.stack([(xa, xb)[i] for i in seq]), new)
+        for i in range(len(seq)):
+            assert torch.equal(batch[i], want[i]), (len(seq), i, (batch[i] - want[i]).abs().max().item())
 
 
 def _f16_storage_points_report(model, lq, dev):

@@ -376,3 +376,33 @@ def test_chained_head_blob_sizes_follow_the_documented_stream_layout():
     assert lib.ciaosr_head_chain_bytes(ctypes.byref(w), 0) == 16 * KB + (48 + 58) * 16 * KB           # 57 units padded, no imnet_q stream
     assert lib.ciaosr_head_chain_bytes(ctypes.byref(head(64, hidden=(256, 256, 128, 256))), 0) == 0
     assert lib.ciaosr_head_chain_bytes(ctypes.byref(head(64, local_size=3)), 0) == 0
+
+
+def test_round6_host_logic_options_tile_batch_and_error_feedback_rounding():
+    """Host-side pieces of round 6 that need no GPU: `Options('bf16-single')` is the bf16 entry with `bf16_single = 1`; the default
+    tile batch is 7 wherever the dense layers run a 16x32-pixel-tile kernel (fp32 Winograd F(4x4) and, now, the 16-bit modes) and 8 with
+    `dense_direct = 1`; error-feedback rounding to bf16 (`PackedHead._ef_round_bf16`) returns bf16 numbers whose rounding error has every
+    prefix sum -- the row sum in particular -- within half an ulp of the largest element, where round-to-nearest accumulates a random walk."""
+    from ciaosr_amd import hip_ops
+    from ciaosr_amd.head_hip import PackedHead
+    o = hip_ops.Options('bf16-single')
+    assert o.precision == 'bf16' and o.bf16_single == 1 and o.suffix == 'bf16' and 'bf16-single' in hip_ops.PRECISIONS
+    assert hip_ops.Options('bf16').bf16_single == 0
+    r = _small_restorer(dict(scale=2))
+    assert r.tile_batch() == 7 and r.tile_batch(hip_ops.Options('f16')) == 7 and r.tile_batch(hip_ops.Options('bf16-single')) == 7
+    assert r.tile_batch(hip_ops.Options('f16', dense_direct=1)) == 8 and r.tile_batch(hip_ops.Options('fp32', dense_direct=1)) == 8
+    assert r.tile_batch(hip_ops.Options('f16x3')) == 7                       # fp32 trunk
+    r.test_cfg['tile_batch'] = 3
+    assert r.tile_batch(hip_ops.Options('f16')) == 3
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(64, 576, generator=g) * 0.03
+    q = PackedHead._ef_round_bf16(w)
+    assert q.dtype == torch.float32 and torch.equal(q.to(torch.bfloat16).float(), q)          # bf16 numbers: the pack kernels' rounding is the identity
+    rne = w.to(torch.bfloat16).float()
+    import math
+    ulp = 2.0 ** (math.floor(math.log2(w.abs().max().item())) - 7)           # spacing of bf16 numbers (8-bit significand) at the largest magnitude
+    prefix_ef = (q.double() - w.double()).cumsum(1).abs().max().item()
+    prefix_rne = (rne.double() - w.double()).cumsum(1).abs().max().item()
+    assert prefix_ef <= 0.5 * ulp + 1e-12, (prefix_ef, ulp)
+    assert prefix_rne > 4 * prefix_ef, (prefix_rne, prefix_ef)
+    assert (q - w).abs().max().item() <= ulp                                 # an element moves by at most one spacing (rne: half)
