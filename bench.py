@@ -447,7 +447,8 @@ def staged_hbm_rooflines(model, tl, Q, HW, tile_lr, scale, dev):
     """K1 / K4 of the two staged routes on one tile, HIP events on the launch stream: flat scalars (k4_*, k1_*) for the driver's record plus
     the per-kernel objects.  K4 = local_attention_kernel<4> (ciaosr_net.py:203-216): Q x 22 064 B; K1 = gather_rows_kernel
     (ciaosr_net.py:176-196): Q x 21 936 B, both SURVEY 8(d).  `head_rows` is the staged C route's hoisted K1 (layer-1 table rows + the
-    4-column tail instead of the 580 / 644-wide inputs)."""
+    4-column tail instead of the 580 / 644-wide inputs; priced on its nominal bytes -- two table rows read, two hidden rows written per
+    (query, sample) -- of which the reads mostly hit on-die)."""
     from ciaosr_amd import hip_ops
     from ciaosr_amd._lib import HEAD_STAGED
     out, hb = {}, {}

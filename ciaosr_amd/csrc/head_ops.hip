@@ -100,6 +100,60 @@ __global__ __launch_bounds__(256) void head_rows_kernel(HeadRowsP p) {
     }
 }
 
+// The same rows with ONE WAVE PER QUERY (round 6; 256-wide first layers = one float4 per lane): the J (query, sample) rows of a query share its
+// coordinate loads and index math, the lane's eight tail-weight rows are fetched once instead of J times, and -- the point -- all 2 J table
+// rows are requested before the first store.  The one-row-per-wave form above puts 2 KB of stores behind a three-deep dependent load chain
+// (coord -> key sample -> table row) with one row in flight per wave: 0.33 of the HBM peak on its nominal bytes, latency- not bandwidth-bound
+// (profiles/r6_c3tile_staged_rooflines.txt).  Same arithmetic per element: bitwise the same rows.
+template <int J>
+__global__ __launch_bounds__(256) void head_rows_query_kernel(HeadRowsP p) {
+    const int lane = threadIdx.x & 63;
+    const int i = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= p.nq) return;
+    const long q = p.q0 + i;
+    const float cy = p.coord[2 * q], cx = p.coord[2 * q + 1];
+    const long c0 = cell0_index(q, p.chunk);
+    const float c0y = p.cell[2 * c0], c0x = p.cell[2 * c0 + 1];
+    const float sy = mul_rn(p.cell[2 * q], (float)p.H);       // scale_ = cell * [H, W]  (:191-193)
+    const float sx = mul_rn(p.cell[2 * q + 1], (float)p.W);
+    KeySample s[J];
+    int kpix[J];
+    float4 tk[J], tv[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        s[j] = key_sample(cy, cx, c0y, c0x, p.H, p.W, j, p.local_size);
+        kpix[j] = s[j].ky * p.W + s[j].kx;
+        tk[j] = reinterpret_cast<const float4*>(p.Tk + (size_t)kpix[j] * p.wk0)[lane];
+        tv[j] = reinterpret_cast<const float4*>(p.Tv + (size_t)kpix[j] * p.wv0)[lane];
+    }
+    float4 wkt[4], wvt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        wkt[e] = *reinterpret_cast<const float4*>(p.tailK + (size_t)(4 * lane + e) * p.ld_tail_k);
+        wvt[e] = *reinterpret_cast<const float4*>(p.tailV + (size_t)(4 * lane + e) * p.ld_tail_v);
+    }
+    if (lane == 0) {
+        const int iy = nearest_index(cy, p.H), ix = nearest_index(cx, p.W);
+        p.q_idx[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? iy * p.W + ix : -1;
+    }
+    auto act = [](float v, int code) -> float {
+        return code == CIAOSR_ACT_RELU ? fmaxf(v, 0.f) : code == CIAOSR_ACT_SIN ? sinf(v) : code == CIAOSR_ACT_COS ? cosf(v) : v;
+    };
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const long row = (long)i * J + j;
+        if (lane == 0) p.k_idx[row] = kpix[j];
+        float rk[4] = {tk[j].x, tk[j].y, tk[j].z, tk[j].w}, rv[4] = {tv[j].x, tv[j].y, tv[j].z, tv[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rk[e] = act(rk[e] + wkt[e].x * s[j].rel_y + wkt[e].y * s[j].rel_x + wkt[e].z * sy + wkt[e].w * sx, p.relu_k);
+            rv[e] = act(rv[e] + wvt[e].x * s[j].rel_y + wvt[e].y * s[j].rel_x + wvt[e].z * sy + wvt[e].w * sx, p.relu_v);
+        }
+        reinterpret_cast<float4*>(p.Hk + (size_t)row * p.wk0)[lane] = make_float4(rk[0], rk[1], rk[2], rk[3]);
+        reinterpret_cast<float4*>(p.Hv + (size_t)row * p.wv0)[lane] = make_float4(rv[0], rv[1], rv[2], rv[3]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1 gather rows: the MLP inputs as the reference assembles them (net:176-196), one wavefront per (query, sample).
 // HBM traffic per query (fp32, C=64): write 4*580*4 + 4*644*4 + 576*4 B (21 936 B incl. coords).
@@ -485,7 +539,10 @@ int head_indices(const float* coord, const float* cell, long q0, int nq, int chu
 
 int head_rows(const HeadRowsP& p, hipStream_t s) {
     ProfScope prof("head_rows", s);
-    hipLaunchKernelGGL(head_rows_kernel, dim3(ceil_div((long)p.nq * p.J, 4)), dim3(256), 0, s, p);
+    if (p.wk0 == 256 && p.wv0 == 256 && p.J == 4)       // the configs' head: one wave per query, every table row of the query in flight at once
+        hipLaunchKernelGGL(head_rows_query_kernel<4>, dim3(ceil_div((long)p.nq, 4)), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL(head_rows_kernel, dim3(ceil_div((long)p.nq * p.J, 4)), dim3(256), 0, s, p);
     return launch_status("head_rows");
 }
 

@@ -20,7 +20,8 @@ Q_TILE, CHUNK = 768 * 768, 30000
 LAUNCHES = -(-Q_TILE // CHUNK)
 # algorithmic HBM bytes per query (SURVEY 8(d), C = 64, x4)
 ALGO = {'local_attention_kernel<4>': 22064.0, 'gather_rows_kernel': 21936.0, 'local_attention_h16_kernel': 11056.0,
-        'head_rows_kernel': 4 * 2 * 256 * 4.0 * 2}          # hoisted K1: reads 2 table rows + writes 2 hidden rows of 256 fp32 per (query, sample)
+        'head_rows_kernel': 4 * 2 * 256 * 4.0 * 2,          # hoisted K1: reads 2 table rows + writes 2 hidden rows of 256 fp32 per (query, sample)
+        'head_rows_query_kernel': 4 * 2 * 256 * 4.0 * 2}    # ... one wave per query (round 6)
 
 stats_rows, pmc, table = [], {}, []
 for route in ROUTES:
@@ -44,7 +45,7 @@ for route in ROUTES:
             continue
         avg_ns, calls = float(hit[0]['AverageNs']), int(hit[0]['Calls'])
         cnt = [v for k, v in pm.items() if kname in k]
-        waves_per_q = 4 if kname in ('gather_rows_kernel', 'head_rows_kernel') else 1
+        waves_per_q = 4 if kname in ('gather_rows_kernel', 'head_rows_kernel') else 1      # head_rows_query_kernel: one wave per query
         # queries of an average launch: from the counter pass's grid sizes (one wavefront per query / per (query, sample) row) -- the as-written
         # route launches per eval_bsize chunk (20 per tile: 19 x 30 000 + 19 824), the C library's staged route per 65 536 queries (9 per tile)
         q_launch = cnt[0]['waves_per_launch'] / waves_per_q if cnt else Q_TILE / LAUNCHES
