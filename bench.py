@@ -1124,6 +1124,13 @@ def main():
                 line['cpu_baseline'] = cpu_baseline_c3(n_tiles_img, out_pixels, scale)
         if world == 1 and args.workload == 'c3' and args.head_route == 'fused':
             line['scale_model'] = scale_model(model, ms, n_tiles_img, lr_h * scale, lr_w * scale, dev)
+        if 'extras' in line and 'c3_f16_mode_mpix_s' in line['extras']:
+            # the opt-in modes of the same workload at a glance (whole C3 image, one timed step each; PSNR-gated, see README): flat, up front
+            ex = line['extras']
+            line['modes_mpix_s'] = {'fp32 (headline)': line['value'],
+                                    **{nm: ex[f'c3_{key}_mode_mpix_s'] for nm, key in (('f16x3 (fp32 tolerance)', 'f16x3'), ('f16x3-fast', 'f16x3_fast'), ('f16', 'f16'),
+                                                                                          ('bf16-single', 'bf16_single'), ('f16-pairs', 'f16_pairs'), ('bf16 (weight pairs)', 'bf16'))
+                                       if f'c3_{key}_mode_mpix_s' in ex}}
         # key order of the printed line: the contract's keys, the flat roofline scalars, the CPU baseline and the scaling model FIRST; the bulky
         # per-kernel tables and extras last (a consumer that keeps only the head or only the tail of a > 16-KB line still gets the headline)
         if line.get('roofline'):
