@@ -127,8 +127,8 @@ def kernel_work(tag, Q, HW, C=64, hidden=256, J=4, blocks=16, layers=8):
     the exact layer-1 hoist; bytes for the HBM-bound K4 = SURVEY 8(d)'s 22 064 B/query.  Kernels that reach the
     same result with fewer multiplies (Winograd, box sum) are priced on the reference's form here; `executed_ratio` gives the
     flops their MFMAs actually execute, so that a fraction above 1 never stands alone."""
-    if tag.endswith('_f16x3'):             # both operands as half pairs: the same algorithmic work, three MFMAs per product
-        tag = tag[:-6] + '_bf16'
+    if tag.endswith('_f16x3') or tag.endswith('_bf16x3'):      # both operands as 16-bit pairs: the same algorithmic work, three MFMAs per product
+        tag = tag[:tag.rindex('_')] + '_bf16'
     if tag.endswith('_f16'):               # IEEE-half kernels: the bf16 kernels' work and peak (same MFMA rate)
         tag = tag[:-4] + '_bf16'
     if tag in ('head_kv_chain_bf16', 'head_kv_chain_pairs_bf16'):   # the weights-stationary form of the 16-bit kv kernel (round 5): same work
@@ -200,7 +200,7 @@ def _executed_ratio(tag, HW, C=64, precision='fp32', bf16_single=False):
     dense_wino_f32.hip); the fp32 correlation scores are a 3x3 diagonal box sum of a K = C/2 per-pixel correlation whose D blocks
     of (8+2)x(16+2) query-halo x (4+2)x(16+2) key-halo pixels are computed as 6 x 4 MFMA tiles of 32x32 per 8x16 x 4x16 item
     (csa_scores_f32.hip); hi + lo weight pairs issue two MFMAs per product (bf16 pairs, f16-pairs), activation pairs three."""
-    if tag.endswith('_f16x3'):
+    if tag.endswith('_f16x3') or tag.endswith('_bf16x3'):
         return 3.0
     base = tag[:-5] if tag.endswith('_bf16') else (tag[:-4] if tag.endswith('_f16') else tag)
     half = base != tag
@@ -603,7 +603,7 @@ def other_configs(dev):
                                   test_cfg=dict(scale=sc)).eval()
             seeded_init_(m, seed=0, gain=1.0)
             m = m.to(dev)
-            m.test_cfg['allow_f16_substitute'] = True      # C5 'bf16' = the f16 kernels (LocalImplicitSRSWINIR.effective_options); labelled as such below
+            # C5 'bf16' runs as 'bf16x3' (bf16 hi + lo weights and activations in the head: LocalImplicitSRSWINIR.effective_options); labelled below
             lq = synthetic_pair(48, 48, 4)[0].to(dev)
             ht = wt = round(48 * sc)
             coord, cell = hip_ops.make_coord_cell(ht, wt, dev)
@@ -612,7 +612,8 @@ def other_configs(dev):
             for prec in precisions:
                 o = hip_ops.Options(prec)
                 eff = m.generator.effective_options(o)
-                label = f'{name}_{prec}' if eff.precision == prec else f'{name}_{prec}_runs_as_{eff.precision}'
+                eff_name = eff.precision + ('x3' if eff.f16_pairs == 2 else '')
+                label = f'{name}_{prec}' if eff_name == prec else f'{name}_{prec}_runs_as_{eff_name}'
                 for _ in range(3):
                     m.restore(lq, coord, cell, options=o)
                 # millisecond-scale, launch-bound steps timed from the host: the best of three groups of 20 (a group of 10 picked up host
@@ -669,7 +670,7 @@ def main():
     ap.add_argument('--no-extras', action='store_true', help='skip the extra measurements (C2, one bf16 tile, staged K4) after the timed region')
     ap.add_argument('--no-rccl-probe', action='store_true', help='N = 1: do not start the child that creates a 1-rank RCCL communicator on this GPU '
                     '(counts `rccl_ranks`, runs one grouped self send / receive of a 7-MB tile behind queued work) after the timed region')
-    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'],
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16', 'bf16x3', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast'],
                     help='fp32 (default, the reference\'s arithmetic): exact-fp32 MFMA everywhere; bf16: bf16 MFMA inputs (weights as hi + lo '
                          'pairs), fp32 accumulation; f16: IEEE half MFMA inputs (one MFMA per product, saturating conversions), fp32 accumulation; '
                          'f16-pairs: half activations, every weight as a half hi + lo pair (two MFMAs per product); f16x3: the fp32-tolerance '
@@ -1002,8 +1003,10 @@ def main():
                 + ('; head weights and activations as half hi+lo pairs (three MFMAs per product), fp32 trunk' if args.precision == 'f16x3' else '')
                 + ('; head weights and activations as half hi+lo pairs (three MFMAs per product), trunk with half weight pairs' if args.precision == 'f16x3-fast' else '')
                 if args.precision.startswith('f16') else
-                'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
-                + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs')),
+                ('bf16 MFMA inputs (fp32 accumulate): head weights and activations as bf16 hi+lo pairs (three MFMAs per product), fp32 trunk, bf16 cs_attn contractions'
+                 if args.precision == 'bf16x3' else
+                 'bf16 MFMA inputs (fp32 accumulate) in the head, the dense layers and the cs_attn contractions; weights as '
+                 + ('single bf16' if args.bf16_single else 'bf16 hi+lo pairs'))),
             'data': 'synthetic',
             'config': {'workload': wl_desc + (', fp32' if args.precision == 'fp32' else f', {args.precision} mode')
                        + ('' if world == 1 else (f'; encoder on rank 0, RCCL broadcast of the feature map, query range sharded over {world} GPUs, '
@@ -1068,6 +1071,8 @@ def main():
                 if 'f16x3' in hip_ops.PRECISIONS:
                     modes.append(('f16x3', hip_ops.Options('f16x3'), 'f16x3'))
                     modes.append(('f16x3_fast', hip_ops.Options('f16x3-fast'), 'f16x3-fast'))
+                if 'bf16x3' in hip_ops.PRECISIONS:
+                    modes.append(('bf16x3', hip_ops.Options('bf16x3'), 'bf16x3'))
                 o16, oh = modes[0][1], modes[2][1]
                 for nm, o, prec in modes:
                     model.restore(tl, options=o)
@@ -1128,7 +1133,7 @@ def main():
             # the opt-in modes of the same workload at a glance (whole C3 image, one timed step each; PSNR-gated, see README): flat, up front
             ex = line['extras']
             line['modes_mpix_s'] = {'fp32 (headline)': line['value'],
-                                    **{nm: ex[f'c3_{key}_mode_mpix_s'] for nm, key in (('f16x3 (fp32 tolerance)', 'f16x3'), ('f16x3-fast', 'f16x3_fast'), ('f16', 'f16'),
+                                    **{nm: ex[f'c3_{key}_mode_mpix_s'] for nm, key in (('f16x3 (fp32 tolerance)', 'f16x3'), ('bf16x3 (fp32 tolerance)', 'bf16x3'), ('f16x3-fast', 'f16x3_fast'), ('f16', 'f16'),
                                                                                           ('bf16-single', 'bf16_single'), ('f16-pairs', 'f16_pairs'), ('bf16 (weight pairs)', 'bf16'))
                                        if f'c3_{key}_mode_mpix_s' in ex}}
         # key order of the printed line: the contract's keys, the flat roofline scalars, the CPU baseline and the scaling model FIRST; the bulky

@@ -85,7 +85,7 @@ static int rdn_forward(const float* x_nchw, int B, int H, int W, const ciaosr_rd
     // f16_pairs = 2 ("f16x3", the fp32-tolerance fast mode): the trunk runs its fp32 route -- half ACTIVATIONS in 128 dense layers
     // alone cost rms 4.6e-5 / max 4e-4 on the full C3 tile, and activation pairs (three MFMAs per product + a second patch) would
     // cost the dense layers about what the fp32 Winograd form does
-    if (prec == kF16 && opt && opt->f16_pairs == 2) prec = kF32;
+    if ((prec == kF16 || prec == kBF16) && opt && opt->f16_pairs == 2) prec = kF32;      // "f16x3" and (round 6) "bf16x3"
     const bool bf16 = prec != kF32;      // a 16-bit MFMA mode (bf16 or f16 entry)
     // route thresholds (per-call options; defaults: halo-resident dense layers from 128 tiles of 12x12 pixels on, small-map
     // kernels up to 18432 pixels = 128 such tiles)

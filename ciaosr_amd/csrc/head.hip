@@ -131,13 +131,14 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
     const bool bf16 = prec != kF32;                  // a 16-bit MFMA mode (bf16 or f16 entry)
     const int route = opt ? opt->head_route : 0;
     // hi + lo weight pairs: the bf16 entry unless single is asked for, the f16 entry when pairs are asked for
-    const bool lo = (prec == kBF16 && !(opt && opt->bf16_single)) || (prec == kF16 && opt && opt->f16_pairs);
+    const bool lo = (prec == kBF16 && (!(opt && opt->bf16_single) || (opt && opt->f16_pairs == 2))) || (prec == kF16 && opt && opt->f16_pairs);
     // f16_pairs = 2 / 3 ("f16x3" / "f16x3-fast"): the activations of the three MLP chains as half pairs too (head_fused_wide.hip), every table in fp32
-    const bool x3 = prec == kF16 && opt && opt->f16_pairs >= 2;
+    // (round 6: the _bf16 entry takes f16_pairs = 2 too -- "bf16x3": bf16 hi + lo weights AND activations; bf16_single is ignored then)
+    const bool x3 = (prec == kF16 && opt && opt->f16_pairs >= 2) || (prec == kBF16 && opt && opt->f16_pairs == 2);
     // f16x3 runs the wide-workgroup kernels (head_fused_wide.hip: its two activation arrays leave room for one workgroup per CU);
     // f16 / f16-pairs keep the 128-row kernels with two workgroups per CU (head_fused_h16.hip) and take the wide form -- 256 rows, half
     // the weight stream per MFMA, measured equal in time: one workgroup per CU exposes its gather phases -- only with head_route bit 3
-    const bool wide16 = prec == kF16 && (x3 || (route & CIAOSR_HEAD_WIDE_WG));
+    const bool wide16 = x3 || (prec == kF16 && (route & CIAOSR_HEAD_WIDE_WG));
     const int wide_mode = x3 ? 2 : (lo ? 1 : 0);
     CIAOSR_CHECK_ARG(feat_hwc && w && coord && cell && rgb && workspace && H >= 1 && W >= 1 && Q >= 1);
     CIAOSR_CHECK_ARG(options_ok(opt));
@@ -288,7 +289,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                 RUN(h16_ops(prec).head_kv_chain(kp, w, blob, lo ? 1 : 0, opt ? opt->query_grid_w : 0, chain_flag, s));
                 kp.gate = chain_flag;
             }
-            RUN(wide16 ? wide::head_kv_fused_wide(kp, wide_mode, s) : bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
+            RUN(wide16 ? (prec == kF16 ? f16::wide::head_kv_fused_wide(kp, wide_mode, s) : b16::wide::head_kv_fused_wide(kp, wide_mode, s))
+                       : bf16 ? h16_ops(prec).head_kv_fused(kp, s) : head_kv_fused(kp, s));
             const ciaosr_mlp_t& mq = w->q;
             FusedQP qp;
             qp.Z = Z; qp.ldz = p.Dv; qp.Dv = p.Dv;
@@ -311,7 +313,8 @@ static int head_forward(const float* feat_hwc, int H, int W, const ciaosr_head_w
                 RUN(h16_ops(prec).head_decode_chain(qp, w, qblob, lo ? 1 : 0, s));
                 continue;
             }
-            RUN(wide16 ? wide::head_decode_fused_wide(qp, wide_mode, s) : bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
+            RUN(wide16 ? (prec == kF16 ? f16::wide::head_decode_fused_wide(qp, wide_mode, s) : b16::wide::head_decode_fused_wide(qp, wide_mode, s))
+                       : bf16 ? h16_ops(prec).head_decode_fused(qp, s) : head_decode_fused(qp, s));
             continue;
         }
         HeadRowsP hp;

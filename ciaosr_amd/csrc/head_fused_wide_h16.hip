@@ -25,13 +25,18 @@
 // Same row order as head_fused_h16.hip generalised to QW = rows / 4 queries: row m = QW j + q (j = key sample), so the four samples of
 // a query are four row tiles of ONE lane and z = sum_j a_j value_j . w_v,j is four FMAs on the lane's own accumulators; swapped MFMA
 // operands (weights = A from L2 in pre-packed fragment order, activations = B from LDS via ds_read_b128); hidden layers in place.
-#define CIAOSR_F16 1
+// Round 6: compiled per element type like the other 16-bit units (-DCIAOSR_F16=1 -> ciaosr::f16::wide, =0 -> ciaosr::b16::wide).  The bf16
+// build carries the pair mode only ("bf16x3": bf16 hi + lo weights AND activations, 16 mantissa bits each, three MFMAs per product, fp32 Z):
+// what the SwinIR-CiaoSR head (BASELINE config 5, "bf16") runs, whose 8-bit single-bf16 activations miss the 0.01 dB gate (0.060 dB).
 #include "h16_util.h"
 #include "index_math.h"
 #include "ops.h"
 
 namespace ciaosr {
+namespace CIAOSR_H16_NS {
 namespace wide {
+
+constexpr bool kF16 = CIAOSR_F16 != 0;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -80,6 +85,12 @@ __device__ __forceinline__ void xstore4(__amdgpu_buffer_rsrc_t rsrc, unsigned by
 // (a, b) -> packed halves hi = half(clamp(x)), lo = half(clamp(x) - hi); RELU: clamp = [0, 65504], else [-65504, 65504]
 template <bool RELU>
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    if constexpr (!kF16) {      // bf16: no saturation (fp32 range); hi = bf16(x) to nearest even, lo = bf16(x - hi) (the residual is exact in fp32)
+        const float va = RELU ? fmaxf(a, 0.f) : a, vb = RELU ? fmaxf(b, 0.f) : b;
+        hi = pack_h16x2<false>(va, vb);
+        lo = pack_h16x2<false>(va - h16_lo<false>(hi), vb - h16_hi<false>(hi));
+        return;
+    }
     const float floor_ = RELU ? 0.f : -kHalfMax;
     const f32x2_t v = {__builtin_amdgcn_fmed3f(a, floor_, kHalfMax), __builtin_amdgcn_fmed3f(b, floor_, kHalfMax)};
     const f16x2_t h = __builtin_convertvector(v, f16x2_t);
@@ -95,22 +106,24 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
 }
 // hi + lo of packed element 0 / 1 back to fp32 (one v_fma_mix_f32 each: hi * 1.0 + lo, both half operands from their packed registers)
 __device__ __forceinline__ float pair0(unsigned hi, unsigned lo) {
+    if constexpr (!kF16) return h16_lo<false>(hi) + h16_lo<false>(lo);
     float r;
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi), "v"(lo));
     return r;
 }
 __device__ __forceinline__ float pair1(unsigned hi, unsigned lo) {
+    if constexpr (!kF16) return h16_hi<false>(hi) + h16_hi<false>(lo);
     float r;
     asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(hi), "v"(lo));
     return r;
 }
 // element 0 / 1 of a packed activation pair (AP: hi + lo) as fp32
 template <bool AP>
-__device__ __forceinline__ float act0(unsigned hi, unsigned lo) { if constexpr (AP) return pair0(hi, lo); else return h16_lo<true>(hi); }
+__device__ __forceinline__ float act0(unsigned hi, unsigned lo) { if constexpr (AP) return pair0(hi, lo); else return h16_lo<kF16>(hi); }
 template <bool AP>
-__device__ __forceinline__ float act1(unsigned hi, unsigned lo) { if constexpr (AP) return pair1(hi, lo); else return h16_hi<true>(hi); }
+__device__ __forceinline__ float act1(unsigned hi, unsigned lo) { if constexpr (AP) return pair1(hi, lo); else return h16_hi<kF16>(hi); }
 
-__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) { return mfma_h16<true>(a, b, c); }
+__device__ __forceinline__ f32x16 mfma(uint4 a, uint4 b, f32x16 c) { return mfma_h16<kF16>(a, b, c); }
 
 // Weight ring: RD stages, requested RD - 1 k-steps ahead.  A k-step of the 256-row modes is only 8 MFMAs = 256 cycles of the SIMD's
 // pipe, shared by its two waves: two steps ahead (the 128-row kernels' depth) is ~1000 cycles at best, about one L2 round trip under
@@ -192,8 +205,8 @@ __device__ __forceinline__ void store_act4(unsigned short* Xh, unsigned short* X
         *reinterpret_cast<uint2*>(Xl + off) = l;
     } else {
         uint2 o;
-        o.x = RELU ? pack_relu_h16x2<true>(a, b) : pack_h16x2<true>(a, b);
-        o.y = RELU ? pack_relu_h16x2<true>(c, d) : pack_h16x2<true>(c, d);
+        o.x = RELU ? pack_relu_h16x2<kF16>(a, b) : pack_h16x2<kF16>(a, b);
+        o.y = RELU ? pack_relu_h16x2<kF16>(c, d) : pack_h16x2<kF16>(c, d);
         *reinterpret_cast<uint2*>(Xh + off) = o;
     }
 }
@@ -261,7 +274,7 @@ __device__ __forceinline__ void store_z(__amdgpu_buffer_rsrc_t rs_z, unsigned zo
     if constexpr (AP) {
         xstore4(rs_z, ok ? zoff + (unsigned)d0 * 4u : kOobX, z);
     } else {
-        const uint2 zb = pack_h16x4<true>(z.x, z.y, z.z, z.w);
+        const uint2 zb = pack_h16x4<kF16>(z.x, z.y, z.z, z.w);
         i32x2 zi; zi.x = (int)zb.x; zi.y = (int)zb.y;
         __builtin_amdgcn_raw_buffer_store_b64(zi, rs_z, (int)(ok ? zoff + (unsigned)d0 * 2u : kOobX), 0, 0);
     }
@@ -754,22 +767,29 @@ static int launch_decode(const FusedQP& p, hipStream_t s, const char* tag) {
 
 // mode: 0 = f16 (half weights, half activations), 1 = f16-pairs (weight pairs), 2 = f16x3 (weight and activation pairs, fp32 Z)
 int head_kv_fused_wide(const FusedKVP& p, int mode, hipStream_t s) {
-    if (mode == 2) return launch_kv<ModeX3>(p, s, "head_kv_fused_f16x3");
-    if (mode == 1) return launch_kv<ModePairs>(p, s, "head_kv_fused_f16");
-    return launch_kv<ModeF16>(p, s, "head_kv_fused_f16");
+    if (mode == 2) return launch_kv<ModeX3>(p, s, "head_kv_fused" CIAOSR_H16_SUFFIX "x3");
+    if constexpr (kF16) {
+        if (mode == 1) return launch_kv<ModePairs>(p, s, "head_kv_fused_f16");
+        return launch_kv<ModeF16>(p, s, "head_kv_fused_f16");
+    }
+    return CIAOSR_ERR_UNSUPPORTED;       // the bf16 build carries the pair mode only
 }
 
 int head_decode_fused_wide(const FusedQP& p, int mode, hipStream_t s) {
-    if (mode == 2) return launch_decode<ModeX3>(p, s, "head_decode_fused_f16x3");
-    if (mode == 1) return launch_decode<ModePairs>(p, s, "head_decode_fused_f16");
-    return launch_decode<ModeF16>(p, s, "head_decode_fused_f16");
+    if (mode == 2) return launch_decode<ModeX3>(p, s, "head_decode_fused" CIAOSR_H16_SUFFIX "x3");
+    if constexpr (kF16) {
+        if (mode == 1) return launch_decode<ModePairs>(p, s, "head_decode_fused_f16");
+        return launch_decode<ModeF16>(p, s, "head_decode_fused_f16");
+    }
+    return CIAOSR_ERR_UNSUPPORTED;
 }
 
 }  // namespace wide
+}  // namespace CIAOSR_H16_NS
 }  // namespace ciaosr
 
-#ifdef CIAOSR_PROBE
+#if defined(CIAOSR_PROBE) && CIAOSR_F16
 extern "C" int ciaosr_debug_probe_x3_read(unsigned long long* host, int n_words) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::wide::g_xprobe), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(ciaosr::f16::wide::g_xprobe), (size_t)n_words * 8) == hipSuccess ? 0 : -1;
 }
 #endif

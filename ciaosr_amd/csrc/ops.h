@@ -190,6 +190,10 @@ int head_decode_fused(const FusedQP& p, hipStream_t s);
     int head_kv_chain_h16(const FusedKVP& kp, const ciaosr_head_weights_t* w, const void* blob, int pairs, int grid_w, int* flag,     \
                           hipStream_t s);                                                                                             \
     int pack_fragments_h16(const float* W, int ld, int N, int K, void* P, hipStream_t s, int residual, void* P_lo);                   \
+    namespace wide {                                                                                                                  \
+    int head_kv_fused_wide(const FusedKVP& p, int mode, hipStream_t s);                                                               \
+    int head_decode_fused_wide(const FusedQP& p, int mode, hipStream_t s);                                                            \
+    }                                                                                                                                 \
     int dense_h16_tiles(int H, int W);                                                                                                \
     int cast_group_h16(const float* X, int ldx, unsigned short* Xb, int ldxb, int col, long HW, hipStream_t s);                       \
     int dense_layer_h16(float* X, int ldx, unsigned short* Xb, int ldxb, int H, int W, int l, const void* frag16,                     \
@@ -207,12 +211,9 @@ namespace b16 { CIAOSR_H16_DECLS }
 namespace f16 { CIAOSR_H16_DECLS }
 #undef CIAOSR_H16_DECLS
 
-// head_fused_wide.hip: the fused head of the IEEE-half modes with one wide workgroup per CU.  mode 0 = f16 (256 rows), 1 = f16-pairs
-// (256 rows, weights as hi + lo pairs), 2 = f16x3 (128 rows, weights AND activations as pairs: three MFMAs per product, Z in fp32)
-namespace wide {
-int head_kv_fused_wide(const FusedKVP& p, int mode, hipStream_t s);
-int head_decode_fused_wide(const FusedQP& p, int mode, hipStream_t s);
-}
+// (head_fused_wide_h16.hip, declared per element type above: the fused head with one wide workgroup per CU.  mode 0 = f16 (256 rows), 1 = f16-pairs
+// (256 rows, weights as hi + lo pairs), 2 = f16x3 / bf16x3 (128 rows, weights AND activations as pairs: three MFMAs per product, Z in fp32); the
+// bf16 build carries mode 2 only)
 
 // precision of an entry point: the suffix of its name
 enum Prec { kF32 = 0, kBF16 = 1, kF16 = 2 };

@@ -211,7 +211,7 @@ def tile_finalize(E, Wt):
     return out
 
 
-PRECISIONS = ('fp32', 'bf16', 'bf16-single', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast')       # what Options(precision) / test_cfg.precision accept
+PRECISIONS = ('fp32', 'bf16', 'bf16-single', 'bf16x3', 'f16', 'f16-pairs', 'f16x3', 'f16x3-fast')       # what Options(precision) / test_cfg.precision accept
 
 
 class Options:
@@ -221,7 +221,9 @@ class Options:
                hi + lo pairs unless bf16_single), 'f16' (IEEE half MFMA inputs, one MFMA per product, saturating at 65504)
                'f16-pairs' (= 'f16' with f16_pairs=1: half activations, every weight as a half hi + lo pair) or 'f16x3'
                (= 'f16' with f16_pairs=2, the fp32-tolerance fast mode: the head's weights AND activations as half pairs, three
-               MFMAs per product, fp32 trunk and tables, half cs_attn contractions): selects the _f32 / _bf16 / _f16 entry point.
+               MFMAs per product, fp32 trunk and tables, half cs_attn contractions), 'bf16-single' (= 'bf16' with bf16_single=1: one
+               bf16 weight per product, packed with error feedback + calibrated biases), 'bf16x3' (= 'bf16' with f16_pairs=2: the bf16
+               counterpart of 'f16x3'): selects the _f32 / _bf16 / _f16 entry point.
     the rest   fields of ciaosr_options_t (include/ciaosr_hip.h): result-equivalent route choices; 0 = default.
     Immutable; `replace()` returns a modified copy."""
     _C_FIELDS = ('head_route', 'csa_composed_min', 'dense_min_tiles', 'scatter_small_max', 'kv_rows', 'decode_rows', 'bf16_single', 'dense_direct', 'csa_scores_gemm', 'csa_attn_tile128', 'query_grid_w', 'f16_pairs')
@@ -231,6 +233,9 @@ class Options:
         if precision in ('bf16-single', 'bf16_single'):          # ONE bf16 weight per product, error-feedback rounding + calibrated biases (head_hip.py)
             precision = 'bf16'
             kw.setdefault('bf16_single', 1)
+        if precision in ('bf16x3', 'bf16-x3'):                   # bf16 hi + lo weights AND activations in the head (three MFMAs per product, fp32 Z), fp32 trunk
+            precision = 'bf16'                                   # and tables, bf16 cs_attn contractions: the bf16 counterpart of 'f16x3' (round 6)
+            kw.setdefault('f16_pairs', 2)
         if precision in ('f16-pairs', 'f16_pairs', 'f16p'):      # the fp32-tolerance fast mode: half activations, half weight PAIRS
             precision = 'f16'
             kw.setdefault('f16_pairs', 1)

@@ -211,22 +211,20 @@ class LocalImplicitSRSWINIR(LocalImplicitSRNet):
     allow_f16_substitute = False
 
     def effective_options(self, options=None):
-        """`precision='bf16'` does not exist on the SwinIR-CiaoSR head (C = 180: 1620-wide logit dot products in front of the 4-way
-        softmax).  Measured against the reference at BASELINE config 5's own size, the bf16 mode's 8-bit ACTIVATIONS (weights as pairs
-        cannot help) leave rms 3.6e-3 = 0.060 dB at a 30-dB quality level, six times the 0.01 dB gate, where IEEE half -- same MFMA
-        rate, 11-bit activations -- measures 0.0007 dB.  A mode that misses the gate is not offered, and is not swapped silently either:
-        the call raises CiaoSRHipError unless the caller opts in to the substitution -- `test_cfg.allow_f16_substitute = True` (or the
-        generator attribute of the same name): one warning, then the f16 kernels, and `effective_options(opt).precision == 'f16'` is what
-        labels and ratios must be taken from (bench.py does).  The launch-bound SwinIR trunk is fp32 in every mode."""
+        """`precision='bf16'` on the SwinIR-CiaoSR head (C = 180: 1620-wide logit dot products in front of the 4-way softmax) runs as
+        **'bf16x3'**: bf16 hi + lo pairs for the head's weights AND activations (three MFMAs per product, fp32 Z, fp32 tables).  The
+        plain bf16 forms -- 8-bit ACTIVATIONS, whatever the weights -- leave rms 3.6e-3 = 0.060 dB at a 30-dB quality level against the
+        reference at BASELINE config 5's own size, six times the 0.01 dB gate, and are therefore not offered here; the pair form measures
+        max |delta| 9.3e-6, 0.00005 dB (inside the fp32 tolerance) at 3.83 ms per image (f16: 3.71, fp32: 4.97).  `effective_options(opt)`
+        returns what actually runs (labels and ratios are taken from it: bench.py does).  Rounds 4-5 refused the name or, on
+        `test_cfg.allow_f16_substitute = True` (or the generator attribute), ran the IEEE-half kernels with a warning: that opt-in is
+        still honoured.  The launch-bound SwinIR trunk is fp32 in every mode."""
         opt = hip_ops.as_options(options)
-        if opt.precision != 'bf16':
+        if opt.precision != 'bf16' or opt.f16_pairs == 2:      # 'bf16x3' asked for by name
             return opt
         cfg = getattr(self, '_test_cfg', None)
         if not (self.allow_f16_substitute or (cfg is not None and cfg.get('allow_f16_substitute', False))):
-            raise CiaoSRHipError("precision='bf16' is not offered on the SwinIR-CiaoSR head: its 8-bit activations in front of the local "
-                                 "attention measure 0.060 dB at 30 dB on BASELINE config 5, six times the 0.01 dB PSNR gate.  Use "
-                                 "precision='f16' (same MFMA rate, 0.0007 dB), or set test_cfg.allow_f16_substitute = True to have "
-                                 "'bf16' run the f16 kernels")
+            return opt.replace(f16_pairs=2, bf16_single=0)     # bf16 as named: the pair form that meets the gate
         if not LocalImplicitSRSWINIR._warned_bf16:
             import warnings
             warnings.warn("precision='bf16' on the SwinIR-CiaoSR head does not meet the 0.01 dB PSNR gate (8-bit activations in front of "

@@ -125,7 +125,11 @@ typedef struct ciaosr_options {
                              * layers): max |delta| 4.0e-4, rms 4.6e-5 on the Gaussian-weight C3 tile at 2/3 of the time -- but NOT an
                              * fp32-tolerance mode in general: on trained-like trunk statistics (features of magnitude > 100, tests/golden/
                              * stress_rdn_x4_*) the half activations of the dense layers leave max |delta| 2.7e-2 (rms 2.6e-4; both PSNR
-                             * gates hold, 0.0006 dB at 30 dB).  It is a PSNR-gated mode like 1; the fp32-tolerance mode is 2 */
+                             * gates hold, 0.0006 dB at 30 dB).  It is a PSNR-gated mode like 1; the fp32-tolerance mode is 2.
+                             * _bf16 entries (round 6): 2 = "bf16x3", the same form with bf16 hi + lo pairs (16 mantissa bits per operand;
+                             * frag16 + frag16_lo of every head layer are read, bf16_single is ignored, fp32 trunk and tables, bf16
+                             * cs_attn contractions): full C3 tile max |delta| 1.8e-4, SwinIR-CiaoSR (C = 180) at BASELINE config 5's
+                             * size 9.3e-6 -- the bf16 mode that meets the gate there (8-bit bf16 activations: 0.060 dB); 1 and 3 are ignored by the _bf16 entries */
 } ciaosr_options_t;
 
 /* ---- layout plumbing -------------------------------------------------------------------- */

@@ -378,6 +378,22 @@ def test_chained_head_blob_sizes_follow_the_documented_stream_layout():
     assert lib.ciaosr_head_chain_bytes(ctypes.byref(head(64, local_size=3)), 0) == 0
 
 
+def r_swin_bf16_is_x3():
+    """`precision='bf16'` on the SwinIR-CiaoSR generator resolves to 'bf16x3' (f16_pairs = 2), to 'f16' with the rounds-4/5 opt-in."""
+    import warnings
+    from ciaosr_amd import hip_ops
+    m = _swinir_ciaosr(dict(scale=3.3))
+    eff = m.generator.effective_options('bf16')
+    ok = eff.precision == 'bf16' and eff.f16_pairs == 2 and eff.bf16_single == 0
+    ok = ok and m.generator.effective_options(hip_ops.Options('bf16-single')).f16_pairs == 2
+    ok = ok and m.generator.effective_options('f16').precision == 'f16' and m.generator.effective_options('bf16x3').f16_pairs == 2
+    m.test_cfg['allow_f16_substitute'] = True
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        ok = ok and m.generator.effective_options('bf16').precision == 'f16'
+    return ok
+
+
 def test_round6_host_logic_options_tile_batch_and_error_feedback_rounding():
     """Host-side pieces of round 6 that need no GPU: `Options('bf16-single')` is the bf16 entry with `bf16_single = 1`; the default
     tile batch is 7 wherever the dense layers run a 16x32-pixel-tile kernel (fp32 Winograd F(4x4) and, now, the 16-bit modes) and 8 with
@@ -388,6 +404,9 @@ def test_round6_host_logic_options_tile_batch_and_error_feedback_rounding():
     o = hip_ops.Options('bf16-single')
     assert o.precision == 'bf16' and o.bf16_single == 1 and o.suffix == 'bf16' and 'bf16-single' in hip_ops.PRECISIONS
     assert hip_ops.Options('bf16').bf16_single == 0
+    x3 = hip_ops.Options('bf16x3')
+    assert x3.precision == 'bf16' and x3.f16_pairs == 2 and x3.suffix == 'bf16' and 'bf16x3' in hip_ops.PRECISIONS
+    assert r_swin_bf16_is_x3()
     r = _small_restorer(dict(scale=2))
     assert r.tile_batch() == 7 and r.tile_batch(hip_ops.Options('f16')) == 7 and r.tile_batch(hip_ops.Options('bf16-single')) == 7
     assert r.tile_batch(hip_ops.Options('f16', dense_direct=1)) == 8 and r.tile_batch(hip_ops.Options('fp32', dense_direct=1)) == 8
