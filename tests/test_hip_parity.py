@@ -1125,13 +1125,14 @@ def test_condition_stress_trained_like_trunk_vs_reference(dev, size):
 
 
 @pytest.mark.parametrize('precision', ['f16', 'bf16', 'bf16-single', 'f16-pairs'])
-@pytest.mark.parametrize('hw', [(150, 170), (192, 192)])
+@pytest.mark.parametrize('hw', [(150, 170), (192, 192), (24, 1040)])
 def test_dense_16bit_wide_tiles_vs_12x12_kernels_and_batch_invariance(dev, precision, hw):
     """The round-6 cut of the 16-bit dense layers (dense_h16_wide_kernel: 16x32-pixel tiles, one persistent 512-thread workgroup per CU,
     weights and halo patch through LDS by DMA, waves split pixels -- no K-slice reduction) against the 12x12-tile kernels it replaces on
     big maps (`dense_direct = 1` keeps them): the same 16-bit products summed in a different order, so the RDN trunk features agree to the
-    element type's rounding of the layer outputs -- on a map that is a whole number of tiles and on a ragged one (150 x 170: partial
-    tiles in both directions, halo outside the image on every side); against the fp32 trunk both sit at the same distance.  And a
+    element type's rounding of the layer outputs -- on a map that is a whole number of tiles, on a ragged one (150 x 170: partial
+    tiles in both directions, halo outside the image on every side) and on a strip (24 x 1040: a second tile row that is half empty, 33
+    tile columns with an 16-pixel remainder); against the fp32 trunk both sit at the same distance.  And a
     tile's result must not depend on the batch it is computed in: images [A, B, A, B, A] and a batch of seven through one batched call
     (persistent workgroups walking several items; the 8 x 32 tile shape of small launches against the 16 x 32 shape of full ones) are bitwise
     the single-image results."""
